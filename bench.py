@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py -- MLPG frames/sec on BASELINE.json configs[1] (per GPU: 256 utterances
+x T=1000 x 60-dim mgc static+delta+delta-delta = 180 columns, float64, per-frame
+variances, standard 3 windows), weak-scaled over N GPUs (one process per GPU,
+independent shards, no data-path collective).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (one mlpg_hip_forward launch through the C
+ABI) over the rank's resident batch.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+WINDOWS = [
+    (0, 0, np.array([1.0])),
+    (1, 1, np.array([-0.5, 0.0, 0.5])),
+    (1, 1, np.array([1.0, -2.0, 1.0])),
+]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--static-dim", type=int, default=60)
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 generic, 2 wave")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--gather", action="store_true", help="also time an RCCL all-gather of the outputs (reported separately)")
+    return ap.parse_args()
+
+
+def cpu_baseline(T, D, seconds):
+    """Oracle (C port of the reference's numpy/bandmat/Cython path) timed on ONE host core
+    on a bounded sample of the same workload."""
+    from oracle import mlpg as O
+    O.build()
+    rng = np.random.RandomState(1234)
+    m = rng.randn(4, T, D)
+    v = rng.rand(4, T, D) + 0.1
+    t0 = time.perf_counter()
+    O.mlpg_batch(m, v, WINDOWS)
+    per4 = time.perf_counter() - t0
+    n = int(max(8, min(4096, seconds / max(per4 / 4, 1e-6))))
+    n -= n % 4
+    reps = n // 4
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.mlpg_batch(m, v, WINDOWS)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n * T / dt,
+        "unit": "frames/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%d utterances x T=%d x D=%d float64 through oracle/mlpg_oracle.c (C restatement of "
+                  "paramgen.mlpg, bit-exact vs the reference), %.1f s on 1 core of %d" % (n, T, D, dt, os.cpu_count()),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from nnmnkwii_amd import _hip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    B, T, sd = args.batch, args.frames, args.static_dim
+    D = 3 * sd
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    means = torch.randn(B, T, D, dtype=torch.float64, device=dev, generator=gen)
+    variances = torch.rand(B, T, D, dtype=torch.float64, device=dev, generator=gen) + 0.1
+
+    def step():
+        return _hip.forward(means, variances, WINDOWS, None, algo=args.algo, want_status=True)
+
+    for _ in range(args.warmup):
+        out, status = step()
+    torch.cuda.synchronize(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        out, status = step()
+        ev[k][1].record()
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # kernel time from HIP events recorded on the stream the kernel is launched on
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    assert int(status.abs().max().item()) == 0, "a system was not positive definite"
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    gather_ms = None
+    if args.gather and world > 1:
+        full = torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=dev)
+        dist.all_gather_into_tensor(full, out)
+        torch.cuda.synchronize(dev)
+        barrier()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(full, out)
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        # parity spot check outside the timed region (oracle = checker only)
+        from oracle import mlpg as O
+        O.build()
+        yo = O.mlpg(means[0].cpu().numpy(), variances[0].cpu().numpy(), WINDOWS)
+        err = float(np.abs(out[0].cpu().numpy() - yo).max() / np.abs(yo).max())
+        assert err < 1e-9, err
+
+        frames = world * B * T * args.steps
+        alg_bytes = 56.0 * sd * B * T            # 56 B per (frame, static dim) per launch
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        res = {
+            "metric": "MLPG frames/sec (batch, 60-dim mgc x3 windows)",
+            "value": frames / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: %d utterances/GPU x T=%d x %d-dim mgc static+delta+delta-delta "
+                            "(%d columns), float64, per-frame variances, std 3 windows; mlpg_hip_forward via C ABI"
+                            % (B, T, sd, D),
+                "batch_per_gpu": B, "frames": T, "static_dim": sd, "algo": args.algo,
+                "parallelism": "batch-sharded x%d, no data-path collective" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms": kern_ms,
+                "algorithmic_bytes": alg_bytes,
+            },
+            "parity_rel_err_vs_oracle": err,
+        }
+        if gather_ms is not None:
+            res["allgather_ms"] = gather_ms
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(T, D, args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

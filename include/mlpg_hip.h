@@ -1,0 +1,147 @@
+/*
+ * include/mlpg_hip.h -- C ABI of libmlpg_hip.so (MI355X / gfx950).
+ *
+ * The reference (r9y9/nnmnkwii) has no FFI for this path: its native code is a
+ * set of Cython extension modules imported by name.  This header is therefore
+ * the boundary *we* introduce beneath the reference's Python signatures; each
+ * entry point names the reference routine(s) it replaces (paths relative to
+ * /root/reference/nnmnkwii/).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - All data pointers are DEVICE pointers on `device`, row-major, densely
+ *    packed.  Pointers suffixed _h are HOST pointers (tiny window tables).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
+ *    only enqueue work; they never synchronise.  `status`/`path_len` are filled
+ *    on the stream: read them after synchronising it.
+ *  - dtype codes: MLPG_HIP_F32 = 0, MLPG_HIP_F64 = 1.
+ *  - Return value: 0 on success, negative MLPG_HIP_E* on argument/runtime
+ *    errors (text via mlpg_hip_last_error()).  Numerical failures (a leading
+ *    minor that is not positive definite) are reported per system in `status`,
+ *    never as a return code.
+ *  - Windows are the reference's `(l, u, coeff)` triples packed as win_l_h[nw],
+ *    win_u_h[nw], win_coef_h[sum(l+u+1)] (float64), window 0 first
+ *    (paramgen/_mlpg.py:13-50).  Feature columns are window-major: column
+ *    w*static_dim + d (paramgen/_mlpg.py:187-188).
+ *  - Batches are the reference's zero-padded (B, Tmax, D) arrays
+ *    (util/__init__.py:44-66, datasets/__init__.py:152-218); `lengths` (device
+ *    int32[B], or NULL for "all Tmax") gives the valid frames per utterance.
+ *    Output frames >= lengths[b] are zero-filled.
+ *  - Re-entrant per (device, stream); internal scratch is cached per device
+ *    and released by mlpg_hip_shutdown().  No OpenMP, no global mutable state
+ *    besides that cache and the last-error string (thread-local).
+ */
+#ifndef MLPG_HIP_H_
+#define MLPG_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLPG_HIP_F32 0
+#define MLPG_HIP_F64 1
+
+#define MLPG_HIP_EINVAL (-1)   /* bad argument (shape, dtype, window table)   */
+#define MLPG_HIP_ERUNTIME (-2) /* HIP runtime error (launch, malloc, device)  */
+#define MLPG_HIP_ENOMEM (-3)   /* scratch allocation failed                   */
+
+/* variance modes */
+#define MLPG_HIP_VAR_FRAME 0   /* var is (B, Tmax, D)                         */
+#define MLPG_HIP_VAR_GLOBAL 1  /* var is (D,), tiled over frames (_mlpg.py:169-170) */
+#define MLPG_HIP_VAR_UNIT 2    /* var == NULL: unit variances (_mlpg.py:297-373) */
+
+/* kernel selection for the forward/backward solves */
+#define MLPG_HIP_ALGO_AUTO 0    /* wave-per-system when it applies, else generic */
+#define MLPG_HIP_ALGO_GENERIC 1 /* thread-per-system, factor in HBM scratch       */
+#define MLPG_HIP_ALGO_WAVE 2    /* wave-per-system, factor in registers           */
+
+int mlpg_hip_abi_version(void);
+const char *mlpg_hip_last_error(void);
+int mlpg_hip_device_count(void);
+/* Frees the per-device scratch caches. */
+void mlpg_hip_shutdown(void);
+
+/*
+ * MLPG forward, batched.  Replaces paramgen.mlpg (paramgen/_mlpg.py:92-199)
+ * and everything beneath it: build_win_mats (:13-50), build_poe (:53-89),
+ * _bandmat/tensor.pyx dot_mv_plus_equals (:20-64) / dot_mm_plus_equals
+ * (:82-174) and _bandmat/linalg.pyx solveh (:290-304) = _cholesky_banded
+ * (:36-104) + _solve_triangular_banded (:106-176) x2.
+ *
+ *   out[b, :, d] = (sum_w W_w^T diag(tau_w) W_w)^-1 sum_w W_w^T (tau_w * mu_w)
+ *   tau_w = 1/var evaluated in the INPUT dtype (:188), zeroed on the first/last
+ *   max(max(l,u)) frames for w >= 1 (:177,191-193); all later arithmetic float64.
+ *
+ *   mean : (B, Tmax, D) dtype      var : per var_mode      out : (B, Tmax, D/nw) dtype
+ *   status : int32 (B * D/nw): 0, or k = "k-th leading minor not positive
+ *            definite" (linalg.pyx:79-82); may be NULL.
+ */
+int mlpg_hip_forward(int device, void *stream, int dtype, int algo,
+                     const void *mean, const void *var, int var_mode,
+                     const int32_t *lengths, int B, int Tmax, int D,
+                     int num_windows, const int32_t *win_l_h,
+                     const int32_t *win_u_h, const double *win_coef_h,
+                     void *out, int32_t *status);
+
+/*
+ * MLPG backward (gradient w.r.t. the means), batched.  Replaces
+ * paramgen.mlpg_grad (paramgen/_mlpg.py:202-281; the reference solves a dense
+ * T x T right-hand side with LAPACK dgbsv per static dim and window, :275).
+ * Here: z = P_d^-1 o_d with the same banded factor as the forward, then
+ *   grad[b, t, w*sd+d] = tau_w[t] * sum_k coeff_w[l_w+k] * z[t+k]      (O(T)).
+ *
+ *   var      : as in mlpg_hip_forward (in_dtype); grad_out : (B, Tmax, sd) in_dtype
+ *   grad_mean: (B, Tmax, D) out_dtype (the reference returns float32, :248)
+ * With var_mode == MLPG_HIP_VAR_UNIT this is also the backward of
+ * autograd.UnitVarianceMLPG (autograd/_impl/mlpg.py:145-172: R^T . grad).
+ */
+int mlpg_hip_backward(int device, void *stream, int in_dtype, int out_dtype,
+                      int algo, const void *var, int var_mode,
+                      const void *grad_out, const int32_t *lengths, int B,
+                      int Tmax, int D, int num_windows,
+                      const int32_t *win_l_h, const int32_t *win_u_h,
+                      const double *win_coef_h, void *grad_mean,
+                      int32_t *status);
+
+/*
+ * Trailing-zero trim.  Replaces preprocessing.trim_zeros_frames with trim="b"
+ * (preprocessing/generic.py:291-332) applied to every utterance of a padded
+ * (N, T, D) batch: lengths[n] = number of frames left after dropping trailing
+ * frames whose sum_d |x| < eps.
+ */
+int mlpg_hip_trim_lengths(int device, void *stream, int dtype, const void *X,
+                          int N, int T, int D, double eps, int32_t *lengths);
+
+/*
+ * fastdtw(x, y, radius, dist=L2) for N utterance pairs.  Replaces the
+ * per-pair call in DTWAligner.transform (preprocessing/alignment.py:48-54;
+ * fastdtw itself is the third-party package slaypni/fastdtw, see
+ * oracle/dtw_oracle.c for the restated semantics and tie rule).
+ *
+ *   X : (N, Tx, D) float64, Y : (N, Ty, D) float64, lenx/leny : int32[N] valid
+ *   frames (>= 1).  path_i/path_j : int32 (N, Tx+Ty) 0-based index pairs,
+ *   path_len : int32[N] (0 if the pair failed), cost : float64[N] = accumulated
+ *   distance D[len_x, len_y] (alignment.py:50, before the :51 normalisation).
+ */
+int mlpg_hip_fastdtw_l2(int device, void *stream, const double *X,
+                        const double *Y, const int32_t *lenx,
+                        const int32_t *leny, int N, int Tx, int Ty, int D,
+                        int radius, int32_t *path_i, int32_t *path_j,
+                        int32_t *path_len, double *cost);
+
+/*
+ * Gather rows along the warping path into zero-padded outputs.  Replaces
+ * alignment.py:52-54,72-73:  out[n, k, :] = src[n, path[n, k], :] for
+ * k < path_len[n], zeros after.  src (N, Tsrc, D), out (N, Tout, D), same dtype.
+ */
+int mlpg_hip_gather_path(int device, void *stream, int dtype, const void *src,
+                         const int32_t *path, const int32_t *path_len, int N,
+                         int Tsrc, int path_stride, int D, int Tout, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLPG_HIP_H_ */

@@ -1,0 +1,257 @@
+"""ctypes binding of libmlpg_hip.so (include/mlpg_hip.h) + thin tensor helpers.
+
+PyTorch is used here for device memory, streams and nothing else: every
+numerical result comes from the hand-written HIP kernels behind the C ABI.
+There is NO CPU fallback: if the shared library or a GPU is missing, the calls
+raise.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+F32, F64 = 0, 1
+VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
+ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libmlpg_hip.so")
+
+EXPORTS = (
+    "mlpg_hip_abi_version",
+    "mlpg_hip_last_error",
+    "mlpg_hip_device_count",
+    "mlpg_hip_shutdown",
+    "mlpg_hip_forward",
+    "mlpg_hip_backward",
+    "mlpg_hip_trim_lengths",
+    "mlpg_hip_fastdtw_l2",
+    "mlpg_hip_gather_path",
+)
+
+
+class HipExtensionError(RuntimeError):
+    """The HIP extension is missing, failed to load, or a call into it failed."""
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load libmlpg_hip.so (once). Raises HipExtensionError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(SO_PATH):
+            raise HipExtensionError(
+                "nnmnkwii_amd: %s is missing -- build it with `python nnmnkwii_amd/csrc/build.py` "
+                "(or __graft_entry__.build()); there is no CPU fallback" % SO_PATH)
+        try:
+            L = ctypes.CDLL(SO_PATH)
+        except OSError as e:  # pragma: no cover
+            raise HipExtensionError("nnmnkwii_amd: cannot load %s: %s" % (SO_PATH, e))
+        vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+        L.mlpg_hip_abi_version.restype = ci
+        L.mlpg_hip_abi_version.argtypes = []
+        L.mlpg_hip_last_error.restype = ctypes.c_char_p
+        L.mlpg_hip_last_error.argtypes = []
+        L.mlpg_hip_device_count.restype = ci
+        L.mlpg_hip_device_count.argtypes = []
+        L.mlpg_hip_shutdown.restype = None
+        L.mlpg_hip_shutdown.argtypes = []
+        L.mlpg_hip_forward.restype = ci
+        L.mlpg_hip_forward.argtypes = [ci, vp, ci, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
+        L.mlpg_hip_backward.restype = ci
+        L.mlpg_hip_backward.argtypes = [ci, vp, ci, ci, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
+        L.mlpg_hip_trim_lengths.restype = ci
+        L.mlpg_hip_trim_lengths.argtypes = [ci, vp, ci, vp, ci, ci, ci, cd, vp]
+        L.mlpg_hip_fastdtw_l2.restype = ci
+        L.mlpg_hip_fastdtw_l2.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
+        L.mlpg_hip_gather_path.restype = ci
+        L.mlpg_hip_gather_path.argtypes = [ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise HipExtensionError("%s failed (%d): %s" % (what, rc, lib().mlpg_hip_last_error().decode()))
+
+
+def torch_mod():
+    import torch
+    return torch
+
+
+def require_gpu(device=None):
+    """Return a torch.device for the GPU to use, or raise (no CPU fallback)."""
+    torch = torch_mod()
+    lib()
+    if not torch.cuda.is_available():
+        raise HipExtensionError("nnmnkwii_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                                "there is no CPU fallback")
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise HipExtensionError("nnmnkwii_amd computes on GPU only, got device %s" % device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def pack_windows(windows):
+    """Reference `(l, u, coeff)` triples -> (int32 l[], int32 u[], float64 coeff[]) host arrays."""
+    wl, wu, wc = [], [], []
+    for l, u, coeff in windows:
+        l, u = int(l), int(u)
+        assert l >= 0 and u >= 0                     # paramgen/_mlpg.py:44
+        coeff = np.asarray(coeff, dtype=np.float64).ravel()
+        assert len(coeff) == l + u + 1               # paramgen/_mlpg.py:45
+        wl.append(l)
+        wu.append(u)
+        wc.append(coeff)
+    return (np.ascontiguousarray(wl, dtype=np.int32), np.ascontiguousarray(wu, dtype=np.int32),
+            np.ascontiguousarray(np.concatenate(wc)))
+
+
+def _dt(t):
+    torch = torch_mod()
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float64:
+        return F64
+    raise HipExtensionError("unsupported dtype %s (float32/float64 only)" % t.dtype)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _np(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch_mod().cuda.current_stream(device).cuda_stream)
+
+
+def forward(mean, var, windows, lengths=None, algo=ALGO_AUTO, want_status=True):
+    """Batched MLPG on device tensors.
+
+    mean (B, T, D) cuda float32/float64 contiguous; var: same shape, (D,) or None
+    (unit variances); lengths: cuda int32 (B,) or None.  Returns (out (B,T,sd),
+    status int32 (B*sd) or None), both on the device, enqueued on the current
+    stream (no synchronisation).
+    """
+    torch = torch_mod()
+    assert mean.is_cuda and mean.dim() == 3 and mean.is_contiguous()
+    B, T, D = mean.shape
+    nw = len(windows)
+    wl, wu, wc = pack_windows(windows)
+    if var is None:
+        mode = VAR_UNIT
+    elif var.dim() == 1:
+        mode = VAR_GLOBAL
+        assert var.shape[0] == D and var.dtype == mean.dtype and var.is_contiguous() and var.device == mean.device
+    else:
+        mode = VAR_FRAME
+        assert var.shape == mean.shape and var.dtype == mean.dtype and var.is_contiguous()
+        assert var.device == mean.device
+    if lengths is not None:
+        assert lengths.dtype == torch.int32 and lengths.shape == (B,) and lengths.device == mean.device
+    out = torch.empty((B, T, D // nw), dtype=mean.dtype, device=mean.device)
+    status = torch.empty((B * (D // nw),), dtype=torch.int32, device=mean.device) if want_status else None
+    rc = lib().mlpg_hip_forward(mean.device.index, _stream(mean.device), _dt(mean), algo, _p(mean), _p(var), mode,
+                                _p(lengths), B, T, D, nw, _np(wl), _np(wu), _np(wc), _p(out), _p(status))
+    _check(rc, "mlpg_hip_forward")
+    return out, status
+
+
+def backward(var, grad_out, windows, D, lengths=None, out_dtype=None, algo=ALGO_AUTO, want_status=True):
+    """Batched MLPG gradient w.r.t. means on device tensors.
+
+    grad_out (B, T, sd); var (B, T, D), (D,) or None (unit).  Returns
+    (grad_mean (B, T, D) in out_dtype (default float32), status).
+    """
+    torch = torch_mod()
+    assert grad_out.is_cuda and grad_out.dim() == 3 and grad_out.is_contiguous()
+    B, T, sd = grad_out.shape
+    nw = len(windows)
+    assert sd * nw == D
+    wl, wu, wc = pack_windows(windows)
+    if var is None:
+        mode = VAR_UNIT
+    elif var.dim() == 1:
+        mode = VAR_GLOBAL
+        assert var.shape[0] == D and var.dtype == grad_out.dtype and var.is_contiguous()
+    else:
+        mode = VAR_FRAME
+        assert var.shape == (B, T, D) and var.dtype == grad_out.dtype and var.is_contiguous()
+    if out_dtype is None:
+        out_dtype = torch.float32
+    grad = torch.empty((B, T, D), dtype=out_dtype, device=grad_out.device)
+    status = torch.empty((B * sd,), dtype=torch.int32, device=grad_out.device) if want_status else None
+    rc = lib().mlpg_hip_backward(grad_out.device.index, _stream(grad_out.device), _dt(grad_out), _dt(grad), algo,
+                                 _p(var), mode, _p(grad_out), _p(lengths), B, T, D, nw, _np(wl), _np(wu), _np(wc),
+                                 _p(grad), _p(status))
+    _check(rc, "mlpg_hip_backward")
+    return grad, status
+
+
+def trim_lengths(X, eps=1e-7):
+    """int32 (N,) device tensor: frames left after the trailing-zero trim of each utterance."""
+    torch = torch_mod()
+    assert X.is_cuda and X.dim() == 3 and X.is_contiguous()
+    N, T, D = X.shape
+    lengths = torch.empty((N,), dtype=torch.int32, device=X.device)
+    rc = lib().mlpg_hip_trim_lengths(X.device.index, _stream(X.device), _dt(X), _p(X), N, T, D, float(eps),
+                                     _p(lengths))
+    _check(rc, "mlpg_hip_trim_lengths")
+    return lengths
+
+
+def fastdtw_l2(X, Y, lenx, leny, radius=1):
+    """fastdtw paths for N pairs. Returns (path_i, path_j (N, Tx+Ty) int32, path_len (N,), cost (N,))."""
+    torch = torch_mod()
+    assert X.is_cuda and Y.is_cuda and X.dtype == torch.float64 and Y.dtype == torch.float64
+    assert X.is_contiguous() and Y.is_contiguous() and X.dim() == 3 and Y.dim() == 3
+    N, Tx, D = X.shape
+    assert Y.shape[0] == N and Y.shape[2] == D
+    Ty = Y.shape[1]
+    dev = X.device
+    path_i = torch.empty((N, Tx + Ty), dtype=torch.int32, device=dev)
+    path_j = torch.empty((N, Tx + Ty), dtype=torch.int32, device=dev)
+    path_len = torch.empty((N,), dtype=torch.int32, device=dev)
+    cost = torch.empty((N,), dtype=torch.float64, device=dev)
+    rc = lib().mlpg_hip_fastdtw_l2(dev.index, _stream(dev), _p(X), _p(Y), _p(lenx), _p(leny), N, Tx, Ty, D,
+                                   int(radius), _p(path_i), _p(path_j), _p(path_len), _p(cost))
+    _check(rc, "mlpg_hip_fastdtw_l2")
+    return path_i, path_j, path_len, cost
+
+
+def gather_path(src, path, path_len, Tout):
+    """out[n, k] = src[n, path[n, k]] for k < path_len[n], zeros after. (N, Tout, D)."""
+    torch = torch_mod()
+    assert src.is_cuda and src.dim() == 3 and src.is_contiguous() and path.is_contiguous()
+    N, Tsrc, D = src.shape
+    out = torch.empty((N, Tout, D), dtype=src.dtype, device=src.device)
+    rc = lib().mlpg_hip_gather_path(src.device.index, _stream(src.device), _dt(src), _p(src), _p(path),
+                                    _p(path_len), N, Tsrc, path.shape[1], D, Tout, _p(out))
+    _check(rc, "mlpg_hip_gather_path")
+    return out
+
+
+def raise_on_status(status, sd):
+    """Raise the reference's LinAlgError for the first failing (utterance, dim) system."""
+    st = status.cpu().numpy()
+    bad = np.flatnonzero(st)
+    if bad.size:
+        k = int(st[bad[0]])
+        # scipy.linalg.LinAlgError is numpy.linalg.LinAlgError (linalg.pyx:79-82)
+        raise np.linalg.LinAlgError("%d-th leading minor not positive definite" % k)

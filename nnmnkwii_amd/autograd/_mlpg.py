@@ -1,0 +1,187 @@
+"""Differentiable MLPG on PyTorch-ROCm tensors.
+
+Host-side mirror of /root/reference/nnmnkwii/autograd/_impl/mlpg.py.  Forward
+and backward are single launches of the HIP kernels behind
+``include/mlpg_hip.h``; tensors stay on the GPU (CPU tensors are accepted for
+drop-in compatibility and are staged through the GPU).
+"""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from .. import _hip
+from ..paramgen import _mlpg as G
+
+# Reading the per-system status word costs one device synchronisation per call;
+# it is what turns a non-positive-definite system into the reference's
+# LinAlgError.  Training loops that know their variances are positive can turn
+# it off.
+CHECK_STATUS = True
+
+
+def _to_gpu(t, dev):
+    return t.detach().to(dev).contiguous()
+
+
+class MLPG(Function):
+    """Generic MLPG as an autograd function, ``f : (T, D) -> (T, static_dim)``.
+
+    Same contract as the reference class (autograd/_impl/mlpg.py:8-67): 2-D
+    inputs only, float32 output, gradient w.r.t. ``means`` only.  Unlike the
+    reference it runs on the GPU: forward = ``mlpg_hip_forward``, backward =
+    ``mlpg_hip_backward`` (O(T) per system instead of the reference's dense
+    ``T x T`` solve).
+    """
+
+    @staticmethod
+    def forward(ctx, means, variances, windows):
+        assert means.dim() == 2  # we cannot do MLPG on minibatch (reference :44)
+        ctx.windows = windows
+        ctx.save_for_backward(means, variances)
+        assert means.size() == variances.size()
+        dev = _hip.require_gpu(means.device if means.is_cuda else None)
+        m = _to_gpu(means, dev)
+        if m.dtype not in (torch.float32, torch.float64):
+            m = m.to(torch.float64)
+        v = _to_gpu(variances, dev).to(m.dtype)
+        y, status = _hip.forward(m[None], v[None], windows, want_status=CHECK_STATUS)
+        if CHECK_STATUS:
+            _hip.raise_on_status(status, y.shape[-1])
+        return y[0].to(torch.float32).to(means.device)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        means, variances = ctx.saved_tensors
+        dev = _hip.require_gpu(means.device if means.is_cuda else None)
+        v = _to_gpu(variances, dev)
+        if v.dtype not in (torch.float32, torch.float64):
+            v = v.to(torch.float64)
+        go = _to_gpu(grad_output, dev).to(v.dtype)
+        grad, status = _hip.backward(v[None], go[None], ctx.windows, means.shape[-1],
+                                     out_dtype=torch.float32, want_status=CHECK_STATUS)
+        if CHECK_STATUS:
+            _hip.raise_on_status(status, go.shape[-1])
+        return grad[0].to(device=means.device, dtype=means.dtype), None, None
+
+
+# (data_ptr, device, shape, version) -> (windows, T) or None, so that the full
+# check of R against the registered matrix happens once per tensor.
+_R_CACHE = {}
+
+
+def _identify_R(R):
+    """Recover (windows, T) if R came from paramgen.unit_variance_mlpg_matrix."""
+    key = (R.data_ptr(), str(R.device), tuple(R.shape), R._version, R.dtype)
+    if key in _R_CACHE:
+        return _R_CACHE[key]
+    found = None
+    if R.dim() == 2 and R.shape[0] > 0 and R.shape[1] % R.shape[0] == 0:
+        T, K = R.shape
+        flat = R.detach().reshape(-1)
+        idx = (np.arange(97, dtype=np.int64) * 2654435761 + 12345) % max(T * K, 1)
+        sample = flat[torch.from_numpy(idx).to(R.device)].to(torch.float32).cpu().numpy()
+        fp = (int(T), int(K)) + tuple(sample.tolist())
+        reg = G.lookup_unit_variance_matrix(fp)
+        if reg is not None:
+            windows, T_reg, R_reg = reg
+            same = torch.equal(R.detach().to(torch.float32).cpu(), torch.from_numpy(R_reg))
+            if same and T_reg == T:
+                found = ([(l, u, np.asarray(c)) for l, u, c in windows], T)
+    if len(_R_CACHE) > 64:
+        _R_CACHE.clear()
+    _R_CACHE[key] = found
+    return found
+
+
+class UnitVarianceMLPG(Function):
+    """MLPG for unit-variance inputs, ``y = R mu`` (autograd/_impl/mlpg.py:70-172).
+
+    ``R`` must come from :func:`nnmnkwii_amd.paramgen.unit_variance_mlpg_matrix`;
+    it is recognised by content, and the product ``R mu`` (and ``R^T g`` in the
+    backward) is then evaluated by the banded unit-variance kernels -- O(T) per
+    column and no dense ``(T, nw*T)`` traffic.  Accepts ``(T, D)``,
+    ``(T*nw, static_dim)``, ``(B, T, D)`` and ``(B, T*nw, static_dim)`` means.
+    """
+
+    @staticmethod
+    def forward(ctx, means, R):
+        ctx.save_for_backward(means, R)
+        ctx.num_windows = R.shape[-1] // R.shape[0]
+        T = R.shape[0]
+        ident = _identify_R(R)
+        if ident is None:
+            raise _hip.HipExtensionError(
+                "unit_variance_mlpg: R was not produced by nnmnkwii_amd.paramgen.unit_variance_mlpg_matrix "
+                "(or was modified); the banded MI355X kernels need the window set it was built from")
+        windows, _ = ident
+        ctx.windows = windows
+        nw = ctx.num_windows
+        dim = means.dim()
+        if dim == 2:
+            T_, D = means.shape
+            B = 1
+            m3 = means.reshape(B, T_, D)
+        else:
+            B, T_, D = means.shape
+            m3 = means
+        reshaped = not (T == T_)
+        dev = _hip.require_gpu(means.device if means.is_cuda else None)
+        m3 = _to_gpu(m3, dev)
+        if m3.dtype not in (torch.float32, torch.float64):
+            m3 = m3.to(torch.float32)
+        if reshaped:
+            # (B, nw*T, sd) -> frame-major (B, T, nw*sd), the layout the kernels read
+            static_dim = D
+            m3 = m3.view(B, nw, T, static_dim).transpose(1, 2).contiguous().view(B, T, nw * static_dim)
+        else:
+            static_dim = D // nw
+        out, _ = _hip.forward(m3, None, windows, want_status=False)
+        out = out.to(device=means.device, dtype=means.dtype)
+        if dim == 2:
+            return out.view(-1, static_dim)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        means, R = ctx.saved_tensors
+        T = R.shape[0]
+        nw = ctx.num_windows
+        dim = means.dim()
+        if dim == 2:
+            T_, D = means.shape
+            B = 1
+            grad_output = grad_output.reshape(B, T, -1)
+        else:
+            B, T_, D = means.shape
+        reshaped = not (T == T_)
+        dev = _hip.require_gpu(means.device if means.is_cuda else None)
+        go = _to_gpu(grad_output, dev)
+        if go.dtype not in (torch.float32, torch.float64):
+            go = go.to(torch.float32)
+        sd = go.shape[-1]
+        grad, _ = _hip.backward(None, go, ctx.windows, nw * sd, out_dtype=go.dtype, want_status=False)
+        if reshaped:
+            grad = grad.view(B, T, nw, sd).transpose(1, 2).contiguous().view(B, nw * T, sd)
+        grad = grad.to(device=means.device, dtype=means.dtype)
+        if dim == 2:
+            return grad.view(-1, D), None
+        return grad, None
+
+
+def mlpg(means, variances, windows):
+    """Maximum Likelihood Parameter Generation on tensors (autograd/_impl/mlpg.py:175-199).
+
+    ``means`` ``(T, D)`` (requires_grad allowed), ``variances`` ``(T, D)`` or a
+    global ``(D,)``, ``windows`` as in :func:`nnmnkwii_amd.paramgen.mlpg`.
+    """
+    T, D = means.size()
+    if variances.dim() == 1 and variances.shape[0] == D:
+        variances = variances.expand(T, D)
+    assert means.size() == variances.size()
+    return MLPG.apply(means, variances, windows)
+
+
+def unit_variance_mlpg(R, means):
+    """Unit-variance MLPG; note the argument order ``(R, means)``
+    (autograd/_impl/mlpg.py:202-217)."""
+    return UnitVarianceMLPG.apply(means, R)

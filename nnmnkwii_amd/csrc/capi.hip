@@ -1,0 +1,289 @@
+// C-ABI entry points of libmlpg_hip.so (declared in include/mlpg_hip.h).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+
+namespace mlpg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- per-device grow-only scratch ------------------------------------------
+namespace {
+constexpr int kMaxDevices = 16, kSlots = 4;
+struct Slot {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+};
+Slot g_slots[kMaxDevices][kSlots];
+std::mutex g_mu;
+}  // namespace
+
+void *scratch(int device, int slot, size_t bytes) {
+  if (device < 0 || device >= kMaxDevices || slot < 0 || slot >= kSlots) {
+    set_error("scratch: bad device/slot %d/%d", device, slot);
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  Slot &s = g_slots[device][slot];
+  if (s.bytes >= bytes && s.ptr) return s.ptr;
+  if (s.ptr) {
+    // the previous users of this buffer may still be running on some stream
+    (void)hipDeviceSynchronize();
+    (void)hipFree(s.ptr);
+    s.ptr = nullptr;
+    s.bytes = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  void *p = nullptr;
+  if (hipMalloc(&p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    want = bytes;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("scratch: hipMalloc of %zu bytes failed", bytes);
+      return nullptr;
+    }
+  }
+  s.ptr = p;
+  s.bytes = want;
+  return p;
+}
+
+namespace {
+
+int pack_windows(int nw, const int32_t *wl, const int32_t *wu, const double *wc, WinSet *ws) {
+  if (nw < 1 || nw > kMaxWindows || !wl || !wu || !wc) {
+    set_error("num_windows must be in [1, %d] and the window tables non-NULL", kMaxWindows);
+    return MLPG_HIP_EINVAL;
+  }
+  memset(ws, 0, sizeof(*ws));
+  ws->nw = nw;
+  int off = 0;
+  for (int w = 0; w < nw; ++w) {
+    if (wl[w] < 0 || wu[w] < 0 || wl[w] > kMaxExtent || wu[w] > kMaxExtent) {
+      set_error("window %d: extents (l=%d, u=%d) must be in [0, %d]", w, wl[w], wu[w], kMaxExtent);
+      return MLPG_HIP_EINVAL;
+    }
+    const int n = wl[w] + wu[w] + 1;
+    if (off + n > kMaxCoef) {
+      set_error("too many window coefficients (> %d)", kMaxCoef);
+      return MLPG_HIP_EINVAL;
+    }
+    ws->l[w] = wl[w];
+    ws->u[w] = wu[w];
+    ws->off[w] = off;
+    for (int i = 0; i < n; ++i) ws->c[off + i] = wc[off + i];
+    off += n;
+    if (wl[w] + wu[w] > ws->q) ws->q = wl[w] + wu[w];
+    const int m = wl[w] > wu[w] ? wl[w] : wu[w];
+    if (m > ws->mw) ws->mw = m;
+  }
+  return 0;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+    if (device != prev && hipSetDevice(device) != hipSuccess) ok = false;
+    target = device;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0 && prev != target) (void)hipSetDevice(prev);
+  }
+  int target = -1;
+};
+
+int check_common(int B, int Tmax, int D, int nw) {
+  if (B < 0 || Tmax < 0 || D < 0 || nw < 1) {
+    set_error("negative size (B=%d, Tmax=%d, D=%d) or num_windows=%d", B, Tmax, D, nw);
+    return MLPG_HIP_EINVAL;
+  }
+  if (D % nw != 0) {
+    set_error("D=%d is not a multiple of num_windows=%d", D, nw);
+    return MLPG_HIP_EINVAL;
+  }
+  return 0;
+}
+
+int solve_entry(int device, void *stream, int in_dtype, int out_dtype, int algo, bool backward, const void *mean,
+                const void *var, int var_mode, const void *grad_out, const int32_t *lengths, int B, int Tmax,
+                int D, int nw, const int32_t *wl, const int32_t *wu, const double *wc, void *out,
+                int32_t *status) {
+  if (int rc = check_common(B, Tmax, D, nw)) return rc;
+  if ((in_dtype != MLPG_HIP_F32 && in_dtype != MLPG_HIP_F64) ||
+      (out_dtype != MLPG_HIP_F32 && out_dtype != MLPG_HIP_F64)) {
+    set_error("dtype must be MLPG_HIP_F32 or MLPG_HIP_F64");
+    return MLPG_HIP_EINVAL;
+  }
+  if (var_mode < 0 || var_mode > 2 || (var_mode != MLPG_HIP_VAR_UNIT && !var)) {
+    set_error("bad var_mode %d / NULL var", var_mode);
+    return MLPG_HIP_EINVAL;
+  }
+  if (B * (long)Tmax * D > 0 && (!out || (backward ? !grad_out : !mean))) {
+    set_error("NULL data pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  WinSet ws;
+  if (int rc = pack_windows(nw, wl, wu, wc, &ws)) return rc;
+  if (B == 0 || Tmax == 0 || D == 0) return 0;
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  Problem p;
+  p.mean = mean;
+  p.var = var;
+  p.grad_out = grad_out;
+  p.lengths = lengths;
+  p.out = out;
+  p.status = status;
+  p.var_mode = var_mode;
+  p.B = B;
+  p.Tmax = Tmax;
+  p.D = D;
+  p.sd = D / nw;
+  hipStream_t st = (hipStream_t)stream;
+  if (algo == MLPG_HIP_ALGO_WAVE && !wave_supported(p, ws)) {
+    set_error("MLPG_HIP_ALGO_WAVE does not support this problem (T=%d, half-bandwidth %d)", Tmax, ws.q);
+    return MLPG_HIP_EINVAL;
+  }
+  const bool use_wave = algo == MLPG_HIP_ALGO_WAVE || (algo == MLPG_HIP_ALGO_AUTO && wave_supported(p, ws));
+  if (use_wave) return launch_wave(st, in_dtype, out_dtype, backward, p, ws, device);
+  return launch_generic(st, in_dtype, out_dtype, backward, p, ws, device);
+}
+
+}  // namespace
+}  // namespace mlpg
+
+using namespace mlpg;
+
+extern "C" {
+
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 1; }
+
+__attribute__((visibility("default"))) const char *mlpg_hip_last_error(void) { return g_err; }
+
+__attribute__((visibility("default"))) int mlpg_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+__attribute__((visibility("default"))) void mlpg_hip_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  for (int d = 0; d < kMaxDevices; ++d)
+    for (int s = 0; s < kSlots; ++s)
+      if (g_slots[d][s].ptr) {
+        (void)hipSetDevice(d);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(g_slots[d][s].ptr);
+        g_slots[d][s] = Slot();
+      }
+  if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_forward(int device, void *stream, int dtype, int algo,
+                                                            const void *mean, const void *var, int var_mode,
+                                                            const int32_t *lengths, int B, int Tmax, int D,
+                                                            int num_windows, const int32_t *win_l_h,
+                                                            const int32_t *win_u_h, const double *win_coef_h,
+                                                            void *out, int32_t *status) {
+  return solve_entry(device, stream, dtype, dtype, algo, false, mean, var, var_mode, nullptr, lengths, B, Tmax, D,
+                     num_windows, win_l_h, win_u_h, win_coef_h, out, status);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_backward(int device, void *stream, int in_dtype, int out_dtype,
+                                                             int algo, const void *var, int var_mode,
+                                                             const void *grad_out, const int32_t *lengths, int B,
+                                                             int Tmax, int D, int num_windows,
+                                                             const int32_t *win_l_h, const int32_t *win_u_h,
+                                                             const double *win_coef_h, void *grad_mean,
+                                                             int32_t *status) {
+  return solve_entry(device, stream, in_dtype, out_dtype, algo, true, nullptr, var, var_mode, grad_out, lengths, B,
+                     Tmax, D, num_windows, win_l_h, win_u_h, win_coef_h, grad_mean, status);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_trim_lengths(int device, void *stream, int dtype, const void *X,
+                                                                 int N, int T, int D, double eps,
+                                                                 int32_t *lengths) {
+  if (N < 0 || T < 0 || D < 0 || (dtype != MLPG_HIP_F32 && dtype != MLPG_HIP_F64)) {
+    set_error("trim_lengths: bad arguments");
+    return MLPG_HIP_EINVAL;
+  }
+  if (N == 0) return 0;
+  if (!lengths || (!X && (long)T * D > 0)) {
+    set_error("trim_lengths: NULL pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  return launch_trim((hipStream_t)stream, dtype, X, N, T, D, eps, lengths);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_fastdtw_l2(int device, void *stream, const double *X,
+                                                               const double *Y, const int32_t *lenx,
+                                                               const int32_t *leny, int N, int Tx, int Ty, int D,
+                                                               int radius, int32_t *path_i, int32_t *path_j,
+                                                               int32_t *path_len, double *cost) {
+  if (N < 0 || Tx < 1 || Ty < 1 || D < 1 || radius < 1) {
+    set_error("fastdtw: need N >= 0, Tx, Ty, D >= 1 and radius >= 1");
+    return MLPG_HIP_EINVAL;
+  }
+  if (N == 0) return 0;
+  if (!X || !Y || !lenx || !leny || !path_i || !path_j || !path_len || !cost) {
+    set_error("fastdtw: NULL pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  return launch_fastdtw((hipStream_t)stream, device, X, Y, lenx, leny, N, Tx, Ty, D, radius, path_i, path_j,
+                        path_len, cost);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_gather_path(int device, void *stream, int dtype, const void *src,
+                                                                const int32_t *path, const int32_t *path_len, int N,
+                                                                int Tsrc, int path_stride, int D, int Tout,
+                                                                void *out) {
+  if (N < 0 || Tsrc < 0 || D < 0 || Tout < 0 || path_stride < 0 ||
+      (dtype != MLPG_HIP_F32 && dtype != MLPG_HIP_F64)) {
+    set_error("gather_path: bad arguments");
+    return MLPG_HIP_EINVAL;
+  }
+  if (N == 0 || Tout == 0 || D == 0) return 0;
+  if (!src || !path || !path_len || !out) {
+    set_error("gather_path: NULL pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  return launch_gather((hipStream_t)stream, dtype, src, path, path_len, N, Tsrc, path_stride, D, Tout, out);
+}
+
+}  // extern "C"

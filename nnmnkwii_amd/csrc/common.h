@@ -1,0 +1,65 @@
+// Shared host/device definitions for libmlpg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/mlpg_hip.h"
+
+namespace mlpg {
+
+constexpr int kMaxWindows = 8;
+constexpr int kMaxCoef = 48;   // sum over windows of (l+u+1)
+constexpr int kMaxExtent = 4;  // max l or u of any window (half-bandwidth <= 8)
+
+// Window table passed BY VALUE as a kernel argument (lands in SGPRs / the
+// kernarg segment; no device allocation, no __constant__ upload to order).
+struct WinSet {
+  int nw;
+  int q;   // half-bandwidth of P: max_w (l_w + u_w)            (_mlpg.py:72-73)
+  int mw;  // edge width: max_w max(l_w, u_w)                   (_mlpg.py:177)
+  int l[kMaxWindows];
+  int u[kMaxWindows];
+  int off[kMaxWindows];  // offset of window w's coefficients in c[]
+  double c[kMaxCoef];
+};
+
+// Problem description shared by the forward and backward kernels.
+struct Problem {
+  const void *mean;      // (B, Tmax, D)   forward only
+  const void *var;       // per var_mode
+  const void *grad_out;  // (B, Tmax, sd)  backward only
+  const int32_t *lengths;
+  void *out;             // forward: (B, Tmax, sd); backward: (B, Tmax, D)
+  int32_t *status;
+  int var_mode;
+  int B, Tmax, D, sd;
+};
+
+void set_error(const char *fmt, ...);
+// Grow-only per-device scratch. Returns nullptr (and sets the error) on failure.
+void *scratch(int device, int slot, size_t bytes);
+
+// launchers (one per translation unit)
+int launch_generic(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
+                   int device);
+bool wave_supported(const Problem &p, const WinSet &w);
+int launch_wave(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
+                int device);
+int launch_trim(hipStream_t s, int dtype, const void *X, int N, int T, int D, double eps, int32_t *lengths);
+int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, const int32_t *lenx,
+                   const int32_t *leny, int N, int Tx, int Ty, int D, int radius, int32_t *path_i,
+                   int32_t *path_j, int32_t *path_len, double *cost);
+int launch_gather(hipStream_t s, int dtype, const void *src, const int32_t *path, const int32_t *path_len, int N,
+                  int Tsrc, int path_stride, int D, int Tout, void *out);
+
+#define MLPG_HIP_CHECK(expr)                                                        \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      ::mlpg::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return MLPG_HIP_ERUNTIME;                                                     \
+    }                                                                               \
+  } while (0)
+
+}  // namespace mlpg

@@ -1,0 +1,202 @@
+// Generic MLPG kernels: one THREAD per (utterance, static dim) system, any
+// window set with half-bandwidth <= 8, any T.  Adjacent lanes take adjacent
+// static dims so that every global access is a contiguous run of lanes
+// (feature columns are window-major: column w*sd + d).
+//
+// This is the fallback / cross-check path (algo = MLPG_HIP_ALGO_GENERIC); the
+// wave-per-system kernel in mlpg_wave.hip is the fast path for the common case.
+// The banded factor does not fit on chip at one system per lane, so it goes to
+// an HBM scratch laid out [frame][row][system] (system fastest = coalesced).
+//
+// Math (reference: paramgen/_mlpg.py:92-199, _bandmat/linalg.pyx:36-176):
+//   P[f+k, f] = sum_w sum_t c_w[l_w+f-t] c_w[l_w+f+k-t] tau_w[t]
+//   rhs[f]    = sum_w sum_t c_w[l_w+f-t] tau_w[t] mu_w[t]      (forward)
+//             = grad_out[f, d]                                  (backward)
+//   right-looking banded Cholesky fused with the forward substitution, then a
+//   reverse sweep for L^T x = z.  Backward epilogue:
+//   grad[t, w*sd+d] = tau_w[t] * sum_k c_w[l_w+k] x[t+k]   (paramgen/_mlpg.py:202-281)
+#include "common.h"
+
+namespace mlpg {
+namespace {
+
+template <typename T>
+__device__ __forceinline__ double recip_in_dtype(T v);
+template <>
+__device__ __forceinline__ double recip_in_dtype<float>(float v) {
+  return (double)__fdiv_rn(1.0f, v);  // reciprocal evaluated in float32 (_mlpg.py:188)
+}
+template <>
+__device__ __forceinline__ double recip_in_dtype<double>(double v) {
+  return 1.0 / v;
+}
+
+template <int Q, typename TIN, typename TOUT, bool BWD>
+__global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, double *__restrict__ scratch, long S) {
+  const long s = (long)blockIdx.x * 64 + threadIdx.x;
+  if (s >= S) return;
+  const int sd = p.sd, D = p.D, Tmax = p.Tmax;
+  const int b = (int)(s / sd), d = (int)(s % sd);
+  int T = p.lengths ? p.lengths[b] : Tmax;
+  T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
+  const TIN *mean = BWD ? nullptr : (const TIN *)p.mean + (size_t)b * Tmax * D;
+  const TIN *var = (const TIN *)p.var;
+  if (p.var_mode == MLPG_HIP_VAR_FRAME) var += (size_t)b * Tmax * D;
+  const TIN *gout = BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * sd : nullptr;
+  TOUT *out = (TOUT *)p.out + (size_t)b * Tmax * (BWD ? D : sd);
+  const int mw = ws.mw, nw = ws.nw, var_mode = p.var_mode;
+
+  auto tau = [&](int w, int t) -> double {
+    // zero precision on the edge frames of the dynamic windows; Python's
+    // precisions[-0:] slice makes mw == 0 zero the whole column (_mlpg.py:191-193)
+    if (w != 0 && (mw == 0 || t < mw || t >= T - mw)) return 0.0;
+    if (var_mode == MLPG_HIP_VAR_UNIT) return 1.0;
+    const TIN v = (var_mode == MLPG_HIP_VAR_GLOBAL) ? var[w * sd + d] : var[(size_t)t * D + w * sd + d];
+    return recip_in_dtype<TIN>(v);
+  };
+
+  constexpr int R = Q + 2;  // scratch rows per frame: 1/L_ff, L_{f+1..f+Q, f}, z_f
+  double pend[Q + 1][Q + 1];
+  double rp[Q + 1];
+#pragma unroll
+  for (int j = 0; j <= Q; ++j) {
+    rp[j] = 0.0;
+#pragma unroll
+    for (int k = 0; k <= Q; ++k) pend[j][k] = 0.0;
+  }
+
+  int bad = 0;
+  for (int f = 0; f < T; ++f) {
+    double pk[Q + 1];
+#pragma unroll
+    for (int k = 0; k <= Q; ++k) pk[k] = 0.0;
+    double rhs = BWD ? (double)gout[(size_t)f * sd + d] : 0.0;
+    for (int w = 0; w < nw; ++w) {
+      const int l = ws.l[w], u = ws.u[w];
+      const double *c = ws.c + ws.off[w];
+      const int t0 = f - u < 0 ? 0 : f - u;
+      const int t1 = f + l > T - 1 ? T - 1 : f + l;
+      for (int t = t0; t <= t1; ++t) {
+        const double a = c[l + f - t] * tau(w, t);
+        if (!BWD) rhs += a * (double)mean[(size_t)t * D + w * sd + d];
+#pragma unroll
+        for (int k = 0; k <= Q; ++k) {
+          const int idx = l + f + k - t;
+          if (idx <= l + u && f + k < T) pk[k] += a * c[idx];
+        }
+      }
+    }
+    double v[Q + 1];
+#pragma unroll
+    for (int k = 0; k <= Q; ++k) v[k] = pk[k] + pend[0][k];
+    if (v[0] <= 0.0) {  // NaN passes, as in linalg.pyx:78
+      bad = f + 1;
+      break;
+    }
+    const double iv0 = 1.0 / v[0];
+    const double siv0 = sqrt(iv0);
+    const double zf = (rhs + rp[0]) * siv0;
+    double *sc = scratch + ((size_t)f * R) * S + s;
+    sc[0] = siv0;
+#pragma unroll
+    for (int k = 1; k <= Q; ++k) {
+      const double Lk = v[k] * siv0;
+      sc[(size_t)k * S] = Lk;
+      rp[k - 1] = rp[k] - Lk * zf;
+    }
+    sc[(size_t)(Q + 1) * S] = zf;
+    // trailing update of the next Q columns (linalg.pyx:93-95), shifted one
+    // column to the left so that pend[0] is always "the current frame"
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+#pragma unroll
+      for (int l = 0; l <= Q; ++l) {
+        double nv = pend[k + 1][l];
+        if (l + k + 1 <= Q) nv -= v[l + k + 1] * v[k + 1] * iv0;
+        pend[k][l] = nv;
+      }
+    }
+  }
+
+  if (p.status) p.status[s] = bad;
+  const int ncol = BWD ? nw : 1;
+  if (bad) T = 0;  // failed system: zero-fill everything
+
+  // reverse sweep: L^T x = z
+  double xw[Q + 1];
+#pragma unroll
+  for (int k = 0; k <= Q; ++k) xw[k] = 0.0;
+  for (int f = T - 1; f >= 0; --f) {
+    double *sc = scratch + ((size_t)f * R) * S + s;
+    double x = sc[(size_t)(Q + 1) * S];
+#pragma unroll
+    for (int k = 1; k <= Q; ++k) x -= sc[(size_t)k * S] * xw[k];
+    x *= sc[0];
+#pragma unroll
+    for (int k = Q; k >= 2; --k) xw[k] = xw[k - 1];
+    if constexpr (Q >= 1) xw[1] = x;
+    if (BWD)
+      sc[(size_t)(Q + 1) * S] = x;
+    else
+      out[(size_t)f * sd + d] = (TOUT)x;
+  }
+
+  if (BWD) {
+    for (int t = 0; t < T; ++t) {
+      for (int w = 0; w < nw; ++w) {
+        const int l = ws.l[w], u = ws.u[w];
+        const double *c = ws.c + ws.off[w];
+        double g = 0.0;
+        for (int k = -l; k <= u; ++k) {
+          const int tt = t + k;
+          if (tt >= 0 && tt < T) g += c[l + k] * scratch[((size_t)tt * R + (Q + 1)) * S + s];
+        }
+        out[(size_t)t * D + w * sd + d] = (TOUT)(tau(w, t) * g);
+      }
+    }
+  }
+  // zero the padding frames (and everything, for a failed system)
+  for (int t = T; t < Tmax; ++t)
+    for (int w = 0; w < ncol; ++w) out[(size_t)t * (BWD ? D : sd) + w * sd + d] = (TOUT)0;
+}
+
+template <int Q, typename TIN, typename TOUT, bool BWD>
+int launch_q(hipStream_t st, const Problem &p, const WinSet &w, int device) {
+  const long S = (long)p.B * p.sd;
+  if (S == 0 || p.Tmax == 0) return 0;
+  const size_t bytes = sizeof(double) * (size_t)(Q + 2) * (size_t)p.Tmax * (size_t)S;
+  double *sc = (double *)scratch(device, 0, bytes);
+  if (!sc) return MLPG_HIP_ENOMEM;
+  const unsigned grid = (unsigned)((S + 63) / 64);
+  hipLaunchKernelGGL((generic_kernel<Q, TIN, TOUT, BWD>), dim3(grid), dim3(64), 0, st, p, w, sc, S);
+  MLPG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <typename TIN, typename TOUT, bool BWD>
+int launch_t(hipStream_t st, const Problem &p, const WinSet &w, int device) {
+  if (w.q == 0) return launch_q<0, TIN, TOUT, BWD>(st, p, w, device);
+  if (w.q == 1) return launch_q<1, TIN, TOUT, BWD>(st, p, w, device);
+  if (w.q == 2) return launch_q<2, TIN, TOUT, BWD>(st, p, w, device);
+  if (w.q <= 4) return launch_q<4, TIN, TOUT, BWD>(st, p, w, device);
+  if (w.q <= 8) return launch_q<8, TIN, TOUT, BWD>(st, p, w, device);
+  set_error("half-bandwidth %d > 8 is not supported", w.q);
+  return MLPG_HIP_EINVAL;
+}
+
+}  // namespace
+
+int launch_generic(hipStream_t st, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
+                   int device) {
+  if (!backward) {
+    return dtype == MLPG_HIP_F32 ? launch_t<float, float, false>(st, p, w, device)
+                                 : launch_t<double, double, false>(st, p, w, device);
+  }
+  if (dtype == MLPG_HIP_F32)
+    return out_dtype == MLPG_HIP_F32 ? launch_t<float, float, true>(st, p, w, device)
+                                     : launch_t<float, double, true>(st, p, w, device);
+  return out_dtype == MLPG_HIP_F32 ? launch_t<double, float, true>(st, p, w, device)
+                                   : launch_t<double, double, true>(st, p, w, device);
+}
+
+}  // namespace mlpg

@@ -1,0 +1,223 @@
+"""MLPG on MI355X behind the signatures of ``nnmnkwii.paramgen``.
+
+Host-side mirror of /root/reference/nnmnkwii/paramgen/_mlpg.py.  All numerical
+work is done by the HIP kernels in ``nnmnkwii_amd/csrc`` through the C ABI in
+``include/mlpg_hip.h``; this module only validates arguments the way the
+reference does, moves arrays to the GPU and maps kernel status words to the
+reference's exceptions.
+"""
+import numpy as np
+
+from .. import _hip
+
+__all__ = [
+    "build_win_mats",
+    "mlpg",
+    "mlpg_grad",
+    "unit_variance_mlpg_matrix",
+    "reshape_means",
+    "full_window_mat",
+    "mlpg_batch",
+]
+
+
+class BandMat(object):
+    """Minimal stand-in for the reference's bandmat.BandMat container
+    (paramgen/_bandmat/core.pyx:20-87): ``l``, ``u``, ``data``, ``transposed``,
+    ``.T``, ``.size`` and ``.full()``.  LAPACK band layout:
+    ``full[j + i, j] == data[u + i, j]`` for ``i in [-u, l]``.
+    """
+
+    def __init__(self, l, u, data, transposed=False):
+        self.l = l
+        self.u = u
+        self.data = data
+        self.transposed = transposed
+        assert self.l >= 0 and self.u >= 0
+        assert self.data.ndim == 2 and self.data.shape[0] == self.l + self.u + 1
+
+    def __repr__(self):
+        return "BandMat(%r, %r, %r, transposed=%r)" % (self.l, self.u, self.data, self.transposed)
+
+    @property
+    def size(self):
+        return self.data.shape[1]
+
+    @property
+    def T(self):
+        return BandMat(self.u, self.l, self.data, transposed=not self.transposed)
+
+    def full(self):
+        l, u = (self.u, self.l) if self.transposed else (self.l, self.u)
+        n = self.size
+        m = np.zeros((n, n))
+        for i in range(-u, l + 1):
+            j = np.arange(max(0, -i), max(0, n + min(0, -i)))
+            m[j + i, j] = self.data[u + i, j]
+        return m.T if self.transposed else m
+
+
+def build_win_mats(windows, T):
+    """Window matrices as banded containers (reference: paramgen/_mlpg.py:13-50).
+
+    ``W[t, t+k] = win_coeff[l+k]`` for ``k in [-l, u]``, one ``T x T`` Toeplitz
+    band per window.
+    """
+    win_mats = []
+    for l, u, win_coeff in windows:
+        assert l >= 0 and u >= 0
+        assert len(win_coeff) == l + u + 1
+        data = np.tile(np.reshape(np.asarray(win_coeff, dtype=np.float64), (l + u + 1, 1)), T)
+        win_mats.append(BandMat(u, l, data).T)
+    return win_mats
+
+
+def full_window_mat(win_mats, T):
+    """Concatenated dense window matrix ``(T*num_windows, T)`` (paramgen/_mlpg.py:284-294)."""
+    return np.concatenate([w.full() for w in win_mats], axis=0) if len(win_mats) else np.zeros((0, T))
+
+
+def _as_float(a):
+    a = np.asarray(a)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64)
+    return a
+
+
+def mlpg_batch(means, variances, windows, lengths=None, algo=_hip.ALGO_AUTO, check=True, device=None):
+    """Batched MLPG over a zero-padded ``(B, Tmax, D)`` batch -- the GPU-native
+    form of the reference's per-utterance loop (util/__init__.py:44-66).
+
+    ``means``/``variances`` are numpy arrays or CUDA tensors (float32/float64);
+    ``variances`` may be ``(B, Tmax, D)``, a global ``(D,)`` or ``None`` (unit
+    variances).  ``lengths`` (B,) gives the valid frames per utterance; output
+    frames beyond it are zero.  Returns the same kind of object as ``means``,
+    shape ``(B, Tmax, D // len(windows))``.
+    """
+    torch = _hip.torch_mod()
+    is_np = not torch.is_tensor(means)
+    dev = _hip.require_gpu(device if is_np or not means.is_cuda else means.device)
+    if is_np:
+        means_h = np.ascontiguousarray(_as_float(means))
+        m = torch.from_numpy(means_h).to(dev)
+    else:
+        m = means.to(dev).contiguous()
+    assert m.dim() == 3
+    if variances is None:
+        v = None
+    elif torch.is_tensor(variances):
+        v = variances.to(device=dev, dtype=m.dtype).contiguous()
+    else:
+        v = torch.from_numpy(np.ascontiguousarray(np.asarray(variances))).to(device=dev, dtype=m.dtype)
+    if v is not None and v.dim() != 1:
+        assert v.shape == m.shape                         # paramgen/_mlpg.py:171
+    L = None
+    if lengths is not None:
+        L = torch.as_tensor(np.asarray(lengths) if not torch.is_tensor(lengths) else lengths).to(
+            device=dev, dtype=torch.int32).contiguous()
+    out, status = _hip.forward(m, v, windows, L, algo=algo, want_status=check)
+    if check:
+        _hip.raise_on_status(status, out.shape[-1])
+    if is_np:
+        return out.cpu().numpy()
+    return out
+
+
+def mlpg(mean_frames, variance_frames, windows):
+    """Maximum Likelihood Parameter Generation, ``(T, D) -> (T, static_dim)``.
+
+    Drop-in for ``nnmnkwii.paramgen.mlpg`` (paramgen/_mlpg.py:92-199): same
+    arguments, same output dtype (that of ``mean_frames``), accepts per-frame
+    ``(T, D)`` or global ``(D,)`` variances, raises ``AssertionError`` on a shape
+    mismatch and ``numpy.linalg.LinAlgError`` ("k-th leading minor not positive
+    definite") when a system is not positive definite.
+    """
+    mean_frames = np.asarray(mean_frames)
+    variance_frames = np.asarray(variance_frames)
+    dtype = mean_frames.dtype
+    T, D = mean_frames.shape
+    if not (variance_frames.ndim == 1 and variance_frames.shape[0] == D):
+        assert mean_frames.shape == variance_frames.shape
+        variance_frames = variance_frames[None]
+    y = mlpg_batch(mean_frames[None], variance_frames, windows)
+    return y[0].astype(dtype, copy=False)
+
+
+def mlpg_grad(mean_frames, variance_frames, windows, grad_output):
+    """Gradient of MLPG w.r.t. the means, ``float32 (T, D)``.
+
+    Drop-in for ``nnmnkwii.paramgen.mlpg_grad`` (paramgen/_mlpg.py:202-281).
+    The reference solves a dense ``T x T`` right-hand side per (dim, window);
+    the HIP kernel computes the same quantity in O(T):
+    ``grad[:, w*sd+d] = tau_w * (W_w P_d^-1 o_d)``.
+    """
+    torch = _hip.torch_mod()
+    mean_frames = np.asarray(mean_frames)
+    variance_frames = _as_float(variance_frames)
+    T, D = mean_frames.shape
+    dev = _hip.require_gpu()
+    dt = torch.float32 if variance_frames.dtype == np.float32 else torch.float64
+    v = torch.from_numpy(np.ascontiguousarray(variance_frames)).to(dev)
+    if v.dim() == 2:
+        assert v.shape == (T, D)
+        v = v[None]
+    go = torch.from_numpy(np.ascontiguousarray(np.asarray(grad_output))).to(device=dev, dtype=dt)[None].contiguous()
+    grad, status = _hip.backward(v, go, windows, D, out_dtype=torch.float32)
+    _hip.raise_on_status(status, D // len(windows))
+    return grad[0].cpu().numpy()
+
+
+# registry of MLPG matrices handed out by unit_variance_mlpg_matrix, so that
+# autograd.unit_variance_mlpg(R, means) can recover (windows, T) from R and run
+# the banded O(T) kernels instead of a dense (T x nw*T) product.
+_UV_REGISTRY = {}
+
+
+def _fingerprint(R):
+    """Cheap content key of an MLPG matrix: shape + a fixed sample of entries."""
+    T, K = R.shape
+    flat = R.reshape(-1)
+    n = flat.shape[0]
+    idx = (np.arange(97, dtype=np.int64) * 2654435761 + 12345) % max(n, 1)
+    return (int(T), int(K)) + tuple(np.asarray(flat[idx], dtype=np.float32).tolist())
+
+
+def unit_variance_mlpg_matrix(windows, T):
+    """MLPG matrix ``R = (sum_w W~_w^T W_w)^-1 [W~_0^T ... W~_{nw-1}^T]``, float32 ``(T, nw*T)``.
+
+    Drop-in for ``nnmnkwii.paramgen.unit_variance_mlpg_matrix``
+    (paramgen/_mlpg.py:297-373).  Column ``w*T + t`` of ``R`` is the response to
+    a unit mean at window ``w``, frame ``t``: the matrix is obtained with ONE
+    unit-variance MLPG launch over ``nw*T`` one-hot "dimensions" instead of a
+    dense banded inverse.  The returned array is a plain ndarray; it is also
+    remembered so that ``autograd.unit_variance_mlpg`` can use the banded kernels.
+    """
+    torch = _hip.torch_mod()
+    dev = _hip.require_gpu()
+    nw = len(windows)
+    K = nw * T
+    E = torch.zeros((T, nw, K), dtype=torch.float64, device=dev)
+    t = torch.arange(T, device=dev)
+    for w in range(nw):
+        E[t, w, w * T + t] = 1.0
+    out, status = _hip.forward(E.view(1, T, nw * K), None, windows)
+    _hip.raise_on_status(status, K)
+    R = out[0].to(torch.float32).cpu().numpy()
+    _UV_REGISTRY[_fingerprint(R)] = (tuple((int(l), int(u), tuple(np.asarray(c, dtype=np.float64).tolist()))
+                                           for l, u, c in windows), int(T), R)
+    return R
+
+
+def lookup_unit_variance_matrix(R_np_or_fp):
+    """(windows, T, R) registered for this matrix, or None."""
+    key = R_np_or_fp if isinstance(R_np_or_fp, tuple) else _fingerprint(R_np_or_fp)
+    return _UV_REGISTRY.get(key)
+
+
+def reshape_means(means, static_dim):
+    """``(T, D) -> (T*num_windows, static_dim)``; no-op if already reshaped
+    (paramgen/_mlpg.py:376-405)."""
+    T, D = means.shape
+    if D == static_dim:
+        return means
+    return means.reshape(T, -1, static_dim).transpose(1, 0, 2).reshape(-1, static_dim)

@@ -1,0 +1,85 @@
+"""DTW alignment of padded utterance batches on MI355X.
+
+Host-side mirror of /root/reference/nnmnkwii/preprocessing/alignment.py:9-76.
+The per-pair Python loop (trim -> fastdtw -> gather -> pad) of the reference
+becomes three batched HIP launches over all pairs: trailing-zero trim,
+multi-resolution fastdtw with an anti-diagonal DP, and a gather along the
+warping paths (C ABI: include/mlpg_hip.h).
+"""
+import numpy as np
+from numpy.linalg import norm
+
+from .. import _hip
+
+
+def _default_dist(x, y):
+    return norm(x - y)
+
+
+class DTWAligner(object):
+    """Align feature matrices with fastdtw (radius-limited multi-resolution DTW).
+
+    Same constructor and ``transform`` contract as the reference class: inputs
+    are zero-padded ``(N, Tx, D)`` / ``(N, Ty, D)`` arrays; outputs are two
+    ``(N, max(T_longer, longest path), D)`` arrays with the dtype of the longer
+    input.  ``dist`` must be left at its default (Euclidean ``norm(x - y)``):
+    the HIP kernel evaluates that local cost itself, and an arbitrary Python
+    callable cannot run on the GPU -- any other ``dist`` raises
+    ``NotImplementedError`` (there is no CPU fallback).
+
+    Attributes:
+        dist (function): Distance function (default L2).
+        radius (int): fastdtw radius.
+        verbose (int): Verbose flag.
+    """
+
+    def __init__(self, dist=_default_dist, radius=1, verbose=0):
+        self.verbose = verbose
+        self.dist = dist
+        self.radius = radius
+
+    def _paths(self, X, Y):
+        """Device-side trim + fastdtw. Returns torch tensors (Xd, Yd, path_i, path_j, path_len, cost, lenx, leny)."""
+        torch = _hip.torch_mod()
+        if self.dist is not _default_dist:
+            raise NotImplementedError(
+                "nnmnkwii_amd.DTWAligner evaluates the default Euclidean local cost on the GPU; "
+                "custom `dist` callables are not supported")
+        dev = _hip.require_gpu()
+        Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
+        Yd = torch.from_numpy(np.ascontiguousarray(Y)).to(dev)
+        if Xd.dtype not in (torch.float32, torch.float64):
+            Xd = Xd.to(torch.float64)
+        if Yd.dtype not in (torch.float32, torch.float64):
+            Yd = Yd.to(torch.float64)
+        lenx = _hip.trim_lengths(Xd)                       # alignment.py:49
+        leny = _hip.trim_lengths(Yd)
+        X64 = Xd if Xd.dtype == torch.float64 else Xd.to(torch.float64)   # fastdtw casts to float
+        Y64 = Yd if Yd.dtype == torch.float64 else Yd.to(torch.float64)
+        path_i, path_j, path_len, cost = _hip.fastdtw_l2(X64, Y64, lenx, leny, self.radius)   # :50
+        return Xd, Yd, path_i, path_j, path_len, cost, lenx, leny
+
+    def transform(self, XY):
+        torch = _hip.torch_mod()
+        X, Y = XY
+        assert X.ndim == 3 and Y.ndim == 3                 # alignment.py:42
+        longer = X if X.shape[1] > Y.shape[1] else Y       # :44
+        N = X.shape[0]
+        if N == 0:
+            return np.zeros_like(longer), np.zeros_like(longer)
+        Xd, Yd, path_i, path_j, path_len, cost, lenx, leny = self._paths(X, Y)
+        plen = path_len.cpu().numpy()
+        if (plen <= 0).any():
+            bad = int(np.flatnonzero(plen <= 0)[0])
+            raise ValueError("DTWAligner: pair %d has an empty (all-zero) utterance or could not be aligned" % bad)
+        T_out = max(int(longer.shape[1]), int(plen.max()))  # :55-71 (outputs only ever grow)
+        Xa = _hip.gather_path(Xd, path_i, path_len, T_out)  # :52-54,72
+        Ya = _hip.gather_path(Yd, path_j, path_len, T_out)  # :73
+        out_dtype = longer.dtype
+        Xa = Xa.cpu().numpy().astype(out_dtype, copy=False)
+        Ya = Ya.cpu().numpy().astype(out_dtype, copy=False)
+        if self.verbose > 0:
+            d = cost.cpu().numpy() / (lenx.cpu().numpy() + leny.cpu().numpy())   # :51
+            for idx in range(N):
+                print("{}, distance: {}".format(idx, d[idx]))
+        return Xa, Ya

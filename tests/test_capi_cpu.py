@@ -1,0 +1,120 @@
+"""CPU-side checks (-m "not gpu"): the C-ABI library loads and exports every
+symbol include/mlpg_hip.h declares, argument validation works without a GPU,
+and the host-side mirrors of the reference helpers behave like the reference."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cases import WINDOW_SETS
+from oracle import mlpg as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from nnmnkwii_amd.csrc import build as hip_build
+    hip_build.build()
+    from nnmnkwii_amd import _hip
+    return _hip.lib()
+
+
+def test_exports_match_header(L):
+    from nnmnkwii_amd import _hip
+    hdr = open(os.path.join(ROOT, "include", "mlpg_hip.h")).read()
+    declared = set(re.findall(r"\b(mlpg_hip_\w+)\s*\(", hdr))
+    assert declared == set(_hip.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.mlpg_hip_abi_version() == 1
+
+
+def test_argument_validation_without_gpu(L):
+    wl = np.array([0, 1], dtype=np.int32)
+    wu = np.array([0, 1], dtype=np.int32)
+    wc = np.array([1.0, -0.5, 0.0, 0.5])
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    fake = ctypes.c_void_p(64)
+    # D not a multiple of num_windows
+    rc = L.mlpg_hip_forward(0, None, 1, 0, fake, fake, 0, None, 1, 4, 5, 2, p(wl), p(wu), p(wc), fake, None)
+    assert rc == -1 and b"multiple" in L.mlpg_hip_last_error()
+    # bad dtype
+    rc = L.mlpg_hip_forward(0, None, 7, 0, fake, fake, 0, None, 1, 4, 4, 2, p(wl), p(wu), p(wc), fake, None)
+    assert rc == -1
+    # window extent too large
+    wl2 = np.array([0, 9], dtype=np.int32)
+    rc = L.mlpg_hip_forward(0, None, 1, 0, fake, fake, 0, None, 1, 4, 4, 2, p(wl2), p(wu), p(wc), fake, None)
+    assert rc == -1 and b"extents" in L.mlpg_hip_last_error()
+    # empty batch is a no-op
+    rc = L.mlpg_hip_forward(0, None, 1, 0, None, fake, 0, None, 0, 4, 4, 2, p(wl), p(wu), p(wc), None, None)
+    assert rc == 0
+    rc = L.mlpg_hip_fastdtw_l2(0, None, fake, fake, fake, fake, 1, 4, 4, 2, 0, fake, fake, fake, fake)
+    assert rc == -1
+    assert L.mlpg_hip_device_count() >= 0
+
+
+def test_pack_windows():
+    from nnmnkwii_amd import _hip
+    wl, wu, wc = _hip.pack_windows(WINDOW_SETS["wide3"])
+    assert wl.tolist() == [0, 2, 2] and wu.tolist() == [0, 2, 2] and wc.shape == (11,)
+    with pytest.raises(AssertionError):
+        _hip.pack_windows([(1, 1, np.array([1.0]))])
+
+
+def test_win_mats_and_full_window_mat():
+    # reference: tests/test_paramgen.py:62-79
+    from nnmnkwii_amd import paramgen as G
+    for wname, windows in WINDOW_SETS.items():
+        for T in (1, 2, 5, 10):
+            win_mats = G.build_win_mats(windows, T)
+            fulls = [w.full() for w in win_mats]
+            for (l, u, c), w, f in zip(windows, win_mats, fulls):
+                assert (w.l, w.u, w.transposed) == (l, u, True)
+                assert np.array_equal(f, O.window_matrix(l, u, c, T))
+                assert np.array_equal(w.T.full(), f.T)
+            assert np.array_equal(G.full_window_mat(win_mats, T), np.vstack(fulls))
+
+
+def test_reshape_means():
+    # reference: tests/test_paramgen.py:98-110
+    from nnmnkwii_amd import paramgen as G
+    T, sd = 10, 2
+    for windows in WINDOW_SETS.values():
+        means = np.random.RandomState(0).rand(T, sd * len(windows))
+        r = G.reshape_means(means, sd)
+        assert r.shape == (T * len(windows), sd)
+        assert G.reshape_means(r, sd) is r or len(windows) == 1
+        assert np.array_equal(r, O.reshape_means(means, sd))
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product raises instead of silently computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nnmnkwii_amd import HipExtensionError
+    from nnmnkwii_amd import paramgen as G
+    with pytest.raises(HipExtensionError):
+        G.mlpg(np.zeros((4, 3)), np.ones((4, 3)), WINDOW_SETS["std3"])
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "nnmnkwii_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+                assert "liboracle" not in src, fn
+
+
+def test_dtw_custom_dist_rejected():
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    a = DTWAligner(dist=lambda x, y: 0.0)
+    with pytest.raises(NotImplementedError):
+        a.transform((np.zeros((1, 3, 2)), np.zeros((1, 3, 2))))
+    d = DTWAligner()
+    assert d.radius == 1 and d.verbose == 0 and callable(d.dist)
