@@ -64,16 +64,17 @@ class MLPG(Function):
         return grad[0].to(device=means.device, dtype=means.dtype), None, None
 
 
-# (data_ptr, device, shape, version) -> (windows, T) or None, so that the full
-# check of R against the registered matrix happens once per tensor.
-_R_CACHE = {}
-
-
 def _identify_R(R):
-    """Recover (windows, T) if R came from paramgen.unit_variance_mlpg_matrix."""
-    key = (R.data_ptr(), str(R.device), tuple(R.shape), R._version, R.dtype)
-    if key in _R_CACHE:
-        return _R_CACHE[key]
+    """Recover (windows, T) if R came from paramgen.unit_variance_mlpg_matrix.
+
+    R is recognised by content (a sampled fingerprint, then a full comparison
+    against the registered matrix); the verdict is cached ON the tensor object
+    together with its version counter, so a training loop that keeps R around
+    pays for the check once.
+    """
+    cached = getattr(R, "_nnmnkwii_amd_ident", None)
+    if cached is not None and cached[0] == R._version:
+        return cached[1]
     found = None
     if R.dim() == 2 and R.shape[0] > 0 and R.shape[1] % R.shape[0] == 0:
         T, K = R.shape
@@ -87,9 +88,10 @@ def _identify_R(R):
             same = torch.equal(R.detach().to(torch.float32).cpu(), torch.from_numpy(R_reg))
             if same and T_reg == T:
                 found = ([(l, u, np.asarray(c)) for l, u, c in windows], T)
-    if len(_R_CACHE) > 64:
-        _R_CACHE.clear()
-    _R_CACHE[key] = found
+    try:
+        R._nnmnkwii_amd_ident = (R._version, found)
+    except AttributeError:  # pragma: no cover
+        pass
     return found
 
 

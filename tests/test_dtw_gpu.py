@@ -1,0 +1,124 @@
+"""GPU parity tests for the DTW path (-m gpu).
+
+Oracle = oracle/dtw.py (restatement of fastdtw; PARITY UNPINNED against the
+reference, see its header).  Bar: alignment indices bit-exact vs that oracle on
+continuous random data, accumulated cost within 1e-12 relative; tie-heavy
+inputs are held only to the reference's own assertions (shapes, norm).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dtw as OD
+
+pytestmark = pytest.mark.gpu
+
+
+def _tracks(rng, t, D):
+    return np.cumsum(rng.randn(t, D), 0) * 0.1
+
+
+def _run_pairs(pairs, radius=1):
+    from nnmnkwii_amd import _hip
+    N = len(pairs)
+    D = pairs[0][0].shape[1]
+    Tx = max(len(x) for x, _ in pairs)
+    Ty = max(len(y) for _, y in pairs)
+    X = np.zeros((N, Tx, D))
+    Y = np.zeros((N, Ty, D))
+    for n, (x, y) in enumerate(pairs):
+        X[n, :len(x)] = x
+        Y[n, :len(y)] = y
+    lenx = torch.tensor([len(x) for x, _ in pairs], dtype=torch.int32, device="cuda")
+    leny = torch.tensor([len(y) for _, y in pairs], dtype=torch.int32, device="cuda")
+    pi, pj, pl, cost = _hip.fastdtw_l2(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), lenx, leny, radius)
+    return pi.cpu().numpy(), pj.cpu().numpy(), pl.cpu().numpy(), cost.cpu().numpy()
+
+
+@pytest.mark.parametrize("radius", [1, 2, 3])
+def test_paths_bit_exact_vs_oracle(radius):
+    rng = np.random.RandomState(10 + radius)
+    sizes = [(1, 1), (1, 7), (2, 2), (3, 3), (2, 40), (40, 3), (5, 7), (20, 31), (64, 50), (33, 17), (100, 120),
+             (129, 64), (65, 257), (200, 200), (301, 299), (7, 300)]
+    pairs = [(_tracks(rng, tx, 4), _tracks(rng, ty, 4)) for tx, ty in sizes]
+    pi, pj, pl, cost = _run_pairs(pairs, radius)
+    for n, (x, y) in enumerate(pairs):
+        d, path = OD.fastdtw(x, y, radius)
+        assert pl[n] == len(path), (n, sizes[n])
+        assert np.array_equal(pi[n, :pl[n]], path[:, 0]), (n, sizes[n])
+        assert np.array_equal(pj[n, :pl[n]], path[:, 1]), (n, sizes[n])
+        assert abs(cost[n] - d) <= 1e-12 * max(d, 1e-300), (n, sizes[n])
+
+
+def test_baseline_config4_shape():
+    """BASELINE configs[3] shape at reduced batch: T in [700, 900], 25-dim, radius 1."""
+    rng = np.random.RandomState(1234)
+    pairs = []
+    for _ in range(24):
+        tx, ty = rng.randint(700, 901, size=2)
+        pairs.append((_tracks(rng, tx, 25), _tracks(rng, ty, 25)))
+    pi, pj, pl, cost = _run_pairs(pairs, 1)
+    for n, (x, y) in enumerate(pairs):
+        d, path = OD.fastdtw(x, y, 1)
+        assert pl[n] == len(path)
+        assert np.array_equal(pi[n, :pl[n]], path[:, 0]) and np.array_equal(pj[n, :pl[n]], path[:, 1])
+        assert abs(cost[n] - d) <= 1e-12 * d
+        # path validity properties (size independent)
+        steps_i, steps_j = np.diff(pi[n, :pl[n]]), np.diff(pj[n, :pl[n]])
+        assert pi[n, 0] == 0 and pj[n, 0] == 0 and pi[n, pl[n] - 1] == len(x) - 1 and pj[n, pl[n] - 1] == len(y) - 1
+        assert ((steps_i >= 0) & (steps_i <= 1) & (steps_j >= 0) & (steps_j <= 1) & (steps_i + steps_j >= 1)).all()
+
+
+def test_aligner_matches_oracle_transform():
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    rng = np.random.RandomState(3)
+    N, D = 6, 5
+    for (Tx, Ty, dt) in ((60, 75, np.float64), (75, 60, np.float32), (50, 50, np.float64)):
+        X = np.zeros((N, Tx, D), dtype=dt)
+        Y = np.zeros((N, Ty, D), dtype=dt)
+        for n in range(N):
+            a, b = rng.randint(Tx // 2, Tx + 1), rng.randint(Ty // 2, Ty + 1)
+            X[n, :a] = _tracks(rng, a, D)
+            Y[n, :b] = _tracks(rng, b, D)
+        Xa, Ya = DTWAligner().transform((X, Y))
+        Xo, Yo, paths, dists = OD.dtw_align(X, Y)
+        assert Xa.shape == Ya.shape == Xo.shape
+        assert Xa.dtype == Xo.dtype
+        assert np.array_equal(Xa, Xo) and np.array_equal(Ya, Yo)
+
+
+def test_reference_assertions_on_shifted_copy():
+    # reference tests/test_preprocessing.py:441-457: zero-shifted copy triggers the frame
+    # length adjustment; only shapes are asserted (ties are everywhere in this input)
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    rng = np.random.RandomState(0)
+    X = np.zeros((3, 40, 5))
+    for n, t in enumerate((40, 33, 21)):
+        X[n, :t] = rng.rand(t, 5) + 0.1
+    Y = np.pad(X, [(0, 0), (5, 0), (0, 0)], mode="constant", constant_values=0)[:, :-5, :]
+    Xa, Ya = DTWAligner().transform((X, Y))
+    assert Xa.shape == Ya.shape
+    # and a time-stretched copy aligns closer than the raw pair (:488-489)
+    t = np.linspace(0, 1, 200)[:, None]
+    x = np.sin(2 * np.pi * (1 + np.arange(4)) * t)
+    y = np.sin(2 * np.pi * (1 + np.arange(4)) * t ** 1.5)
+    Xa, Ya = DTWAligner().transform((x[None], y[None]))
+    assert Xa.shape == Ya.shape
+    assert np.linalg.norm(Xa - Ya) < np.linalg.norm(x - y)
+
+
+def test_trim_zeros_frames():
+    from nnmnkwii_amd.preprocessing import trim_zeros_frames
+    rng = np.random.RandomState(0)
+    for dt in (np.float32, np.float64):
+        x = rng.rand(100, 10).astype(dt)
+        assert trim_zeros_frames(x) is x
+        x[70:] = 0
+        x[:5] = 0
+        assert np.array_equal(trim_zeros_frames(x), OD.trim_zeros_frames(x))
+        assert trim_zeros_frames(x).shape == (70, 10)
+        assert trim_zeros_frames(x, trim="f").shape == (95, 10)
+        assert trim_zeros_frames(x, trim="fb").shape == (65, 10)
+        x[60] = 1e-9   # below eps -> still "zero" but interior
+        assert trim_zeros_frames(x).shape == (70, 10)
+    assert trim_zeros_frames(np.zeros((8, 3))).shape == (0, 3)
