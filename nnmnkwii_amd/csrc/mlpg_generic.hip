@@ -15,21 +15,10 @@
 //   right-looking banded Cholesky fused with the forward substitution, then a
 //   reverse sweep for L^T x = z.  Backward epilogue:
 //   grad[t, w*sd+d] = tau_w[t] * sum_k c_w[l_w+k] x[t+k]   (paramgen/_mlpg.py:202-281)
-#include "common.h"
+#include "assemble.h"
 
 namespace mlpg {
 namespace {
-
-template <typename T>
-__device__ __forceinline__ double recip_in_dtype(T v);
-template <>
-__device__ __forceinline__ double recip_in_dtype<float>(float v) {
-  return (double)__fdiv_rn(1.0f, v);  // reciprocal evaluated in float32 (_mlpg.py:188)
-}
-template <>
-__device__ __forceinline__ double recip_in_dtype<double>(double v) {
-  return 1.0 / v;
-}
 
 template <int Q, typename TIN, typename TOUT, bool BWD>
 __global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, double *__restrict__ scratch, long S) {
@@ -39,21 +28,10 @@ __global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, doubl
   const int b = (int)(s / sd), d = (int)(s % sd);
   int T = p.lengths ? p.lengths[b] : Tmax;
   T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
-  const TIN *mean = BWD ? nullptr : (const TIN *)p.mean + (size_t)b * Tmax * D;
-  const TIN *var = (const TIN *)p.var;
-  if (p.var_mode == MLPG_HIP_VAR_FRAME) var += (size_t)b * Tmax * D;
-  const TIN *gout = BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * sd : nullptr;
+  const SysView<TIN, BWD> view = make_view<TIN, BWD>(p, ws, b, d, T);
   TOUT *out = (TOUT *)p.out + (size_t)b * Tmax * (BWD ? D : sd);
-  const int mw = ws.mw, nw = ws.nw, var_mode = p.var_mode;
-
-  auto tau = [&](int w, int t) -> double {
-    // zero precision on the edge frames of the dynamic windows; Python's
-    // precisions[-0:] slice makes mw == 0 zero the whole column (_mlpg.py:191-193)
-    if (w != 0 && (mw == 0 || t < mw || t >= T - mw)) return 0.0;
-    if (var_mode == MLPG_HIP_VAR_UNIT) return 1.0;
-    const TIN v = (var_mode == MLPG_HIP_VAR_GLOBAL) ? var[w * sd + d] : var[(size_t)t * D + w * sd + d];
-    return recip_in_dtype<TIN>(v);
-  };
+  const int nw = ws.nw;
+  auto tau = [&](int w, int t) -> double { return view.tau(w, t); };
 
   constexpr int R = Q + 2;  // scratch rows per frame: 1/L_ff, L_{f+1..f+Q, f}, z_f
   double pend[Q + 1][Q + 1];
@@ -67,25 +45,8 @@ __global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, doubl
 
   int bad = 0;
   for (int f = 0; f < T; ++f) {
-    double pk[Q + 1];
-#pragma unroll
-    for (int k = 0; k <= Q; ++k) pk[k] = 0.0;
-    double rhs = BWD ? (double)gout[(size_t)f * sd + d] : 0.0;
-    for (int w = 0; w < nw; ++w) {
-      const int l = ws.l[w], u = ws.u[w];
-      const double *c = ws.c + ws.off[w];
-      const int t0 = f - u < 0 ? 0 : f - u;
-      const int t1 = f + l > T - 1 ? T - 1 : f + l;
-      for (int t = t0; t <= t1; ++t) {
-        const double a = c[l + f - t] * tau(w, t);
-        if (!BWD) rhs += a * (double)mean[(size_t)t * D + w * sd + d];
-#pragma unroll
-        for (int k = 0; k <= Q; ++k) {
-          const int idx = l + f + k - t;
-          if (idx <= l + u && f + k < T) pk[k] += a * c[idx];
-        }
-      }
-    }
+    double pk[Q + 1], rhs;
+    assemble_frame<Q, TIN, BWD>(view, ws, f, pk, rhs);
     double v[Q + 1];
 #pragma unroll
     for (int k = 0; k <= Q; ++k) v[k] = pk[k] + pend[0][k];
