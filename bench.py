@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 generic, 2 wave")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-check", action="store_true", help="profiling/ablation only: skip status and parity checks")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL all-gather of the outputs (reported separately)")
     return ap.parse_args()
 
@@ -122,7 +123,11 @@ def main():
 
     # kernel time from HIP events recorded on the stream the kernel is launched on
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    assert int(status.abs().max().item()) == 0, "a system was not positive definite"
+    if not args.no_check:
+        assert int(status.abs().max().item()) == 0, "a system was not positive definite"
+    elif os.environ.get("MLPG_DUMP_STATUS"):
+        st = status.cpu().numpy()[:64 * 8].reshape(64, 8)
+        print("phase cycles/64 (wait, asm, solve, out, total, slots) mean over 64 WGs:", st.mean(0).tolist(), file=sys.stderr)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -146,7 +151,8 @@ def main():
         O.build()
         yo = O.mlpg(means[0].cpu().numpy(), variances[0].cpu().numpy(), WINDOWS)
         err = float(np.abs(out[0].cpu().numpy() - yo).max() / np.abs(yo).max())
-        assert err < 1e-9, err
+        if not args.no_check:
+            assert err < 1e-9, err
 
         frames = world * B * T * args.steps
         alg_bytes = 56.0 * sd * B * T            # 56 B per (frame, static dim) per launch

@@ -5,10 +5,14 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["capi.hip", "mlpg_generic.hip", "mlpg_wave.hip", "dtw.hip", "dtw_fast.hip"]
-HEADERS = ["common.h", os.path.join("..", "..", "include", "mlpg_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-function"]
+SOURCES = ["capi.hip", "mlpg_generic.hip", "mlpg_wave.hip", "mlpg_wave_fwd_f64.hip", "mlpg_wave_fwd_f32.hip",
+           "mlpg_wave_bwd_f64.hip", "mlpg_wave_bwd_f32.hip", "dtw.hip", "dtw_fast.hip"]
+HEADERS = ["common.h", "assemble.h", "mlpg_wave_impl.h", os.path.join("..", "..", "include", "mlpg_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+# The DTW kernels must round exactly like the CPU oracle (separate multiply and add); the MLPG
+# kernels are free to fuse multiply-adds.
+FILE_FLAGS = {"dtw_fast.hip": ["-ffp-contract=off"], "dtw.hip": ["-ffp-contract=off"]}
+EXTRA = [f for f in os.environ.get("MLPG_HIP_EXTRA_FLAGS", "").split() if f]
 SO = os.path.join(HERE, "libmlpg_hip.so")
 
 
@@ -35,7 +39,7 @@ def build(force=False, verbose=False):
         o = os.path.join(HERE, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc, "-x", "hip", *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, "-x", "hip", *FLAGS, *FILE_FLAGS.get(src, ["-ffp-contract=fast"]), *EXTRA, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -46,7 +50,7 @@ def build(force=False, verbose=False):
         return r.stderr
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), 8)) as ex:
             for err in ex.map(run, jobs):
                 if verbose and err.strip():
                     print(err)

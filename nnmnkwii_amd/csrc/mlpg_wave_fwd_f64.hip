@@ -1,0 +1,8 @@
+// wave-per-system MLPG: forward, float64
+#include "mlpg_wave_impl.h"
+namespace mlpg {
+int launch_wave_fwd_f64(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws) {
+  (void)out_dtype;
+  return launch_t<double, double, false>(st, p, ws);
+}
+}  // namespace mlpg
