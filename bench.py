@@ -127,7 +127,8 @@ def main():
         assert int(status.abs().max().item()) == 0, "a system was not positive definite"
     elif os.environ.get("MLPG_DUMP_STATUS"):
         st = status.cpu().numpy()[:64 * 8].reshape(64, 8)
-        print("phase cycles/64 (wait, asm, solve, out, total, slots) mean over 64 WGs:", st.mean(0).tolist(), file=sys.stderr)
+        print("phase cycles (setup, wait-tiles, lds->regs, dma-issue, assembly, solve, status, output), mean over 64 WGs:",
+              [int(x) for x in st.mean(0)], "sum", int(st.mean(0).sum()), file=sys.stderr)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

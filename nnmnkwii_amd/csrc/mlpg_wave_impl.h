@@ -39,8 +39,22 @@
 #ifndef MLPG_WAVE_DMA
 #define MLPG_WAVE_DMA 1  // 0: never use the LDS-DMA staging path (register staging only)
 #endif
+#ifndef MLPG_WAVE_DMA_AUX
+#define MLPG_WAVE_DMA_AUX 0  // cache policy bits of the LDS-DMA loads (1 sc0, 2 nt, 16 sc1)
+#endif
 #ifndef MLPG_WAVE_ABLATE
 #define MLPG_WAVE_ABLATE 0  // profiling only: 1 skip the solve, 2 skip the global loads, 4 = 1 + skip assembly math
+#endif
+
+#ifdef MLPG_WAVE_TIMING
+#define MLPG_TICK(k)                                                   \
+  do {                                                                 \
+    const long long t_now_ = (long long)__builtin_readcyclecounter(); \
+    tq[k] += t_now_ - t_prev;                                          \
+    t_prev = t_now_;                                                   \
+  } while (0)
+#else
+#define MLPG_TICK(k) do {} while (0)
 #endif
 
 namespace mlpg {
@@ -145,7 +159,7 @@ __device__ __forceinline__ void load_tile_dma(TIN *__restrict__ tile, const TIN 
     if (q >= L::NB || q * L::FB >= T) break;  // wave-uniform
     if (q * L::FB + fl < T && cols_ok) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ptr + k * step),
-                                       (__attribute__((address_space(3))) void *)(tile + q * L::BS), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void *)(tile + q * L::BS), 16, 0, MLPG_WAVE_DMA_AUX);
     }
   }
 }
@@ -375,6 +389,16 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
   const TIN *gout_b = BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * sd : nullptr;
 
   const int f0 = lane * M;  // first frame of this lane's chunk
+#ifdef MLPG_WAVE_STAGGER
+  // de-phase the two workgroups that share a CU: the second resident workgroup of each CU starts late
+  if (slot < 64 && ((slot / 32) & 1)) {
+    for (int k = 0; k < MLPG_WAVE_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
+#ifdef MLPG_WAVE_TIMING
+  long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // setup, wait-for-tiles, lds->regs, dma issue, assembly, solve, status, output
+  long long t_prev = (long long)__builtin_readcyclecounter();
+#endif
   // liveness of the chunk's frames plus one halo frame on each side, bit i+1 <-> frame f0+i:
   // static window: 0 <= t < T;  dynamic windows: mw <= t < T - mw (and nothing at all if mw == 0,
   // Python's precisions[-0:] = 0 slice, _mlpg.py:191-193)
@@ -409,10 +433,12 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
     __syncthreads();
   }
 
+  MLPG_TICK(0);
   if (DMA && MLPG_WAVE_ABLATE != 2) {
     if (kVarTile) load_tile_dma<M, TIN>(tileV, var_b + d0, D, T, gvalid, wv, lane);
     if (!BWD) load_tile_dma<M, TIN>(tileM, mean_b + d0, D, T, gvalid, wv, lane);
   }
+  MLPG_TICK(3);
   for (int w = 0; w < nw; ++w) {
     const int l = ws.l[w], u = ws.u[w];
     const double *cw = ws.c + ws.off[w];
@@ -426,6 +452,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
     TIN rv[M + 2], rm[M + 2];
     if (DMA) {
       __syncthreads();  // drains every wavefront's DMA queue: window w has landed
+      MLPG_TICK(1);
       if (kVarTile) {
         rv[0] = tileV[loD];
         rv[M + 1] = tileV[hiD];
@@ -440,10 +467,12 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
       }
       __syncthreads();  // every wavefront holds its values: the tiles can be refilled now, and
                         // the transfer runs behind this window's arithmetic
+      MLPG_TICK(2);
       if (w + 1 < nw && MLPG_WAVE_ABLATE != 2) {
         if (kVarTile) load_tile_dma<M, TIN>(tileV, var_b + (w + 1) * sd + d0, D, T, gvalid, wv, lane);
         if (!BWD) load_tile_dma<M, TIN>(tileM, mean_b + (w + 1) * sd + d0, D, T, gvalid, wv, lane);
       }
+      MLPG_TICK(3);
     } else {
       if (MLPG_WAVE_ABLATE != 2) {
         if (kVarTile) load_tile_regs<M, TIN>(tileV, var_b + w * sd + d0, D, T, gvalid, tid);
@@ -491,6 +520,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
         if (!BWD) rhs[i - 1] += cm * tm;
       }
     }
+    MLPG_TICK(4);
   }
   // matrix edges: rows >= T are identity rows, entries that would leave the T x T matrix vanish
 #pragma unroll
@@ -515,6 +545,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
   const bool bad = false;
 #endif
 
+  MLPG_TICK(5);
   // ---- status: a non-positive pivot anywhere means the matrix is not positive definite; the
   // reference reports the first failing pivot of the natural-order factorisation ----
   int status = 0;
@@ -529,6 +560,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
   if (sys_valid && lane == 0 && p.status) p.status[(size_t)b * sd + d] = status;
   const bool zero_out = status != 0;
 
+  MLPG_TICK(6);
   // ---- 5. output ----
   if (!BWD) {
     TOUT *tileO = (TOUT *)tileA;
@@ -569,6 +601,15 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
       store_tile<M, TOUT>(tileO, (TOUT *)p.out + (size_t)b * Tmax * D + w * sd + d0, D, T, Tmax, gvalid, tid);
     }
   }
+#ifdef MLPG_WAVE_TIMING
+  // profiling build only: per-phase cycle counts of wavefront 0 of the first 64 workgroups
+  // overwrite the head of the status array (run bench.py --no-check with MLPG_DUMP_STATUS=1)
+  MLPG_TICK(7);
+  __syncthreads();
+  if (tid == 0 && p.status && blockIdx.x < 64 * 8 && (blockIdx.x & 7) == 0) {
+    for (int k = 0; k < 8; ++k) p.status[(blockIdx.x >> 3) * 8 + k] = (int)tq[k];
+  }
+#endif
 }
 
 // ---- launchers ---------------------------------------------------------------------------------

@@ -1,0 +1,98 @@
+"""N > 1 path on CPU (-m "not gpu"): world_size-2 gloo processes exercise the batch sharding
+and the result gather.  The per-shard compute is injected (the oracle, as the checker) because
+the product has no CPU compute path; on GPUs the same code runs with the HIP kernels + RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partition():
+    from nnmnkwii_amd.sharding import shard_range
+    for n in (0, 1, 5, 8, 17, 256, 1024):
+        for world in (1, 2, 3, 4, 8):
+            parts = [shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            for (a, b), (c, d) in zip(parts, parts[1:]):
+                assert b == c and b >= a
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, B, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cases import WINDOW_SETS
+        from nnmnkwii_amd import sharding
+        from oracle import dtw as OD
+        from oracle import mlpg as O
+        windows = WINDOW_SETS["std3"]
+        rng = np.random.RandomState(0)          # same data on every rank (SPMD)
+        T, sd = 40, 3
+        M = rng.randn(B, T, 3 * sd)
+        V = rng.rand(B, T, 3 * sd) + 0.1
+        lengths = rng.randint(1, T + 1, size=B).astype(np.int32)
+
+        def compute(m, v, w, L):
+            return O.mlpg_batch(m, v, w, L)[0]
+
+        full = sharding.mlpg_batch_sharded(M, V, windows, lengths, gather=True, compute=compute)
+        ref = O.mlpg_batch(M, V, windows, lengths)[0]
+        ok = full.shape == ref.shape and np.array_equal(full, ref)
+        local, (lo, hi) = sharding.mlpg_batch_sharded(M, V, windows, lengths, gather=False, compute=compute)
+        ok = ok and (lo, hi) == sharding.shard_range(B, rank, world) and np.array_equal(local, ref[lo:hi])
+        # global variances + torch tensors in/out
+        vg = rng.rand(3 * sd) + 0.1
+        full_t = sharding.mlpg_batch_sharded(torch.from_numpy(M), torch.from_numpy(vg), windows, None, gather=True,
+                                             compute=lambda m, v, w, L: torch.from_numpy(
+                                                 O.mlpg_batch(m.numpy(), v.numpy(), w, L)[0]))
+        ok = ok and torch.is_tensor(full_t) and np.array_equal(full_t.numpy(), O.mlpg_batch(M, vg, windows)[0])
+
+        # DTW: shards of pairs, outputs padded to the global longest path
+        X = np.zeros((B, 30, 4))
+        Y = np.zeros((B, 36, 4))
+        for n in range(B):
+            a, b_ = rng.randint(10, 31), rng.randint(10, 37)
+            X[n, :a] = np.cumsum(rng.randn(a, 4), 0)
+            Y[n, :b_] = np.cumsum(rng.randn(b_, 4), 0)
+        Xf, Yf = sharding.dtw_align_sharded(None, X, Y, transform=lambda xy: OD.dtw_align(xy[0], xy[1])[:2])
+        Xo, Yo, _, _ = OD.dtw_align(X, Y)
+        ok = ok and Xf.shape == Xo.shape and np.array_equal(Xf, Xo) and np.array_equal(Yf, Yo)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [5, 8])
+def test_sharded_mlpg_and_dtw_gloo_world2(B):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

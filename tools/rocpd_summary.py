@@ -31,8 +31,8 @@ def main():
             r[6] or 0, r[7] or 0, r[8] or 0, r[9] or 0, r[10] or 0, r[11] or 0, r[12] or 0))
     if "--pmc" in sys.argv:
         try:
-            q = ("select k.name, p.counter_name, avg(p.value), count(*) from pmc_events p "
-                 "join kernels k on p.dispatch_id = k.dispatch_id group by k.name, p.counter_name")
+            q = ("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                 "group by kernel_name, counter_name")
             print("\ncounters (mean per dispatch)")
             for name, cname, val, n in cur.execute(q):
                 print("%-90s %-28s %18.1f  (n=%d)" % (short(name, 90), cname, val, n))
