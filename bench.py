@@ -74,6 +74,20 @@ def cpu_baseline(T, D, seconds):
     }
 
 
+def measured_traffic(B, T, sd, algo):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (profiles/traffic.json),
+    if it was taken on this exact workload; bench.py cannot run rocprofv3 on itself."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        w = t["workload"]
+        if (w["batch_per_gpu"], w["frames"], w["static_dim"]) == (B, T, sd) and algo in (0, 2):
+            return float(t["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     args = parse()
     import torch
@@ -184,7 +198,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(B, T, sd, args.algo),
+                "traffic_unit": "bytes/launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/traffic.json)",
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes": alg_bytes,
             },

@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""Secondary measurements (1 GPU) for the other BASELINE.json configs; one JSON line per path.
+
+    python tools/bench_paths.py [--quick]
+
+  c2g : config 2 with global (D,) variances and with unit variances (32 B per (frame, dim))
+  c3  : autograd.unit_variance_mlpg forward+backward, B=64 x T=500 x 180, float32 tensors on the GPU
+  c3m : autograd.mlpg (generic variances) forward+backward, one utterance T=500 x 180 float32
+  c4  : DTWAligner on 128 pairs (1 GPU share of config 4), T in [700, 900], 25-dim, radius 1
+  c5  : Merlin-style acoustic paramgen mgc(60)+lf0(1)+bap(5), T=2000, B=512 (1 GPU share of config 5), float64
+
+Each line carries the GPU time (HIP events on the launch stream), the algorithmic bytes, GB/s, and a
+bounded CPU baseline from the oracle on the same host (the checker, timed like bench.py's cpu_baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+WINDOWS = [(0, 0, np.array([1.0])), (1, 1, np.array([-0.5, 0.0, 0.5])), (1, 1, np.array([1.0, -2.0, 1.0]))]
+
+
+def gpu_time(fn, steps=10, warmup=2):
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in evs]))
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    import torch
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd import autograd as AF
+    from nnmnkwii_amd import paramgen as G
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    from oracle import dtw as OD
+    from oracle import mlpg as O
+    O.build()
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    want = lambda k: not args.only or k in args.only.split(",")  # noqa: E731
+
+    # ---- c2g: global / unit variances ----
+    if want("c2g"):
+        B, T, sd = 256, 1000, 60
+        m = torch.randn(B, T, 3 * sd, dtype=torch.float64, device=dev, generator=gen)
+        vg = torch.rand(3 * sd, dtype=torch.float64, device=dev, generator=gen) + 0.1
+        for name, var in (("global", vg), ("unit", None)):
+            ms = gpu_time(lambda: _hip.forward(m, var, WINDOWS, want_status=False))
+            by = 32.0 * sd * B * T
+            emit(path="c2g-" + name, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
+        del m
+
+    # ---- c3: unit-variance autograd fwd+bwd ----
+    if want("c3"):
+        B, T, D = 64, 500, 180
+        R = torch.from_numpy(G.unit_variance_mlpg_matrix(WINDOWS, T)).to(dev)
+        means = torch.rand(B, T, D, device=dev, requires_grad=True)
+        target = torch.rand(B, T, D // 3, device=dev)
+        loss_fn = torch.nn.MSELoss()
+
+        def step():
+            means.grad = None
+            y = AF.unit_variance_mlpg(R, means)
+            loss_fn(y, target).backward()
+
+        ms = gpu_time(step)
+        by = 1920.0 * B * T    # 960 B/frame forward + 960 B/frame backward
+        # reference CPU form: dense R @ means on torch CPU (autograd/_impl/mlpg.py:138,158), 1 thread
+        torch.set_num_threads(1)
+        Rc, mc = R.cpu(), means.detach().cpu().requires_grad_()
+        tc = target.cpu()
+        t0 = time.perf_counter()
+        nrep = 1 if args.quick else 3
+        for _ in range(nrep):
+            mc.grad = None
+            rm = mc.view(B, T, 3, -1).transpose(1, 2).contiguous().view(B, -1, D // 3)
+            loss_fn(torch.matmul(Rc, rm), tc).backward()
+        cpu_s = (time.perf_counter() - t0) / nrep
+        emit(path="c3-unit-variance-autograd-fwd+bwd", ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by,
+             GBps=by / ms / 1e6, cpu_dense_matmul_1thread_frames_per_s=B * T / cpu_s)
+
+    # ---- c3m: generic autograd.mlpg fwd+bwd (one utterance, like the reference's MLPG) ----
+    if want("c3m"):
+        T, D = 500, 180
+        m1 = torch.rand(T, D, device=dev, requires_grad=True)
+        v1 = torch.rand(T, D, device=dev) + 0.1
+        tg = torch.rand(T, D // 3, device=dev)
+        AF._mlpg.CHECK_STATUS = False
+
+        def step1():
+            m1.grad = None
+            torch.nn.MSELoss()(AF.mlpg(m1, v1, WINDOWS), tg).backward()
+
+        ms = gpu_time(step1)
+        AF._mlpg.CHECK_STATUS = True
+        t0 = time.perf_counter()
+        O.mlpg(m1.detach().cpu().numpy(), v1.cpu().numpy(), WINDOWS)
+        cpu_fwd = time.perf_counter() - t0
+        emit(path="c3m-autograd.mlpg-fwd+bwd-1utt", ms=ms, frames_per_s=T / ms * 1e3,
+             cpu_oracle_forward_only_frames_per_s=T / cpu_fwd,
+             note="reference backward is O(T^2) dense solve_banded: 12.7 ms per static dim at T=500 (SURVEY 6)")
+
+    # ---- c4: DTW ----
+    if want("c4"):
+        N = 32 if args.quick else 128
+        rng = np.random.RandomState(1234)
+        Tx = Ty = 900
+        X = np.zeros((N, Tx, 25))
+        Y = np.zeros((N, Ty, 25))
+        for n in range(N):
+            a, b = rng.randint(700, 901, size=2)
+            X[n, :a] = np.cumsum(rng.randn(a, 25), 0) * 0.1
+            Y[n, :b] = np.cumsum(rng.randn(b, 25), 0) * 0.1
+        Xd, Yd = torch.from_numpy(X).to(dev), torch.from_numpy(Y).to(dev)
+        lenx, leny = _hip.trim_lengths(Xd), _hip.trim_lengths(Yd)
+        ms = gpu_time(lambda: _hip.fastdtw_l2(Xd, Yd, lenx, leny, 1))
+        pi, pj, pl, cost = _hip.fastdtw_l2(Xd, Yd, lenx, leny, 1)
+        plen = pl.cpu().numpy()
+        by = float(((lenx + leny).sum().item()) * 25 * 8 + 8 * plen.sum())
+        ncpu = 8 if args.quick else 32
+        t0 = time.perf_counter()
+        for n in range(ncpu):
+            OD.fastdtw(X[n, :int(lenx[n])], Y[n, :int(leny[n])], 1)
+        cpu_s = (time.perf_counter() - t0) / ncpu
+        ms_full = gpu_time(lambda: DTWAligner().transform((X, Y)), steps=3, warmup=1)
+        emit(path="c4-fastdtw-kernel", pairs=N, ms=ms, pairs_per_s=N / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6,
+             cpu_oracle_c_pairs_per_s=1.0 / cpu_s, transform_numpy_to_numpy_ms=ms_full)
+
+    # ---- c5: Merlin-style multi-stream ----
+    if want("c5"):
+        B, T = (128 if args.quick else 512), 2000
+        tot_ms, tot_by = 0.0, 0.0
+        for name, sd in (("mgc", 60), ("lf0", 1), ("bap", 5)):
+            m = torch.randn(B, T, 3 * sd, dtype=torch.float64, device=dev, generator=gen)
+            v = torch.rand(B, T, 3 * sd, dtype=torch.float64, device=dev, generator=gen) + 0.1
+            ms = gpu_time(lambda: _hip.forward(m, v, WINDOWS, want_status=False), steps=5)
+            by = 56.0 * sd * B * T
+            emit(path="c5-" + name, batch=B, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
+            tot_ms += ms
+            tot_by += by
+            del m, v
+        emit(path="c5-all-streams", batch=B, ms=tot_ms, frames_per_s=B * T / tot_ms * 1e3, alg_bytes=tot_by,
+             GBps=tot_by / tot_ms / 1e6)
+
+
+if __name__ == "__main__":
+    main()
