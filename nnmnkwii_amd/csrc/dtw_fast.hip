@@ -11,13 +11,20 @@
 //   2. from the coarsest level (full DTW) down to level 0: per-row windows
 //      [lo_i, hi_i] from the coarser path (interval form of __expand_window:
 //      the union of (2r+1)^2 neighbourhoods along a monotone path is one
-//      interval per row), local costs for every window cell (all lanes in
-//      parallel), then the DP recurrence swept along ANTI-DIAGONALS: lane r
-//      owns row i0+r of a chunk of <= 64 rows and at step s handles column
-//      s - r, so the cells done in one step are exactly one anti-diagonal;
-//      rows hand values down through LDS; 1-byte back-pointers in LDS;
-//   3. back-trace by one lane, new path kept in LDS for the next level.
-// Everything except the pyramid lives in LDS (~42 KB for T = 900, radius 1).
+//      interval per row), then, in chunks of <= 64 rows:
+//        a. the chunk's x rows and y rows are staged in LDS (contiguous,
+//           coalesced copies) and the local cost of every window cell is
+//           computed by all lanes;
+//        b. the DP recurrence is swept along ANTI-DIAGONALS: lane r owns row
+//           i0 + r and at step s handles column s - r, so one step is exactly
+//           one anti-diagonal.  Rows hand their values down with a DPP
+//           wave_shr:1 register move -- no LDS round trip, no barrier inside
+//           the sweep; only the first row of a chunk reads the previous
+//           chunk's last row from LDS (prefetched one step ahead);
+//        c. 2-bit back-pointers are packed 32 cells per 64-bit word in LDS;
+//   3. back-trace by one lane (one LDS word per row, next row prefetched), new
+//      path kept in LDS for the next level.
+// Everything except the pyramid lives in LDS.
 //
 // Arithmetic is bit-compatible with the oracle: cost = sqrt(sum_k (x-y)^2)
 // with separate multiply/add in ascending k; D = min(up+dt, left+dt, diag+dt)
@@ -25,6 +32,17 @@
 #include <math.h>
 
 #include "common.h"
+
+#ifdef MLPG_DTW_TIMING
+#define DTW_TICK(k)                                                    \
+  do {                                                                 \
+    const long long t_now_ = (long long)__builtin_readcyclecounter(); \
+    tq[k] += t_now_ - t_prev;                                          \
+    t_prev = t_now_;                                                   \
+  } while (0)
+#else
+#define DTW_TICK(k) do {} while (0)
+#endif
 
 namespace mlpg {
 namespace {
@@ -37,11 +55,14 @@ struct DtwParams {
   double *cost;
   double *pyr;        // N * pyr_stride doubles: x levels >= 1, then y levels >= 1
   size_t pyr_stride;  // (Tx + Ty) * D
-  int cellcap;        // back-pointer capacity per level
-  int chunkcap;       // D/cost cells per DP chunk
+  int cellcap;        // window cells per level (bound)
+  int chunkcap;       // cost cells per DP chunk
+  int wordcap;        // 64-bit back-pointer words per level
+  int ycap;           // y rows staged per chunk
 };
 
 constexpr int kMaxLevels = 20;
+constexpr int kRows = 64;  // rows per chunk = lanes
 
 __device__ __forceinline__ double l2_cost(const double *__restrict__ a, const double *__restrict__ b, int D) {
   double acc = 0.0;
@@ -63,6 +84,14 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total) {
   return incl - v;
 }
 
+// lane r receives lane r-1's value (lane 0 keeps its own): one DPP move per 32-bit half
+__device__ __forceinline__ double wave_shr1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
@@ -70,11 +99,16 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
   const int Tx = p.Tx, Ty = p.Ty, D = p.D, r = p.radius;
   const int pcap = Tx + Ty;
 
-  // ---- LDS carve (doubles, ints, shorts, bytes) ----
-  double *dchunk = (double *)smem;
-  double *dprev = dchunk + p.chunkcap;
-  int *off = (int *)(dprev + Ty);
-  int *lvl_x = off + (Tx + 1);
+  // ---- LDS carve (doubles / 64-bit words, ints, shorts) ----
+  double *dchunk = (double *)smem;                 // local costs of the chunk's window cells
+  double *dprevA = dchunk + p.chunkcap;            // last row of the previous chunk (ping)
+  double *dprevB = dprevA + Ty;                    //                                  (pong)
+  double *xs = dprevB + Ty;                        // staged x rows of the chunk   [kRows][D]
+  double *ys = xs + kRows * D;                     // staged y rows of the chunk   [ycap][D]
+  unsigned long long *bpw = (unsigned long long *)(ys + (size_t)p.ycap * D);  // packed back-pointers
+  int *off = (int *)(bpw + p.wordcap);             // cell offset of each row (prefix sum of widths)
+  int *woff = off + (Tx + 1);                      // back-pointer word offset of each row
+  int *lvl_x = woff + (Tx + 1);
   int *lvl_y = lvl_x + kMaxLevels;
   int *bcast = lvl_y + kMaxLevels;  // [4]
   unsigned short *lo = (unsigned short *)(bcast + 4);
@@ -83,7 +117,6 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
   unsigned short *clast = cfirst + (Tx / 2 + 2);
   unsigned short *pth_i = clast + (Tx / 2 + 2);
   unsigned short *pth_j = pth_i + pcap;
-  unsigned char *bp = (unsigned char *)(pth_j + pcap);
 
   const int tx = p.lenx[n], ty = p.leny[n];
   int32_t *out_i = p.path_i + (size_t)n * pcap;
@@ -100,6 +133,10 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
   double *px = p.pyr + (size_t)n * p.pyr_stride;
   double *py = px + (size_t)Tx * D;
 
+#ifdef MLPG_DTW_TIMING
+  long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // pyramid, windows+offsets, staging, costs, sweep, backtrace, output
+  long long t_prev = (long long)__builtin_readcyclecounter();
+#endif
   // number of halvings: level K is the first with a side < radius + 2 (full DTW there)
   int K = 0;
   while (K < kMaxLevels - 1 && (tx >> K) >= r + 2 && (ty >> K) >= r + 2) ++K;
@@ -133,6 +170,7 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
     }
   }
 
+  DTW_TICK(0);
   int pstart = pcap, pn = 0;  // current path = pth[pstart .. pstart+pn)
   double level_cost = INFINITY;
   bool fail = false;
@@ -168,31 +206,48 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
     }
     __syncthreads();
 
-    // ---- 2b. row offsets (exclusive scan of the row widths) ----
+    // ---- 2b. row offsets: cells (off) and back-pointer words (woff) ----
     {
       const int rpl = (ltx + 63) / 64;
       const int b0 = lane * rpl < ltx ? lane * rpl : ltx;
       const int b1 = b0 + rpl < ltx ? b0 + rpl : ltx;
-      int sum = 0;
-      for (int i = b0; i < b1; ++i) sum += (int)hi[i] - (int)lo[i] + 1;
-      int total;
-      int run = wave_excl_scan(sum, lane, &total);
+      int sum = 0, wsum = 0;
       for (int i = b0; i < b1; ++i) {
-        off[i] = run;
-        run += (int)hi[i] - (int)lo[i] + 1;
+        const int wdt = (int)hi[i] - (int)lo[i] + 1;
+        sum += wdt;
+        wsum += (wdt + 31) >> 5;
       }
-      if (lane == 0) off[ltx] = total;
-      if (total > p.cellcap) fail = true;
+      int total, wtotal;
+      int run = wave_excl_scan(sum, lane, &total);
+      int wrun = wave_excl_scan(wsum, lane, &wtotal);
+      for (int i = b0; i < b1; ++i) {
+        const int wdt = (int)hi[i] - (int)lo[i] + 1;
+        off[i] = run;
+        woff[i] = wrun;
+        run += wdt;
+        wrun += (wdt + 31) >> 5;
+      }
+      if (lane == 0) {
+        off[ltx] = total;
+        woff[ltx] = wtotal;
+      }
+      if (total > p.cellcap || wtotal > p.wordcap) fail = true;
     }
     __syncthreads();
     if (fail) break;
 
+    DTW_TICK(1);
     // ---- 2c. DP over chunks of rows ----
     int i0 = 0;
     int prevlo = 0, prevhi = -1;
+    double *dprev = dprevA, *dnext = dprevB;
+    double last_val = INFINITY;
     while (i0 < ltx) {
       const int base = off[i0];
-      const bool fits = (i0 + lane < ltx) && (off[i0 + lane + 1] - base <= p.chunkcap);
+      const int ylo = (int)lo[i0];
+      const bool wide = ((int)hi[i0] - ylo + 1) > p.ycap;  // a single row wider than the y stage
+      const bool fits = (i0 + lane < ltx) && (off[i0 + lane + 1] - base <= p.chunkcap) &&
+                        (wide || ((int)hi[i0 + lane] - ylo + 1) <= p.ycap);
       const unsigned long long m = __ballot(fits);
       const int R = (~m == 0ull) ? 64 : (__ffsll((long long)~m) - 1);
       if (R < 1) {
@@ -200,6 +255,13 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
         break;
       }
       const int ncell = off[i0 + R] - base;
+      const int yhi = (int)hi[i0 + R - 1];
+      // stage the chunk's x rows (and y rows unless `wide`): contiguous coalesced copies
+      for (int e = lane; e < R * D; e += 64) xs[e] = xk[(size_t)i0 * D + e];
+      if (!wide)
+        for (int e = lane; e < (yhi - ylo + 1) * D; e += 64) ys[e] = yk[(size_t)ylo * D + e];
+      __syncthreads();
+      DTW_TICK(2);
       // local costs of every window cell of the chunk
       for (int c = lane; c < ncell; c += 64) {
         int a = 0, b = R;
@@ -209,74 +271,110 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
         }
         const int row = i0 + a;
         const int j = (int)lo[row] + c - (off[row] - base);
-        dchunk[c] = l2_cost(xk + (size_t)row * D, yk + (size_t)j * D, D);
+        dchunk[c] = wide ? l2_cost(xs + a * D, yk + (size_t)j * D, D) : l2_cost(xs + a * D, ys + (j - ylo) * D, D);
       }
       __syncthreads();
+      DTW_TICK(3);
+
       // anti-diagonal sweep: lane = row, step s handles column s - lane
       const bool act = lane < R;
       const int i = i0 + lane;
       const int mylo = act ? (int)lo[i] : 0, myhi = act ? (int)hi[i] : -1;
-      const int myoff = act ? off[i] - base : 0;
-      const int gofs = act ? off[i] : 0;
-      int uplo = prevlo, uphi = prevhi;
-      const double *uprow = dprev;
-      if (act && lane > 0) {
-        uplo = (int)lo[i - 1];
-        uphi = (int)hi[i - 1];
-        uprow = dchunk + (off[i - 1] - base);
-      }
+      const int cbase = act ? off[i] - base : 0;
+      const int wbase = act ? woff[i] : 0;
       const int s0 = (int)lo[i0];
       const int s1 = (int)hi[i0 + R - 1] + R - 1;
+      const bool first_row = (i == 0);           // virtual row -1: only D[-1][-1] = 0
+      const bool is_last = act && lane == R - 1;  // hands its row to the next chunk
+      double pub = INFINITY;      // this lane's D at the column it handled in the previous step (INF if none)
+      // row above at column j-1: rows >= 1 of the chunk collect it from the sweep itself; the chunk's
+      // first row needs the previous chunk's last row at column s0 - 1
+      double up_old = (lane == 0 && s0 - 1 >= prevlo && s0 - 1 <= prevhi) ? dprev[s0 - 1 - prevlo] : INFINITY;
       double left = INFINITY;
+      unsigned long long word = 0ull;
+      // prefetched for step s0: local cost and (lane 0) the previous chunk's last row at column j
+      int j = s0 - lane;
+      int cj = j - mylo;
+      cj = cj < 0 ? 0 : (cj > myhi - mylo ? (myhi > mylo ? myhi - mylo : 0) : cj);
+      double dt_n = dchunk[cbase + cj];
+      double pv_n = (j >= prevlo && j <= prevhi) ? dprev[j - prevlo] : INFINITY;
       for (int s = s0; s <= s1; ++s) {
-        const int j = s - lane;
-        if (act && j >= mylo && j <= myhi) {
-          double up = (j >= uplo && j <= uphi) ? uprow[j - uplo] : INFINITY;
-          double dg = (j - 1 >= uplo && j - 1 <= uphi) ? uprow[j - 1 - uplo] : INFINITY;
-          if (i == 0) {
+        j = s - lane;
+        const double dt = dt_n;
+        double up_new = wave_shr1(pub);
+        if (lane == 0) up_new = pv_n;
+        // prefetch for the next step (column j + 1)
+        {
+          int cn = j + 1 - mylo;
+          cn = cn < 0 ? 0 : (cn > myhi - mylo ? (myhi > mylo ? myhi - mylo : 0) : cn);
+          dt_n = dchunk[cbase + cn];
+          pv_n = (j + 1 >= prevlo && j + 1 <= prevhi) ? dprev[j + 1 - prevlo] : INFINITY;
+        }
+        const bool inwin = act && j >= mylo && j <= myhi;
+        double npub = INFINITY;
+        if (inwin) {
+          double up = up_new, dg = up_old;
+          if (first_row) {
             up = INFINITY;
             dg = (j == 0) ? 0.0 : INFINITY;
           }
           const double lf = (j - 1 >= mylo) ? left : INFINITY;
-          const double dt = dchunk[myoff + j - mylo];
           const double cu = __dadd_rn(up, dt), cl = __dadd_rn(lf, dt), cd = __dadd_rn(dg, dt);
           double best = cu;
-          unsigned char code = 0;
-          if (cl < best) { best = cl; code = 1; }
-          if (cd < best) { best = cd; code = 2; }
-          dchunk[myoff + j - mylo] = best;
-          bp[gofs + j - mylo] = code;
+          unsigned long long code = 0ull;
+          if (cl < best) { best = cl; code = 1ull; }
+          if (cd < best) { best = cd; code = 2ull; }
           left = best;
+          npub = best;
+          const int cpos = j - mylo;
+          word |= code << (2 * (cpos & 31));
+          if ((cpos & 31) == 31 || j == myhi) {
+            bpw[wbase + (cpos >> 5)] = word;
+            word = 0ull;
+          }
+          if (is_last) dnext[cpos] = best;
         }
-        __syncthreads();
+        pub = npub;
+        up_old = up_new;
       }
-      // hand the last row of the chunk to the next chunk
-      const int lr = i0 + R - 1;
-      const int lw = (int)hi[lr] - (int)lo[lr] + 1;
-      const int lofs = off[lr] - base;
-      for (int c = lane; c < lw; c += 64) dprev[c] = dchunk[lofs + c];
-      prevlo = (int)lo[lr];
-      prevhi = (int)hi[lr];
+      // value of the chunk's last cell (bottom-right corner of the level if this is the last chunk)
+      last_val = __shfl(left, R - 1);
+      prevlo = (int)lo[i0 + R - 1];
+      prevhi = (int)hi[i0 + R - 1];
+      double *tsw = dprev;
+      dprev = dnext;
+      dnext = tsw;
       __syncthreads();
+      DTW_TICK(4);
       i0 += R;
     }
     if (fail) break;
-    level_cost = (lty - 1 >= prevlo && lty - 1 <= prevhi) ? dprev[lty - 1 - prevlo] : INFINITY;
+    level_cost = (prevhi == lty - 1) ? last_val : INFINITY;
 
     // ---- 3. back-trace (one lane), path written from the end of the buffer ----
     if (lane == 0) {
       int i = ltx - 1, j = lty - 1, pos = pcap;
       int ok = (level_cost < INFINITY) ? 1 : 0;
-      int ro = off[i], rl = (int)lo[i];
+      int rl = (int)lo[i], rw = woff[i];
+      int widx = (j - rl) >> 5;
+      unsigned long long word = bpw[rw + widx];
+      // prefetch of the row above: its lo, word base and first word
+      int nrl = i > 0 ? (int)lo[i - 1] : 0, nrw = i > 0 ? woff[i - 1] : 0, nrh = i > 0 ? (int)hi[i - 1] : -1;
+      unsigned long long nword0 = i > 0 ? bpw[nrw] : 0ull;
       while (ok) {
         if (pos == 0) { ok = 0; break; }
         --pos;
         pth_i[pos] = (unsigned short)i;
         pth_j[pos] = (unsigned short)j;
-        const unsigned char code = bp[ro + j - rl];
+        const int cpos = j - rl;
+        const unsigned code = (unsigned)((word >> (2 * (cpos & 31))) & 3ull);
         if (code == 1) {
           j -= 1;
-          if (j < rl) ok = 0;
+          if (j < rl) { ok = 0; break; }
+          if (((j - rl) >> 5) != widx) {
+            widx = (j - rl) >> 5;
+            word = bpw[rw + widx];
+          }
         } else {
           if (code == 2) j -= 1;
           i -= 1;
@@ -284,9 +382,17 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
             if (j != -1) ok = 0;
             break;
           }
-          ro = off[i];
-          rl = (int)lo[i];
-          if (j < rl || j > (int)hi[i]) ok = 0;
+          rl = nrl;
+          rw = nrw;
+          if (j < rl || j > nrh) { ok = 0; break; }
+          widx = (j - rl) >> 5;
+          word = widx == 0 ? nword0 : bpw[rw + widx];
+          if (i > 0) {
+            nrl = (int)lo[i - 1];
+            nrw = woff[i - 1];
+            nrh = (int)hi[i - 1];
+            nword0 = bpw[nrw];
+          }
         }
       }
       bcast[0] = pos;
@@ -297,6 +403,7 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
     pn = pcap - pstart;
     if (!bcast[1]) fail = true;
     __syncthreads();
+    DTW_TICK(5);
   }
 
   if (fail) {
@@ -314,14 +421,20 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
     p.path_len[n] = pn;
     p.cost[n] = level_cost;
   }
+#ifdef MLPG_DTW_TIMING
+  DTW_TICK(6);
+  __syncthreads();
+  if (lane == 0)
+    for (int q = 0; q < 7; ++q) out_i[pcap - 8 + q] = (int)(tq[q] >> 4);   // profiling build: cycles / 16 in the tail of path_i
+#endif
 }
 
-size_t lds_bytes(int Tx, int Ty, int cellcap, int chunkcap) {
+size_t lds_bytes(int Tx, int Ty, int D, const DtwParams &p) {
   size_t b = 0;
-  b += sizeof(double) * ((size_t)chunkcap + Ty);
-  b += sizeof(int) * ((size_t)(Tx + 1) + 2 * kMaxLevels + 4);
+  b += sizeof(double) * ((size_t)p.chunkcap + 2 * (size_t)Ty + (size_t)kRows * D + (size_t)p.ycap * D);
+  b += sizeof(unsigned long long) * (size_t)p.wordcap;
+  b += sizeof(int) * ((size_t)2 * (Tx + 1) + 2 * kMaxLevels + 4);
   b += sizeof(unsigned short) * ((size_t)2 * Tx + 2 * (Tx / 2 + 2) + 2 * (size_t)(Tx + Ty));
-  b += (size_t)cellcap;
   return (b + 15) & ~(size_t)15;
 }
 
@@ -346,9 +459,13 @@ int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, 
   if (full < cc) cc = full + 64;
   p.cellcap = (int)cc;
   p.chunkcap = Ty > 1024 ? Ty : 1024;
-  const size_t lds = lds_bytes(Tx, Ty, p.cellcap, p.chunkcap);
+  p.wordcap = (int)(cc / 32) + Tx + 8;
+  // y rows staged per chunk: 64 rows of x at unit slope span ~64 + window width rows of y
+  p.ycap = 128;
+  while (p.ycap > 16 && lds_bytes(Tx, Ty, D, p) > 150 * 1024) p.ycap /= 2;
+  const size_t lds = lds_bytes(Tx, Ty, D, p);
   if (lds > 160 * 1024) {
-    set_error("fastdtw: Tx=%d, Ty=%d, radius=%d needs %zu bytes of LDS (> 160 KiB)", Tx, Ty, radius, lds);
+    set_error("fastdtw: Tx=%d, Ty=%d, D=%d, radius=%d needs %zu bytes of LDS (> 160 KiB)", Tx, Ty, D, radius, lds);
     return MLPG_HIP_EINVAL;
   }
   p.pyr = (double *)scratch(device, 1, sizeof(double) * p.pyr_stride * (size_t)N);
