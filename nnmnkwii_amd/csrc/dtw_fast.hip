@@ -292,41 +292,46 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
       double up_old = (lane == 0 && s0 - 1 >= prevlo && s0 - 1 <= prevhi) ? dprev[s0 - 1 - prevlo] : INFINITY;
       double left = INFINITY;
       unsigned long long word = 0ull;
-      // prefetched for step s0: local cost and (lane 0) the previous chunk's last row at column j
-      int j = s0 - lane;
-      int cj = j - mylo;
-      cj = cj < 0 ? 0 : (cj > myhi - mylo ? (myhi > mylo ? myhi - mylo : 0) : cj);
-      double dt_n = dchunk[cbase + cj];
-      double pv_n = (j >= prevlo && j <= prevhi) ? dprev[j - prevlo] : INFINITY;
+      const int wmax = myhi > mylo ? myhi - mylo : 0;
+      const int pmax = prevhi > prevlo ? prevhi - prevlo : 0;
+      // The only loop-carried chain is add -> compare -> select -> DPP; everything the step needs
+      // from LDS (its local cost and, for the chunk's first row, the previous chunk's last row) is
+      // fetched TWO steps ahead so that no step waits on an LDS round trip.
+      auto fetch_dt = [&](int jj) {
+        int c = jj - mylo;
+        c = c < 0 ? 0 : (c > wmax ? wmax : c);
+        return dchunk[cbase + c];
+      };
+      auto fetch_pv = [&](int jj) {
+        int c = jj - prevlo;
+        const bool in = c >= 0 && c <= prevhi - prevlo;
+        c = c < 0 ? 0 : (c > pmax ? pmax : c);
+        const double v = dprev[c];
+        return in ? v : INFINITY;
+      };
+      double dt_a = fetch_dt(s0 - lane), dt_b = fetch_dt(s0 + 1 - lane);
+      double pv_a = fetch_pv(s0 - lane), pv_b = fetch_pv(s0 + 1 - lane);
       for (int s = s0; s <= s1; ++s) {
-        j = s - lane;
-        const double dt = dt_n;
+        const int j = s - lane;
+        const double dt = dt_a;
         double up_new = wave_shr1(pub);
-        if (lane == 0) up_new = pv_n;
-        // prefetch for the next step (column j + 1)
-        {
-          int cn = j + 1 - mylo;
-          cn = cn < 0 ? 0 : (cn > myhi - mylo ? (myhi > mylo ? myhi - mylo : 0) : cn);
-          dt_n = dchunk[cbase + cn];
-          pv_n = (j + 1 >= prevlo && j + 1 <= prevhi) ? dprev[j + 1 - prevlo] : INFINITY;
-        }
+        up_new = (lane == 0) ? pv_a : up_new;
+        dt_a = dt_b;
+        pv_a = pv_b;
+        dt_b = fetch_dt(j + 2);
+        pv_b = fetch_pv(j + 2);
         const bool inwin = act && j >= mylo && j <= myhi;
-        double npub = INFINITY;
+        double up = first_row ? INFINITY : up_new;
+        double dg = first_row ? ((j == 0) ? 0.0 : INFINITY) : up_old;
+        const double lf = (j - 1 >= mylo) ? left : INFINITY;
+        const double cu = __dadd_rn(up, dt), cl = __dadd_rn(lf, dt), cd = __dadd_rn(dg, dt);
+        double best = cu;
+        unsigned long long code = 0ull;
+        if (cl < best) { best = cl; code = 1ull; }
+        if (cd < best) { best = cd; code = 2ull; }
+        const int cpos = j - mylo;
         if (inwin) {
-          double up = up_new, dg = up_old;
-          if (first_row) {
-            up = INFINITY;
-            dg = (j == 0) ? 0.0 : INFINITY;
-          }
-          const double lf = (j - 1 >= mylo) ? left : INFINITY;
-          const double cu = __dadd_rn(up, dt), cl = __dadd_rn(lf, dt), cd = __dadd_rn(dg, dt);
-          double best = cu;
-          unsigned long long code = 0ull;
-          if (cl < best) { best = cl; code = 1ull; }
-          if (cd < best) { best = cd; code = 2ull; }
           left = best;
-          npub = best;
-          const int cpos = j - mylo;
           word |= code << (2 * (cpos & 31));
           if ((cpos & 31) == 31 || j == myhi) {
             bpw[wbase + (cpos >> 5)] = word;
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
           }
           if (is_last) dnext[cpos] = best;
         }
-        pub = npub;
+        pub = inwin ? best : INFINITY;
         up_old = up_new;
       }
       // value of the chunk's last cell (bottom-right corner of the level if this is the last chunk)
@@ -351,57 +356,68 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
     if (fail) break;
     level_cost = (prevhi == lty - 1) ? last_val : INFINITY;
 
-    // ---- 3. back-trace (one lane), path written from the end of the buffer ----
-    if (lane == 0) {
-      int i = ltx - 1, j = lty - 1, pos = pcap;
-      int ok = (level_cost < INFINITY) ? 1 : 0;
-      int rl = (int)lo[i], rw = woff[i];
-      int widx = (j - rl) >> 5;
-      unsigned long long word = bpw[rw + widx];
-      // prefetch of the row above: its lo, word base and first word
-      int nrl = i > 0 ? (int)lo[i - 1] : 0, nrw = i > 0 ? woff[i - 1] : 0, nrh = i > 0 ? (int)hi[i - 1] : -1;
-      unsigned long long nword0 = i > 0 ? bpw[nrw] : 0ull;
+    // ---- 3. back-trace: every lane walks the same (wave-uniform) path; the (lo, hi, first
+    // back-pointer word) of 64 rows at a time are cached one row per lane and read with
+    // v_readlane, so a step costs a handful of scalar instructions instead of LDS round trips ----
+    {
+      int bi = ltx - 1, bj = lty - 1, pos = pcap;
+      int ok = __builtin_amdgcn_readfirstlane((level_cost < INFINITY) ? 1 : 0);
+      int rb = ltx;  // base row of the cached block (forces the first load)
+      int vlo = 0, vhi = -1, vwo = 0;
+      unsigned vw_lo = 0u, vw_hi = 0u;
       while (ok) {
-        if (pos == 0) { ok = 0; break; }
-        --pos;
-        pth_i[pos] = (unsigned short)i;
-        pth_j[pos] = (unsigned short)j;
-        const int cpos = j - rl;
-        const unsigned code = (unsigned)((word >> (2 * (cpos & 31))) & 3ull);
-        if (code == 1) {
-          j -= 1;
-          if (j < rl) { ok = 0; break; }
-          if (((j - rl) >> 5) != widx) {
-            widx = (j - rl) >> 5;
-            word = bpw[rw + widx];
+        if (bi < rb) {
+          rb = bi - 63 < 0 ? 0 : bi - 63;
+          const int idx = rb + lane;
+          const bool v = idx <= bi;
+          vlo = v ? (int)lo[idx] : 0;
+          vhi = v ? (int)hi[idx] : -1;
+          vwo = v ? woff[idx] : 0;
+          const unsigned long long w = v ? bpw[vwo] : 0ull;
+          vw_lo = (unsigned)w;
+          vw_hi = (unsigned)(w >> 32);
+        }
+        const int L = bi - rb;
+        const int rl = __builtin_amdgcn_readlane(vlo, L), rh = __builtin_amdgcn_readlane(vhi, L);
+        const int rwo = __builtin_amdgcn_readlane(vwo, L);
+        const unsigned long long w0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vw_hi, L) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)vw_lo, L);
+        if (bj < rl || bj > rh) { ok = 0; break; }
+        // cells of this row on the path: move left while the back-pointer says so
+        while (true) {
+          if (pos == 0) { ok = 0; break; }
+          --pos;
+          if (lane == 0) {
+            pth_i[pos] = (unsigned short)bi;
+            pth_j[pos] = (unsigned short)bj;
           }
-        } else {
-          if (code == 2) j -= 1;
-          i -= 1;
-          if (i < 0) {
-            if (j != -1) ok = 0;
-            break;
+          const int cpos = bj - rl;
+          unsigned long long w = w0;
+          if (cpos >= 32) {  // wide row: the word is not the cached one
+            const unsigned long long wl = bpw[rwo + (cpos >> 5)];
+            w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wl >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wl);
           }
-          rl = nrl;
-          rw = nrw;
-          if (j < rl || j > nrh) { ok = 0; break; }
-          widx = (j - rl) >> 5;
-          word = widx == 0 ? nword0 : bpw[rw + widx];
-          if (i > 0) {
-            nrl = (int)lo[i - 1];
-            nrw = woff[i - 1];
-            nrh = (int)hi[i - 1];
-            nword0 = bpw[nrw];
+          const unsigned code = (unsigned)((w >> (2 * (cpos & 31))) & 3ull);
+          if (code == 1u) {
+            bj -= 1;
+            if (bj < rl) { ok = 0; break; }
+            continue;
           }
+          if (code == 2u) bj -= 1;
+          bi -= 1;
+          break;
+        }
+        if (!ok) break;
+        if (bi < 0) {
+          if (bj != -1) ok = 0;
+          break;
         }
       }
-      bcast[0] = pos;
-      bcast[1] = ok;
+      pstart = pos;
+      pn = pcap - pstart;
+      if (!ok) fail = true;
     }
-    __syncthreads();
-    pstart = bcast[0];
-    pn = pcap - pstart;
-    if (!bcast[1]) fail = true;
     __syncthreads();
     DTW_TICK(5);
   }
