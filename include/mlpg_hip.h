@@ -107,6 +107,20 @@ int mlpg_hip_backward(int device, void *stream, int in_dtype, int out_dtype,
                       int32_t *status);
 
 /*
+ * Delta features (the step BEFORE MLPG in every pipeline).  Replaces
+ * preprocessing.delta_features (preprocessing/generic.py:229-288: a Python loop over feature
+ * dims of np.correlate(x[:, d], window, "same")), batched:
+ *   out[b, t, w*D + d] = sum_{k=-l_w}^{u_w} coeff_w[l_w + k] * x[b, t + k, d]      (x = 0 outside [0, len_b))
+ * x : (B, Tmax, D) dtype, out : (B, Tmax, D*nw) dtype; accumulation in float64.  For a window
+ * array of length L the reference's "same" correlation is l = L-1-(L-1)/2, u = (L-1)/2.
+ */
+int mlpg_hip_delta_features(int device, void *stream, int dtype, const void *x,
+                            const int32_t *lengths, int B, int Tmax, int D,
+                            int num_windows, const int32_t *win_l_h,
+                            const int32_t *win_u_h, const double *win_coef_h,
+                            void *out);
+
+/*
  * Trailing-zero trim.  Replaces preprocessing.trim_zeros_frames with trim="b"
  * (preprocessing/generic.py:291-332) applied to every utterance of a padded
  * (N, T, D) batch: lengths[n] = number of frames left after dropping trailing

@@ -25,6 +25,7 @@ EXPORTS = (
     "mlpg_hip_shutdown",
     "mlpg_hip_forward",
     "mlpg_hip_backward",
+    "mlpg_hip_delta_features",
     "mlpg_hip_trim_lengths",
     "mlpg_hip_fastdtw_l2",
     "mlpg_hip_gather_path",
@@ -68,6 +69,8 @@ def lib():
         L.mlpg_hip_forward.argtypes = [ci, vp, ci, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
         L.mlpg_hip_backward.restype = ci
         L.mlpg_hip_backward.argtypes = [ci, vp, ci, ci, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
+        L.mlpg_hip_delta_features.restype = ci
+        L.mlpg_hip_delta_features.argtypes = [ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp]
         L.mlpg_hip_trim_lengths.restype = ci
         L.mlpg_hip_trim_lengths.argtypes = [ci, vp, ci, vp, ci, ci, ci, cd, vp]
         L.mlpg_hip_fastdtw_l2.restype = ci
@@ -202,6 +205,20 @@ def backward(var, grad_out, windows, D, lengths=None, out_dtype=None, algo=ALGO_
                                  _p(grad), _p(status))
     _check(rc, "mlpg_hip_backward")
     return grad, status
+
+
+def delta_features(x, windows, lengths=None):
+    """Batched delta features on device tensors: x (B, T, D) -> (B, T, D * len(windows))."""
+    torch = torch_mod()
+    assert x.is_cuda and x.dim() == 3 and x.is_contiguous()
+    B, T, D = x.shape
+    nw = len(windows)
+    wl, wu, wc = pack_windows(windows)
+    out = torch.empty((B, T, D * nw), dtype=x.dtype, device=x.device)
+    rc = lib().mlpg_hip_delta_features(x.device.index, _stream(x.device), _dt(x), _p(x), _p(lengths), B, T, D, nw,
+                                       _np(wl), _np(wu), _np(wc), _p(out))
+    _check(rc, "mlpg_hip_delta_features")
+    return out
 
 
 def trim_lengths(X, eps=1e-7):

@@ -221,6 +221,30 @@ __attribute__((visibility("default"))) int mlpg_hip_backward(int device, void *s
                      Tmax, D, num_windows, win_l_h, win_u_h, win_coef_h, grad_mean, status);
 }
 
+__attribute__((visibility("default"))) int mlpg_hip_delta_features(int device, void *stream, int dtype, const void *x,
+                                                                   const int32_t *lengths, int B, int Tmax, int D,
+                                                                   int num_windows, const int32_t *win_l_h,
+                                                                   const int32_t *win_u_h, const double *win_coef_h,
+                                                                   void *out) {
+  if (B < 0 || Tmax < 0 || D < 0 || (dtype != MLPG_HIP_F32 && dtype != MLPG_HIP_F64)) {
+    set_error("delta_features: bad arguments");
+    return MLPG_HIP_EINVAL;
+  }
+  WinSet ws;
+  if (int rc = pack_windows(num_windows, win_l_h, win_u_h, win_coef_h, &ws)) return rc;
+  if ((long)B * Tmax * D == 0) return 0;
+  if (!x || !out) {
+    set_error("delta_features: NULL pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  return launch_delta((hipStream_t)stream, dtype, x, lengths, B, Tmax, D, ws, out);
+}
+
 __attribute__((visibility("default"))) int mlpg_hip_trim_lengths(int device, void *stream, int dtype, const void *X,
                                                                  int N, int T, int D, double eps,
                                                                  int32_t *lengths) {

@@ -46,6 +46,8 @@ int launch_generic(hipStream_t s, int dtype, int out_dtype, bool backward, const
 bool wave_supported(const Problem &p, const WinSet &w);
 int launch_wave(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
                 int device);
+int launch_delta(hipStream_t s, int dtype, const void *x, const int32_t *lengths, int B, int Tmax, int D,
+                 const WinSet &w, void *out);
 int launch_trim(hipStream_t s, int dtype, const void *X, int N, int T, int D, double eps, int32_t *lengths);
 int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, const int32_t *lenx,
                    const int32_t *leny, int N, int Tx, int Ty, int D, int radius, int32_t *path_i,

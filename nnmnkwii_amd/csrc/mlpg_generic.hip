@@ -145,7 +145,50 @@ int launch_t(hipStream_t st, const Problem &p, const WinSet &w, int device) {
   return MLPG_HIP_EINVAL;
 }
 
+// Delta features: out[b, t, w*D + d] = sum_k c_w[l_w + k] x[b, t + k, d]; one thread per (b, t, d),
+// adjacent lanes = adjacent d (coalesced); the +-l/u neighbour rows come from L1/L2.
+template <typename T>
+__global__ void delta_kernel(const T *__restrict__ x, const int32_t *__restrict__ lengths, int B, int Tmax, int D,
+                             WinSet ws, T *__restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * Tmax * D;
+  if (e >= total) return;
+  const int d = (int)(e % D);
+  const long bt = e / D;
+  const int t = (int)(bt % Tmax), b = (int)(bt / Tmax);
+  int len = lengths ? lengths[b] : Tmax;
+  len = len < 0 ? 0 : (len > Tmax ? Tmax : len);
+  const T *xb = x + (size_t)b * Tmax * D;
+  T *ob = out + ((size_t)b * Tmax + t) * ((size_t)D * ws.nw);
+  for (int w = 0; w < ws.nw; ++w) {
+    double acc = 0.0;
+    if (t < len) {
+      const double *c = ws.c + ws.off[w];
+      for (int k = -ws.l[w]; k <= ws.u[w]; ++k) {
+        const int tt = t + k;
+        if (tt >= 0 && tt < len) acc += c[ws.l[w] + k] * (double)xb[(size_t)tt * D + d];
+      }
+    }
+    ob[(size_t)w * D + d] = (T)acc;
+  }
+}
+
 }  // namespace
+
+int launch_delta(hipStream_t st, int dtype, const void *x, const int32_t *lengths, int B, int Tmax, int D,
+                 const WinSet &w, void *out) {
+  const long total = (long)B * Tmax * D;
+  if (total == 0) return 0;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (dtype == MLPG_HIP_F32)
+    hipLaunchKernelGGL(delta_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, lengths, B, Tmax, D, w,
+                       (float *)out);
+  else
+    hipLaunchKernelGGL(delta_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)x, lengths, B, Tmax, D, w,
+                       (double *)out);
+  MLPG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 
 int launch_generic(hipStream_t st, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
                    int device) {

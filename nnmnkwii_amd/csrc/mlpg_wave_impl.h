@@ -42,6 +42,9 @@
 #ifndef MLPG_WAVE_DMA_AUX
 #define MLPG_WAVE_DMA_AUX 0  // cache policy bits of the LDS-DMA loads (1 sc0, 2 nt, 16 sc1)
 #endif
+#ifndef MLPG_WAVE_PARK
+#define MLPG_WAVE_PARK 1  // park the multipliers in LDS during the cyclic reduction
+#endif
 #ifndef MLPG_WAVE_ABLATE
 #define MLPG_WAVE_ABLATE 0  // profiling only: 1 skip the solve, 2 skip the global loads, 4 = 1 + skip assembly math
 #endif
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
 
   // ---- 2-4. solve ----
 #if MLPG_WAVE_ABLATE != 1 && MLPG_WAVE_ABLATE != 4
-  constexpr bool kPark = (M >= 16) && MINW >= 2;
+  constexpr bool kPark = (M >= 16) && MINW >= 2 && MLPG_WAVE_PARK;
   // parking rows live in the (now idle) tiles, register layout footprint
   const bool bad = solve_chunk<M, kPark>(Pd, P1, P2, rhs, lane, (double *)tileA + wv * RL::TPAD + lane * (M + kSkew),
                                          (double *)tileB + wv * RL::TPAD + lane * (M + kSkew));

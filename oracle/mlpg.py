@@ -198,3 +198,16 @@ def reshape_means(means, static_dim):
     if D == static_dim:
         return means
     return means.reshape(T, -1, static_dim).transpose(1, 0, 2).reshape(-1, static_dim)
+
+
+def delta_features(x, windows):
+    """preprocessing.delta_features restated (preprocessing/generic.py:229-288): per feature
+    dimension, np.correlate(x[:, d], window, "same"); tuple windows use their coefficient array."""
+    x = np.asarray(x)
+    T, D = x.shape
+    out = np.empty((T, D * len(windows)), dtype=x.dtype)
+    for idx, w in enumerate(windows):
+        win = w[2] if isinstance(w, tuple) else w
+        for d in range(D):
+            out[:, D * idx + d] = np.correlate(x[:, d], win, mode="same")
+    return out

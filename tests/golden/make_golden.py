@@ -21,6 +21,11 @@ sys.path.insert(0, HERE)
 from cases import WINDOW_SETS, c2_utterance, rand_case  # noqa: E402
 
 
+def _seed_for(*parts):
+    import zlib
+    return zlib.crc32("/".join(str(p) for p in parts).encode()) & 0x7FFFFFFF
+
+
 def main():
     import nnmnkwii
     from nnmnkwii import paramgen as G
@@ -120,6 +125,18 @@ def main():
             out[key + "/target"] = tg2.numpy().copy()
             out[key + "/y"] = y2.detach().numpy().copy()
             out[key + "/grad"] = m2.grad.numpy().copy()
+
+    # --- delta_features (preprocessing/generic.py:250-288), tuple windows and plain arrays
+    from nnmnkwii.preprocessing import delta_features
+    for wname, windows in WINDOW_SETS.items():
+        for dt in ("f32", "f64"):
+            for T in (5, 12, 40):
+                x = np.random.RandomState(_seed_for(wname, dt, T)).randn(T, 3).astype(np.float32 if dt == "f32" else np.float64)
+                out["delta/%s-%s-T%d/x" % (wname, dt, T)] = x
+                out["delta/%s-%s-T%d/y" % (wname, dt, T)] = delta_features(x, windows)
+    x = np.random.RandomState(5).randn(9, 2)
+    out["delta/plain/x"] = x
+    out["delta/plain/y"] = delta_features(x, [np.array([1.0]), np.array([0.25, 0.5, -1.0, 2.0]), np.array([-0.5, 0.0, 0.5])])
 
     # --- error behaviour: negative variance -> LinAlgError text
     m, v, _ = rand_case("std3", "f64", 10, 1)

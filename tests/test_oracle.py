@@ -142,3 +142,17 @@ def test_dtw_align_reference_properties():
     assert Xa.shape == Ya.shape and Xa.shape[0] == 4 and Xa.shape[1] >= 75
     Xb, Yb, _, _ = OD.dtw_align(X, Y, use_c=False)
     assert np.array_equal(Xa, Xb) and np.array_equal(Ya, Yb)
+
+
+def test_delta_features_oracle_vs_reference(golden):
+    n = 0
+    for k in golden.files:
+        if k.startswith("delta/") and k.endswith("/y") and k != "delta/plain/y":
+            wname = k.split("/")[1].split("-")[0]
+            y = O.delta_features(golden[k[:-1] + "x"], WINDOW_SETS[wname])
+            assert y.dtype == golden[k].dtype and np.array_equal(y, golden[k]), k
+            n += 1
+    assert n == 36
+    y = O.delta_features(golden["delta/plain/x"], [np.array([1.0]), np.array([0.25, 0.5, -1.0, 2.0]),
+                                                   np.array([-0.5, 0.0, 0.5])])
+    assert np.array_equal(y, golden["delta/plain/y"])
