@@ -46,12 +46,90 @@ def parse():
     return ap.parse_args()
 
 
+_REF_WORKER = r"""
+import sys, time, numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import ref
+G = ref.load()
+n, T, D, seed = (int(a) for a in sys.argv[2:6])
+W = [(0, 0, np.array([1.0])), (1, 1, np.array([-0.5, 0.0, 0.5])), (1, 1, np.array([1.0, -2.0, 1.0]))]
+rng = np.random.RandomState(seed)
+m = rng.randn(T, D); v = rng.rand(T, D) + 0.1
+G.mlpg(m, v, W)
+sys.stdin.readline()              # start gun
+t0 = time.perf_counter()
+for _ in range(n):
+    G.mlpg(m, v, W)
+print(time.perf_counter() - t0)
+"""
+
+
+def _reference_pool(n_per_proc, T, D, cores, timeout):
+    """The reference's mlpg on `cores` independent processes (it has no threading of its own).
+    Plain subprocesses with a hard timeout: this leg must never be able to hang the bench."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, "-c", _REF_WORKER, ROOT, str(n_per_proc), str(T), str(D), str(100 + i)],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+             for i in range(cores)]
+    try:
+        time.sleep(min(10.0, 1.0 + 0.05 * cores))          # let every process import and warm up
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        outs = [p.communicate(timeout=timeout)[0] for p in procs]
+        wall = time.perf_counter() - t0
+        busy = [float(o.strip().splitlines()[-1]) for o in outs]
+        return cores * n_per_proc * T / max(max(busy), 1e-9), wall
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+
+
 def cpu_baseline(T, D, seconds):
-    """Oracle (C port of the reference's numpy/bandmat/Cython path) timed on ONE host core
-    on a bounded sample of the same workload."""
+    """CPU path timed on the GPU box's host, bounded sample of the same workload.
+
+    kind "reference": the reference's OWN numpy/bandmat/Cython code (oracle/_ref: its sources
+    compiled unmodified by oracle/build_ref_so.sh), called the way the reference batches -- a
+    Python loop of paramgen.mlpg over utterances (util/__init__.py:44-66) -- on ONE core (the
+    reference is single-threaded).  kind "port": the C restatement oracle/mlpg_oracle.c, if the
+    compiled reference is not present."""
     from oracle import mlpg as O
+    from oracle import ref
     O.build()
     rng = np.random.RandomState(1234)
+    if ref.available():
+        G = ref.load()
+        m = rng.randn(T, D)
+        v = rng.rand(T, D) + 0.1
+        y = G.mlpg(m, v, WINDOWS)
+        assert np.array_equal(y, O.mlpg(m, v, WINDOWS)), "C oracle and compiled reference disagree"
+        t0 = time.perf_counter()
+        G.mlpg(m, v, WINDOWS)
+        per = time.perf_counter() - t0
+        n = int(max(8, min(4096, seconds / max(per, 1e-6))))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            G.mlpg(m, v, WINDOWS)
+        dt = time.perf_counter() - t0
+        res = {
+            "value": n * T / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
+            "sample": "%d utterances x T=%d x D=%d float64 through the reference's own paramgen.mlpg "
+                      "(numpy + bandmat Cython, compiled unmodified into oracle/_ref), Python loop over utterances, "
+                      "%.1f s on 1 core of %d" % (n, T, D, dt, os.cpu_count()),
+        }
+        # the same on many cores (independent processes; the reference itself has no threading)
+        try:
+            cores = max(1, min(os.cpu_count() or 1, 64))
+            per_proc = max(2, int(0.2 * n))
+            rate, wall = _reference_pool(per_proc, T, D, cores, timeout=max(60.0, 6 * seconds))
+            res["pool"] = {"value": rate, "unit": "frames/s", "cores": cores,
+                           "sample": "%d processes x %d utterances each, %.1f s wall" % (cores, per_proc, wall)}
+        except Exception as e:  # the single-core figure is the reported baseline
+            res["pool"] = {"error": str(e)[:200]}
+        return res
     m = rng.randn(4, T, D)
     v = rng.rand(4, T, D) + 0.1
     t0 = time.perf_counter()

@@ -156,3 +156,24 @@ def test_delta_features_oracle_vs_reference(golden):
     y = O.delta_features(golden["delta/plain/x"], [np.array([1.0]), np.array([0.25, 0.5, -1.0, 2.0]),
                                                    np.array([-0.5, 0.0, 0.5])])
     assert np.array_equal(y, golden["delta/plain/y"])
+
+
+def test_oracle_vs_compiled_reference():
+    """Where oracle/_ref (the reference's own modules, compiled by oracle/build_ref_so.sh) is
+    present, the C restatement must match it bit for bit on fresh random inputs."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built")
+    G = ref.load()
+    rng = np.random.RandomState(2024)
+    for wname in ("std3", "wide3", "std2"):
+        windows = WINDOW_SETS[wname]
+        nw = len(windows)
+        for T in (7, 64, 301):
+            m = rng.randn(T, nw * 3)
+            v = rng.rand(T, nw * 3) + 0.05
+            assert np.array_equal(O.mlpg(m, v, windows), G.mlpg(m, v, windows))
+            m32, v32 = m.astype(np.float32), v.astype(np.float32)
+            assert np.array_equal(O.mlpg(m32, v32, windows), G.mlpg(m32, v32, windows))
+        R = G.unit_variance_mlpg_matrix(windows, 12)
+        assert np.abs(R - O.unit_variance_mlpg_matrix(windows, 12)).max() <= 1e-7
