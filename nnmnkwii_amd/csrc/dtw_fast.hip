@@ -62,7 +62,8 @@ struct DtwParams {
 };
 
 constexpr int kMaxLevels = 20;
-constexpr int kRows = 64;  // rows per chunk = lanes
+constexpr int kRows = 64;  // rows per chunk = lanes of the sweeping wavefront
+constexpr int kThreads = 256;  // 4 wavefronts per pair: all of them stage/halve/compute local costs, wavefront 0 sweeps
 
 __device__ __forceinline__ double l2_cost(const double *__restrict__ a, const double *__restrict__ b, int D) {
   double acc = 0.0;
@@ -92,9 +93,10 @@ __device__ __forceinline__ double wave_shr1(double v) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
+__global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool w0 = tid < 64;  // the sweeping wavefront
   const int n = blockIdx.x;
   const int Tx = p.Tx, Ty = p.Ty, D = p.D, r = p.radius;
   const int pcap = Tx + Ty;
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
   int *woff = off + (Tx + 1);                      // back-pointer word offset of each row
   int *lvl_x = woff + (Tx + 1);
   int *lvl_y = lvl_x + kMaxLevels;
-  int *bcast = lvl_y + kMaxLevels;  // [4]
-  unsigned short *lo = (unsigned short *)(bcast + 4);
+  int *bcast = lvl_y + kMaxLevels;  // [8]
+  unsigned short *lo = (unsigned short *)(bcast + 8);
   unsigned short *hi = lo + Tx;
   unsigned short *cfirst = hi + Tx;
   unsigned short *clast = cfirst + (Tx / 2 + 2);
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
   int32_t *out_i = p.path_i + (size_t)n * pcap;
   int32_t *out_j = p.path_j + (size_t)n * pcap;
   if (tx < 1 || ty < 1 || tx > Tx || ty > Ty) {
-    if (lane == 0) {
+    if (tid == 0) {
       p.path_len[n] = 0;
       p.cost[n] = NAN;
     }
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
   while (K < kMaxLevels - 1 && (tx >> K) >= r + 2 && (ty >> K) >= r + 2) ++K;
 
   // ---- 1. pyramid (levels 1..K) ----
-  if (lane == 0) {
+  if (tid == 0) {
     int xo = 0, yo = 0;
     for (int k = 1; k <= K; ++k) {
       lvl_x[k] = xo;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
     for (int k = 1; k <= K; ++k) {
       double *dst = base + lvl[k];
       const int cnt = (len0 >> k) * D;
-      for (int e = lane; e < cnt; e += 64) {
+      for (int e = tid; e < cnt; e += kThreads) {
         const int row = e / D, c = e - row * D;
         dst[e] = __dadd_rn(src[(size_t)(2 * row) * D + c], src[(size_t)(2 * row + 1) * D + c]) * 0.5;
       }
@@ -182,19 +184,19 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
 
     // ---- 2a. per-row windows ----
     if (k == K) {
-      for (int i = lane; i < ltx; i += 64) {
+      for (int i = tid; i < ltx; i += kThreads) {
         lo[i] = 0;
         hi[i] = (unsigned short)(lty - 1);
       }
     } else {
       const int cx = tx >> (k + 1);
-      for (int q = lane; q < pn; q += 64) {
+      for (int q = tid; q < pn; q += kThreads) {
         const int pi = pth_i[pstart + q], pj = pth_j[pstart + q];
         if (q == 0 || pth_i[pstart + q - 1] != pi) cfirst[pi] = (unsigned short)pj;
         if (q == pn - 1 || pth_i[pstart + q + 1] != pi) clast[pi] = (unsigned short)pj;
       }
       __syncthreads();
-      for (int i = lane; i < ltx; i += 64) {
+      for (int i = tid; i < ltx; i += kThreads) {
         const int ci = i >> 1;
         const int r0 = ci - r < 0 ? 0 : ci - r;
         const int r1 = ci + r > cx - 1 ? cx - 1 : ci + r;
@@ -206,8 +208,8 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
     }
     __syncthreads();
 
-    // ---- 2b. row offsets: cells (off) and back-pointer words (woff) ----
-    {
+    // ---- 2b. row offsets: cells (off) and back-pointer words (woff); wavefront 0 ----
+    if (w0) {
       const int rpl = (ltx + 63) / 64;
       const int b0 = lane * rpl < ltx ? lane * rpl : ltx;
       const int b1 = b0 + rpl < ltx ? b0 + rpl : ltx;
@@ -230,10 +232,11 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
       if (lane == 0) {
         off[ltx] = total;
         woff[ltx] = wtotal;
+        bcast[3] = (total > p.cellcap || wtotal > p.wordcap) ? 1 : 0;
       }
-      if (total > p.cellcap || wtotal > p.wordcap) fail = true;
     }
     __syncthreads();
+    if (bcast[3]) fail = true;
     if (fail) break;
 
     DTW_TICK(1);
@@ -246,10 +249,14 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
       const int base = off[i0];
       const int ylo = (int)lo[i0];
       const bool wide = ((int)hi[i0] - ylo + 1) > p.ycap;  // a single row wider than the y stage
-      const bool fits = (i0 + lane < ltx) && (off[i0 + lane + 1] - base <= p.chunkcap) &&
-                        (wide || ((int)hi[i0 + lane] - ylo + 1) <= p.ycap);
-      const unsigned long long m = __ballot(fits);
-      const int R = (~m == 0ull) ? 64 : (__ffsll((long long)~m) - 1);
+      if (w0) {
+        const bool fits = (i0 + lane < ltx) && (off[i0 + lane + 1] - base <= p.chunkcap) &&
+                          (wide || ((int)hi[i0 + lane] - ylo + 1) <= p.ycap);
+        const unsigned long long m = __ballot(fits);
+        if (lane == 0) bcast[2] = (~m == 0ull) ? 64 : (__ffsll((long long)~m) - 1);
+      }
+      __syncthreads();
+      const int R = bcast[2];
       if (R < 1) {
         fail = true;
         break;
@@ -257,13 +264,13 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
       const int ncell = off[i0 + R] - base;
       const int yhi = (int)hi[i0 + R - 1];
       // stage the chunk's x rows (and y rows unless `wide`): contiguous coalesced copies
-      for (int e = lane; e < R * D; e += 64) xs[e] = xk[(size_t)i0 * D + e];
+      for (int e = tid; e < R * D; e += kThreads) xs[e] = xk[(size_t)i0 * D + e];
       if (!wide)
-        for (int e = lane; e < (yhi - ylo + 1) * D; e += 64) ys[e] = yk[(size_t)ylo * D + e];
+        for (int e = tid; e < (yhi - ylo + 1) * D; e += kThreads) ys[e] = yk[(size_t)ylo * D + e];
       __syncthreads();
       DTW_TICK(2);
       // local costs of every window cell of the chunk
-      for (int c = lane; c < ncell; c += 64) {
+      for (int c = tid; c < ncell; c += kThreads) {
         int a = 0, b = R;
         while (b - a > 1) {
           const int mid = (a + b) >> 1;
@@ -276,7 +283,8 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
       __syncthreads();
       DTW_TICK(3);
 
-      // anti-diagonal sweep: lane = row, step s handles column s - lane
+      // anti-diagonal sweep (wavefront 0): lane = row, step s handles column s - lane
+      if (w0) {
       const bool act = lane < R;
       const int i = i0 + lane;
       const int mylo = act ? (int)lo[i] : 0, myhi = act ? (int)hi[i] : -1;
@@ -344,6 +352,7 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
       }
       // value of the chunk's last cell (bottom-right corner of the level if this is the last chunk)
       last_val = __shfl(left, R - 1);
+      }  // w0
       prevlo = (int)lo[i0 + R - 1];
       prevhi = (int)hi[i0 + R - 1];
       double *tsw = dprev;
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
     // ---- 3. back-trace: every lane walks the same (wave-uniform) path; the (lo, hi, first
     // back-pointer word) of 64 rows at a time are cached one row per lane and read with
     // v_readlane, so a step costs a handful of scalar instructions instead of LDS round trips ----
-    {
+    if (w0) {
       int bi = ltx - 1, bj = lty - 1, pos = pcap;
       int ok = __builtin_amdgcn_readfirstlane((level_cost < INFINITY) ? 1 : 0);
       int rb = ltx;  // base row of the cached block (forces the first load)
@@ -414,33 +423,38 @@ __global__ __launch_bounds__(64) void fastdtw_kernel(DtwParams p) {
           break;
         }
       }
-      pstart = pos;
-      pn = pcap - pstart;
-      if (!ok) fail = true;
+      if (lane == 0) {
+        bcast[0] = pos;
+        bcast[1] = ok;
+      }
     }
+    __syncthreads();
+    pstart = bcast[0];
+    pn = pcap - pstart;
+    if (!bcast[1]) fail = true;
     __syncthreads();
     DTW_TICK(5);
   }
 
   if (fail) {
-    if (lane == 0) {
+    if (tid == 0) {
       p.path_len[n] = 0;
       p.cost[n] = NAN;
     }
     return;
   }
-  for (int q = lane; q < pn; q += 64) {
+  for (int q = tid; q < pn; q += kThreads) {
     out_i[q] = pth_i[pstart + q];
     out_j[q] = pth_j[pstart + q];
   }
-  if (lane == 0) {
+  if (tid == 0) {
     p.path_len[n] = pn;
     p.cost[n] = level_cost;
   }
 #ifdef MLPG_DTW_TIMING
   DTW_TICK(6);
   __syncthreads();
-  if (lane == 0)
+  if (tid == 0)
     for (int q = 0; q < 7; ++q) out_i[pcap - 8 + q] = (int)(tq[q] >> 4);   // profiling build: cycles / 16 in the tail of path_i
 #endif
 }
@@ -449,7 +463,7 @@ size_t lds_bytes(int Tx, int Ty, int D, const DtwParams &p) {
   size_t b = 0;
   b += sizeof(double) * ((size_t)p.chunkcap + 2 * (size_t)Ty + (size_t)kRows * D + (size_t)p.ycap * D);
   b += sizeof(unsigned long long) * (size_t)p.wordcap;
-  b += sizeof(int) * ((size_t)2 * (Tx + 1) + 2 * kMaxLevels + 4);
+  b += sizeof(int) * ((size_t)2 * (Tx + 1) + 2 * kMaxLevels + 8);
   b += sizeof(unsigned short) * ((size_t)2 * Tx + 2 * (Tx / 2 + 2) + 2 * (size_t)(Tx + Ty));
   return (b + 15) & ~(size_t)15;
 }
@@ -488,7 +502,7 @@ int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, 
   if (!p.pyr) return MLPG_HIP_ENOMEM;
   MLPG_HIP_CHECK(hipFuncSetAttribute((const void *)fastdtw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
-  hipLaunchKernelGGL(fastdtw_kernel, dim3(N), dim3(64), lds, s, p);
+  hipLaunchKernelGGL(fastdtw_kernel, dim3(N), dim3(kThreads), lds, s, p);
   MLPG_HIP_CHECK(hipGetLastError());
   return 0;
 }

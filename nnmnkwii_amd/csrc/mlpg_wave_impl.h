@@ -168,15 +168,33 @@ __device__ __forceinline__ void load_tile_dma(TIN *__restrict__ tile, const TIN 
 }
 
 // LDS -> global: dst[t * row_stride + g] = tile[g][t] (register layout) for t < T, 0 for T <= t < Tmax.
+// Each thread moves a PAIR of adjacent columns per frame (one 16-byte store for float64 when the
+// run is 16-byte aligned), 128 frames apart per iteration; all index arithmetic is incremental.
 template <int M, typename TOUT>
 __device__ __forceinline__ void store_tile(const TOUT *__restrict__ tile, TOUT *__restrict__ dst, int row_stride, int T,
-                                           int Tmax, int gvalid, int tid) {
-  const int g = tid % kG;
-  if (g >= gvalid) return;
-  const int total = Tmax * kG;
-  for (int e = tid; e < total; e += kG * 64) {
-    const int t = e / kG;
-    dst[(size_t)t * row_stride + g] = t < T ? tile[RegLayout<M>::idx(t, g)] : (TOUT)0;
+                                           int Tmax, int gvalid, int tid, bool aligned_pairs) {
+  using RL = RegLayout<M>;
+  const int g0 = (tid & 1) * 2, t0 = tid >> 1;
+  if (g0 >= gvalid) return;
+  const bool two = g0 + 1 < gvalid;
+  constexpr int kStepL = 128 + (128 >> log2i(M)) * kSkew;  // idx(t + 128) - idx(t)
+  int li = RL::idx(t0, g0);
+  TOUT *gp = dst + (size_t)t0 * row_stride + g0;
+  const size_t gstep = (size_t)128 * row_stride;
+  struct alignas(2 * sizeof(TOUT)) Pair { TOUT a, b; };
+  for (int t = t0; t < Tmax; t += 128, li += kStepL, gp += gstep) {
+    const bool live = t < T;
+    const TOUT va = live ? tile[li] : (TOUT)0;
+    const TOUT vb = (live && two) ? tile[li + RL::TPAD] : (TOUT)0;
+    if (two && aligned_pairs) {
+      Pair pr;
+      pr.a = va;
+      pr.b = vb;
+      *reinterpret_cast<Pair *>(gp) = pr;
+    } else {
+      gp[0] = va;
+      if (two) gp[1] = vb;
+    }
   }
 }
 
@@ -385,6 +403,8 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
   int T = p.lengths ? p.lengths[b] : Tmax;
   T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
   const int mw = ws.mw, nw = ws.nw;
+  // paired output stores need every run start (b, t, [w], d0) to be 2-element aligned
+  const bool out_pairs_ok = (sd % 2 == 0) && (((uintptr_t)p.out & (2 * sizeof(TOUT) - 1)) == 0);
 
   const TIN *mean_b = BWD ? nullptr : (const TIN *)p.mean + (size_t)b * Tmax * D;
   const TIN *var_b = (const TIN *)p.var;
@@ -572,7 +592,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
     for (int i = 0; i < M; ++i)
       if ((liveS >> (i + 1)) & 1ull) tileO[baseR + i] = zero_out ? (TOUT)0 : (TOUT)rhs[i];
     __syncthreads();
-    store_tile<M, TOUT>(tileO, (TOUT *)p.out + (size_t)b * Tmax * sd + d0, sd, T, Tmax, gvalid, tid);
+    store_tile<M, TOUT>(tileO, (TOUT *)p.out + (size_t)b * Tmax * sd + d0, sd, T, Tmax, gvalid, tid, out_pairs_ok);
   } else {
     // grad[t, w*sd+d] = tau_w[t] * (cm x[t-1] + c0 x[t] + cp x[t+1])      (paramgen/_mlpg.py:202-281)
     double xl = __shfl_up(rhs[M - 1], 1), xr = __shfl_down(rhs[0], 1);
@@ -601,7 +621,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
         }
       }
       __syncthreads();
-      store_tile<M, TOUT>(tileO, (TOUT *)p.out + (size_t)b * Tmax * D + w * sd + d0, D, T, Tmax, gvalid, tid);
+      store_tile<M, TOUT>(tileO, (TOUT *)p.out + (size_t)b * Tmax * D + w * sd + d0, D, T, Tmax, gvalid, tid, out_pairs_ok);
     }
   }
 #ifdef MLPG_WAVE_TIMING
