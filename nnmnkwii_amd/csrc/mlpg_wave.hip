@@ -4,8 +4,8 @@
 
 namespace mlpg {
 
-int launch_wave_fwd_f64(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws);
-int launch_wave_fwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws);
+int launch_wave_fwd_f64(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, int device);
+int launch_wave_fwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, int device);
 int launch_wave_bwd_f64(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws);
 int launch_wave_bwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws);
 
@@ -18,8 +18,7 @@ bool wave_supported(const Problem &p, const WinSet &ws) {
 
 int launch_wave(hipStream_t st, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &ws,
                 int device) {
-  (void)device;
-  if (!backward) return dtype == MLPG_HIP_F32 ? launch_wave_fwd_f32(st, out_dtype, p, ws) : launch_wave_fwd_f64(st, out_dtype, p, ws);
+  if (!backward) return dtype == MLPG_HIP_F32 ? launch_wave_fwd_f32(st, out_dtype, p, ws, device) : launch_wave_fwd_f64(st, out_dtype, p, ws, device);
   return dtype == MLPG_HIP_F32 ? launch_wave_bwd_f32(st, out_dtype, p, ws) : launch_wave_bwd_f64(st, out_dtype, p, ws);
 }
 

@@ -293,37 +293,49 @@ __device__ __forceinline__ bool solve_chunk(double (&Pd)[M], double (&P1)[M], do
     const double H11 = I11 * L11 + I12 * L21, H12 = I11 * L12 + I12 * L22;
     const double H21 = I12 * L11 + I22 * L21, H22 = I12 * L12 + I22 * L22;
     const bool hasm = lane - s >= 0, hasp = lane + s < 64;
-    // --- half 1: row j-s (its inverse block for the D update, G, H) ---
+    // The neighbour data is fetched and consumed in SMALL groups separated by scheduling
+    // barriers: otherwise the scheduler hoists all 38 ds_bpermute results to the top of the step
+    // and the live set (on top of the 4M persistent doubles) spills.
     double nL11, nL12, nL21, nL22;
-    {
+    {  // row j-s: inverse block -> K = L_j D_{j-s}^-1;  D -= K L_j^T
       double mI11 = __shfl_up(I11, s), mI12 = __shfl_up(I12, s), mI22 = __shfl_up(I22, s);
-      double mG1 = __shfl_up(G1, s), mG2 = __shfl_up(G2, s);
-      double mH11 = __shfl_up(H11, s), mH12 = __shfl_up(H12, s), mH21 = __shfl_up(H21, s), mH22 = __shfl_up(H22, s);
-      if (!hasm) { mI11 = mI12 = mI22 = 0.0; mG1 = mG2 = 0.0; mH11 = mH12 = mH21 = mH22 = 0.0; }
-      // K = L_j D_{j-s}^-1;  D -= K L_j^T;  F -= L_j G_{j-s};  L' = -L_j H_{j-s}
+      if (!hasm) { mI11 = mI12 = mI22 = 0.0; }
       const double K11 = L11 * mI11 + L12 * mI12, K12 = L11 * mI12 + L12 * mI22;
       const double K21 = L21 * mI11 + L22 * mI12, K22 = L21 * mI12 + L22 * mI22;
       D11 -= K11 * L11 + K12 * L12;
       D12 -= K11 * L21 + K12 * L22;
       D22 -= K21 * L21 + K22 * L22;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {  // row j-s: G -> F -= L_j G_{j-s}
+      double mG1 = __shfl_up(G1, s), mG2 = __shfl_up(G2, s);
+      if (!hasm) { mG1 = mG2 = 0.0; }
       F1 -= L11 * mG1 + L12 * mG2;
       F2 -= L21 * mG1 + L22 * mG2;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {  // row j-s: H -> L' = -L_j H_{j-s}
+      double mH11 = __shfl_up(H11, s), mH12 = __shfl_up(H12, s), mH21 = __shfl_up(H21, s), mH22 = __shfl_up(H22, s);
+      if (!hasm) { mH11 = mH12 = mH21 = mH22 = 0.0; }
       nL11 = -(L11 * mH11 + L12 * mH21); nL12 = -(L11 * mH12 + L12 * mH22);
       nL21 = -(L21 * mH11 + L22 * mH21); nL22 = -(L21 * mH12 + L22 * mH22);
     }
-    __builtin_amdgcn_sched_barrier(0);  // keep the two halves apart: halves the live shuffle results
-    // --- half 2: row j+s (its coupling block to this row L_{j+s}, H_{j+s}, G_{j+s}) ---
-    {
+    __builtin_amdgcn_sched_barrier(0);
+    {  // row j+s: its coupling block L_{j+s} and H_{j+s}, G_{j+s}:  D -= L^T H;  F -= L^T G
       double pL11 = __shfl_down(L11, s), pL12 = __shfl_down(L12, s), pL21 = __shfl_down(L21, s), pL22 = __shfl_down(L22, s);
+      if (!hasp) { pL11 = pL12 = pL21 = pL22 = 0.0; }
+      {
+        double pG1 = __shfl_down(G1, s), pG2 = __shfl_down(G2, s);
+        if (!hasp) { pG1 = pG2 = 0.0; }
+        F1 -= pL11 * pG1 + pL21 * pG2;
+        F2 -= pL12 * pG1 + pL22 * pG2;
+      }
+      __builtin_amdgcn_sched_barrier(0);
       double pH11 = __shfl_down(H11, s), pH12 = __shfl_down(H12, s), pH21 = __shfl_down(H21, s), pH22 = __shfl_down(H22, s);
-      double pG1 = __shfl_down(G1, s), pG2 = __shfl_down(G2, s);
-      if (!hasp) { pL11 = pL12 = pL21 = pL22 = 0.0; pH11 = pH12 = pH21 = pH22 = 0.0; pG1 = pG2 = 0.0; }
-      // D -= L_{j+s}^T H_{j+s};  F -= L_{j+s}^T G_{j+s}
+      if (!hasp) { pH11 = pH12 = pH21 = pH22 = 0.0; }
       D11 -= pL11 * pH11 + pL21 * pH21;
       D12 -= pL11 * pH12 + pL21 * pH22;
       D22 -= pL12 * pH12 + pL22 * pH22;
-      F1 -= pL11 * pG1 + pL21 * pG2;
-      F2 -= pL12 * pG1 + pL22 * pG2;
     }
     L11 = nL11; L12 = nL12; L21 = nL21; L22 = nL22;
     __builtin_amdgcn_sched_barrier(0);
@@ -412,12 +424,6 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
   const TIN *gout_b = BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * sd : nullptr;
 
   const int f0 = lane * M;  // first frame of this lane's chunk
-#ifdef MLPG_WAVE_STAGGER
-  // de-phase the two workgroups that share a CU: the second resident workgroup of each CU starts late
-  if (slot < 64 && ((slot / 32) & 1)) {
-    for (int k = 0; k < MLPG_WAVE_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
 #ifdef MLPG_WAVE_TIMING
   long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // setup, wait-for-tiles, lds->regs, dma issue, assembly, solve, status, output
   long long t_prev = (long long)__builtin_readcyclecounter();
