@@ -455,10 +455,18 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
   TIN *tileV = (TIN *)tileA, *tileM = (TIN *)tileB;
 
   if (BWD) {
-    load_tile_regs<M, TIN>(tileM, gout_b + d0, sd, T, gvalid, tid);
-    __syncthreads();
+    // right-hand side = grad_out[:, d]; runs of G columns with row stride sd
+    if (DMA) {
+      load_tile_dma<M, TIN>(tileM, gout_b + d0, sd, T, gvalid, wv, lane);
+      __syncthreads();
 #pragma unroll
-    for (int i = 0; i < M; ++i) rhs[i] = ((liveS >> (i + 1)) & 1ull) ? (double)tileM[baseR + i] : 0.0;
+      for (int i = 0; i < M; ++i) rhs[i] = ((liveS >> (i + 1)) & 1ull) ? (double)tileM[baseD + i * DL::ESTRIDE] : 0.0;
+    } else {
+      load_tile_regs<M, TIN>(tileM, gout_b + d0, sd, T, gvalid, tid);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < M; ++i) rhs[i] = ((liveS >> (i + 1)) & 1ull) ? (double)tileM[baseR + i] : 0.0;
+    }
     __syncthreads();
   }
 
@@ -611,7 +619,10 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
       const double cm = l ? cw[0] : 0.0, c0 = cw[l], cp = u ? cw[l + 1] : 0.0;
       const unsigned long long live = w ? liveD : liveS;
       __syncthreads();  // previous store_tile / tile users done
-      if (kVarTile) load_tile_regs<M, TIN>(tileV, var_b + w * sd + d0, D, T, gvalid, tid);
+      if (kVarTile) {
+        if (DMA) load_tile_dma<M, TIN>(tileV, var_b + w * sd + d0, D, T, gvalid, wv, lane);
+        else load_tile_regs<M, TIN>(tileV, var_b + w * sd + d0, D, T, gvalid, tid);
+      }
       __syncthreads();
       double tau_glob = 1.0;
       if (VM == MLPG_HIP_VAR_GLOBAL && sys_valid) tau_glob = tau_of<TIN>(var_b[w * sd + d]);
@@ -619,7 +630,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
       for (int i = 0; i < M; ++i) {
         if ((liveS >> (i + 1)) & 1ull) {
           double tau = 0.0;
-          if ((live >> (i + 1)) & 1ull) tau = kVarTile ? tau_of<TIN>(tileV[baseR + i]) : tau_glob;
+          if ((live >> (i + 1)) & 1ull) tau = kVarTile ? tau_of<TIN>(DMA ? tileV[baseD + i * DL::ESTRIDE] : tileV[baseR + i]) : tau_glob;
           const double xm = (i == 0) ? xl : rhs[i > 0 ? i - 1 : 0];
           const double xp = (i == M - 1) ? xr : rhs[i < M - 1 ? i + 1 : M - 1];
           const double gval = tau * (cm * xm + c0 * rhs[i] + cp * xp);  // x == 0 on rows >= T
@@ -662,7 +673,7 @@ bool dma_ok(const Problem &p) {
   if (MLPG_WAVE_DMA == 0) return false;
   if (kG % epl || p.D % epl || p.sd % epl) return false;
   auto al = [](const void *q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
-  return al(p.mean) && al(p.var);
+  return al(p.mean) && al(p.var) && al(p.grad_out);
 }
 
 template <int M, typename TIN, typename TOUT, bool BWD, bool DMA>

@@ -74,6 +74,23 @@ def main():
             emit(path="c2g-" + name, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
         del m
 
+    # ---- c2b: backward (mlpg_hip_backward) at config-2 scale, float64 and float32 ----
+    if want("c2b"):
+        B, T, sd = 256, 1000, 60
+        for name, dt, esz in (("f64", torch.float64, 8), ("f32", torch.float32, 4)):
+            v = torch.rand(B, T, 3 * sd, dtype=dt, device=dev, generator=gen) + 0.1
+            go = torch.randn(B, T, sd, dtype=dt, device=dev, generator=gen)
+            ms = gpu_time(lambda: _hip.backward(v, go, WINDOWS, 3 * sd, out_dtype=dt, want_status=False))
+            by = float(esz) * (3 + 1 + 3) * sd * B * T     # read 3 variances + grad_out, write 3 grads per (frame, dim)
+            emit(path="c2b-backward-" + name, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
+            del v, go
+        m32 = torch.randn(B, T, 3 * sd, dtype=torch.float32, device=dev, generator=gen)
+        v32 = torch.rand(B, T, 3 * sd, dtype=torch.float32, device=dev, generator=gen) + 0.1
+        ms = gpu_time(lambda: _hip.forward(m32, v32, WINDOWS, want_status=False))
+        by = 4.0 * 7 * sd * B * T
+        emit(path="c2-forward-f32", ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
+        del m32, v32
+
     # ---- c3: unit-variance autograd fwd+bwd ----
     if want("c3"):
         B, T, D = 64, 500, 180
