@@ -1,10 +1,11 @@
 """DTW alignment of padded utterance batches on MI355X.
 
-Host-side mirror of /root/reference/nnmnkwii/preprocessing/alignment.py:9-76.
+Host-side mirror of /root/reference/nnmnkwii/preprocessing/alignment.py:9-190.
 The per-pair Python loop (trim -> fastdtw -> gather -> pad) of the reference
 becomes three batched HIP launches over all pairs: trailing-zero trim,
 multi-resolution fastdtw with an anti-diagonal DP, and a gather along the
-warping paths (C ABI: include/mlpg_hip.h).
+warping paths (C ABI: include/mlpg_hip.h).  ``IterativeDTWAligner`` wraps the
+same launches in the reference's align -> fit joint GMM -> convert loop.
 """
 import numpy as np
 from numpy.linalg import norm
@@ -83,3 +84,80 @@ class DTWAligner(object):
             for idx in range(N):
                 print("{}, distance: {}".format(idx, d[idx]))
         return Xa, Ya
+
+
+class IterativeDTWAligner(object):
+    """Align feature matrices iteratively using GMM-based feature conversion
+    (alignment.py:79-190): DTW on (converted X, Y) -> joint GMM on the aligned frames ->
+    convert X frame-wise with that GMM -> repeat; finally gather the ORIGINAL X along the
+    last warping paths.
+
+    The DTW of every iteration is one batched GPU pass over all pairs; the GMM fit stays with
+    scikit-learn (as in the reference) and the frame-wise conversion is
+    :class:`nnmnkwii_amd.baseline.gmm.MLPG` with a static-only window.  Reference behaviours
+    kept on purpose: the aligned buffers persist across iterations and only their prefixes are
+    rewritten (alignment.py:163-164), the GMM is fitted on the zero padding as well (:175-178), and
+    ``random_state`` is left to numpy's global generator (:170-174).
+
+    Attributes:
+        n_iter, dist, radius, verbose, max_iter_gmm, n_components_gmm: as in the reference.
+    """
+
+    def __init__(self, n_iter=3, dist=_default_dist, radius=1, max_iter_gmm=100, n_components_gmm=16, verbose=0):
+        self.n_iter = n_iter
+        self.dist = dist
+        self.radius = radius
+        self.max_iter_gmm = max_iter_gmm
+        self.n_components_gmm = n_components_gmm
+        self.verbose = verbose
+
+    def transform(self, XY):
+        from sklearn.mixture import GaussianMixture
+
+        from ..baseline.gmm import MLPG
+
+        X, Y = XY
+        assert X.ndim == 3 and Y.ndim == 3                    # alignment.py:125
+        longer = X if X.shape[1] > Y.shape[1] else Y          # :127
+        N = len(X)
+        Xc = X.copy()                                          # converted X, updated every iteration (:129)
+        X_aligned = np.zeros_like(longer)
+        Y_aligned = np.zeros_like(longer)
+        aligner = DTWAligner(dist=self.dist, radius=self.radius)
+        path_x, plen = None, None
+
+        for _ in range(self.n_iter):
+            Xd, Yd, path_i, path_j, path_len, cost, lenx, leny = aligner._paths(Xc, Y)
+            plen = path_len.cpu().numpy()
+            if (plen <= 0).any():
+                bad = int(np.flatnonzero(plen <= 0)[0])
+                raise ValueError("IterativeDTWAligner: pair %d has an empty (all-zero) utterance" % bad)
+            T_out = max(int(X_aligned.shape[1]), int(plen.max()))
+            if T_out > X_aligned.shape[1]:                     # outputs only ever grow (:148-162)
+                grow = [(0, 0), (0, T_out - X_aligned.shape[1]), (0, 0)]
+                X_aligned = np.pad(X_aligned, grow, mode="constant", constant_values=0)
+                Y_aligned = np.pad(Y_aligned, grow, mode="constant", constant_values=0)
+            Xg = _hip.gather_path(Xd, path_i, path_len, T_out).cpu().numpy()
+            Yg = _hip.gather_path(Yd, path_j, path_len, T_out).cpu().numpy()
+            prefix = (np.arange(T_out)[None, :] < plen[:, None])[:, :, None]
+            X_aligned = np.where(prefix, Xg.astype(X_aligned.dtype, copy=False), X_aligned)   # prefix writes (:163-164)
+            Y_aligned = np.where(prefix, Yg.astype(Y_aligned.dtype, copy=False), Y_aligned)
+            path_x = path_i.cpu().numpy()
+            if self.verbose > 0:
+                dd = cost.cpu().numpy() / (lenx.cpu().numpy() + leny.cpu().numpy())
+                for idx in range(N):
+                    print("{}, distance: {}".format(idx, dd[idx]))
+
+            gmm = GaussianMixture(n_components=self.n_components_gmm, covariance_type="full", max_iter=self.max_iter_gmm)
+            joint = np.concatenate((X_aligned, Y_aligned), axis=-1).reshape(-1, X.shape[-1] * 2)
+            gmm.fit(joint)                                     # :170-178
+            conv = MLPG(gmm, windows=[(0, 0, np.array([1.0]))])   # no delta: frame-wise conversion (:179-180)
+            nx = lenx.cpu().numpy()                            # trim_zeros_frames(Xc[idx]) of this iteration
+            for idx in range(N):
+                x = Xc[idx][: int(nx[idx])]
+                Xc[idx][: len(x)] = conv.transform(x)          # :181-183
+
+        for idx in range(N):                                   # aligned ORIGINAL X (:186-188)
+            n = int(plen[idx])
+            X_aligned[idx][:n] = X[idx][path_x[idx, :n]]
+        return X_aligned, Y_aligned

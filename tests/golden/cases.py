@@ -49,3 +49,54 @@ def c2_utterance(b, T=1000, sd=60):
     m = rng.randn(T, 3 * sd)
     v = rng.rand(T, 3 * sd) + 0.1
     return m, v
+
+
+def _track(rng, T, D):
+    return np.cumsum(rng.randn(T, D), axis=0) * 0.3
+
+
+def align_batch(name):
+    """Zero-padded (N, Tx, D), (N, Ty, D) pairs of smooth tracks for the DTW aligner goldens.
+
+    small   : content much shorter than the padding (outputs keep the padded length)
+    grow    : full-length content (warping paths longer than the padding: outputs grow)
+    xlonger : X padded longer than Y (the output dtype/length follow X)
+    f32     : float32 inputs
+    """
+    rng = np.random.RandomState(_seed("align", name))
+    N, D = 3, 4
+    if name in ("small", "f32"):
+        Tx, Ty, lo, hi = 40, 44, 12, 22
+    elif name == "grow":
+        Tx, Ty, lo, hi = 18, 18, 17, 19
+    elif name == "xlonger":
+        Tx, Ty, lo, hi = 36, 30, 14, 26
+    else:
+        raise KeyError(name)
+    X = np.zeros((N, Tx, D))
+    Y = np.zeros((N, Ty, D))
+    for n in range(N):
+        tx = int(rng.randint(lo, min(hi, Tx + 1)))
+        ty = int(rng.randint(lo, min(hi, Ty + 1)))
+        base = _track(rng, max(tx, ty) + 8, D)
+        ix = np.sort(rng.choice(len(base), tx, replace=False))
+        iy = np.sort(rng.choice(len(base), ty, replace=False))
+        X[n, :tx] = base[ix] + 0.05 * rng.randn(tx, D)
+        Y[n, :ty] = 0.8 * base[iy] + 0.3 + 0.05 * rng.randn(ty, D)
+    if name == "f32":
+        X, Y = X.astype(np.float32), Y.astype(np.float32)
+    return X, Y
+
+
+def gmm_joint_data(wname, sd, n=400, T=30):
+    """(n, 2*D) joint source/target samples for a GMM fit and a (T, D) source utterance, D = nw*sd."""
+    nw = len(WINDOW_SETS[wname])
+    D = nw * sd
+    rng = np.random.RandomState(_seed("gmm", wname, sd))
+    centers = rng.randn(3, D) * 2.0
+    which = rng.randint(0, 3, size=n)
+    x = centers[which] + rng.randn(n, D)
+    A = np.eye(D) * 0.7 + 0.1 * rng.randn(D, D)
+    y = x @ A + 0.5 + 0.3 * rng.randn(n, D)
+    src = centers[rng.randint(0, 3, size=T)] + rng.randn(T, D)
+    return np.concatenate([x, y], axis=1), src
