@@ -87,6 +87,47 @@ int mlpg_hip_forward(int device, void *stream, int dtype, int algo,
                      void *out, int32_t *status);
 
 /*
+ * Multi-stream MLPG forward over one padded acoustic feature batch (SURVEY 8(f)
+ * rank 3).  Replaces the per-utterance, per-stream Python loop that users of
+ * the reference write around paramgen.mlpg: util.apply_each2d_padded /
+ * apply_each2d_trim (util/__init__.py:19-66) applied to each stream's column
+ * slice of the (N, Tmax, D) zero-padded arrays that
+ * datasets.PaddedFileSourceDataset.asarray produces (datasets/__init__.py:
+ * 152-218), with the stream layout of util/files.py:90-115 (mgc | lf0 | vuv |
+ * bap, each stream window-major: static, delta, delta-delta).
+ *
+ *   mean : (B, Tmax, ld_in) dtype; stream k occupies columns
+ *          [in_col, in_col + max(num_windows,1)*static_dim)
+ *   var  : MLPG_HIP_VAR_FRAME: (B, Tmax, ld_in), same columns;
+ *          MLPG_HIP_VAR_GLOBAL: (ld_in,); MLPG_HIP_VAR_UNIT: NULL
+ *   out  : (B, Tmax, ld_out) dtype; stream k's trajectory goes to columns
+ *          [out_col, out_col + static_dim); other columns are not touched
+ *   windows of stream k: entries win_first .. win_first+num_windows-1 of the
+ *          packed tables (total_windows entries; several streams may share
+ *          them).  num_windows == 0: no dynamic features, the static columns
+ *          are copied through (frames >= lengths[b] zero-filled).
+ *   status : int32 (B, sum_k static_dim), streams in table order; may be NULL.
+ * The slices are consumed in place (no repacking); each stream is one launch
+ * on `stream`.
+ */
+typedef struct {
+  int32_t in_col;      /* first column of the stream in mean / var rows  */
+  int32_t out_col;     /* first column of its trajectory in out rows     */
+  int32_t static_dim;  /* static feature dimension of the stream         */
+  int32_t num_windows; /* 0 = pass-through                               */
+  int32_t win_first;   /* first window of the stream in the window tables */
+} mlpg_hip_stream_t;
+
+int mlpg_hip_forward_streams(int device, void *stream, int dtype, int algo,
+                             const void *mean, const void *var, int var_mode,
+                             int64_t ld_in, const int32_t *lengths, int B,
+                             int Tmax, int num_streams,
+                             const mlpg_hip_stream_t *streams_h,
+                             int total_windows, const int32_t *win_l_h,
+                             const int32_t *win_u_h, const double *win_coef_h,
+                             void *out, int64_t ld_out, int32_t *status);
+
+/*
  * MLPG backward (gradient w.r.t. the means), batched.  Replaces
  * paramgen.mlpg_grad (paramgen/_mlpg.py:202-281; the reference solves a dense
  * T x T right-hand side with LAPACK dgbsv per static dim and window, :275).

@@ -24,6 +24,7 @@ EXPORTS = (
     "mlpg_hip_device_count",
     "mlpg_hip_shutdown",
     "mlpg_hip_forward",
+    "mlpg_hip_forward_streams",
     "mlpg_hip_backward",
     "mlpg_hip_delta_features",
     "mlpg_hip_trim_lengths",
@@ -67,6 +68,9 @@ def lib():
         L.mlpg_hip_shutdown.argtypes = []
         L.mlpg_hip_forward.restype = ci
         L.mlpg_hip_forward.argtypes = [ci, vp, ci, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
+        L.mlpg_hip_forward_streams.restype = ci
+        L.mlpg_hip_forward_streams.argtypes = [ci, vp, ci, ci, vp, vp, ci, ctypes.c_int64, vp, ci, ci, ci, vp, ci, vp, vp, vp,
+                                               vp, ctypes.c_int64, vp]
         L.mlpg_hip_backward.restype = ci
         L.mlpg_hip_backward.argtypes = [ci, vp, ci, ci, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
         L.mlpg_hip_delta_features.restype = ci
@@ -176,6 +180,63 @@ def forward(mean, var, windows, lengths=None, algo=ALGO_AUTO, want_status=True):
     return out, status
 
 
+class StreamDesc(ctypes.Structure):
+    """mlpg_hip_stream_t (include/mlpg_hip.h)."""
+    _fields_ = [("in_col", ctypes.c_int32), ("out_col", ctypes.c_int32), ("static_dim", ctypes.c_int32),
+                ("num_windows", ctypes.c_int32), ("win_first", ctypes.c_int32)]
+
+
+def forward_streams(mean, var, streams, lengths=None, algo=ALGO_AUTO, want_status=True):
+    """Multi-stream MLPG over one (B, T, ld) CUDA batch, streams consumed in place.
+
+    ``streams``: list of ``(in_col, static_dim, windows)``; ``windows`` is a list of (l, u, coeff)
+    triples, or None / [] for a pass-through stream (static columns copied).  Trajectories are
+    written side by side in table order.  Returns (out (B, T, sum static_dim), status (B, sum
+    static_dim) int32 or None).
+    """
+    torch = torch_mod()
+    assert mean.is_cuda and mean.dim() == 3 and mean.is_contiguous()
+    B, T, ld = mean.shape
+    if var is None:
+        mode = VAR_UNIT
+    elif var.dim() == 1:
+        mode = VAR_GLOBAL
+        assert var.shape[0] == ld and var.dtype == mean.dtype and var.is_contiguous() and var.device == mean.device
+    else:
+        mode = VAR_FRAME
+        assert var.shape == mean.shape and var.dtype == mean.dtype and var.is_contiguous() and var.device == mean.device
+    if lengths is not None:
+        assert lengths.dtype == torch.int32 and lengths.shape == (B,) and lengths.device == mean.device
+    table = (StreamDesc * max(len(streams), 1))()
+    wl_all, wu_all, wc_all = [], [], []
+    seen = {}                       # window lists shared between streams are packed once
+    out_col = 0
+    for k, (in_col, sd, windows) in enumerate(streams):
+        nw = len(windows) if windows else 0
+        first = 0
+        if nw:
+            key = id(windows)
+            if key not in seen:
+                wl, wu, wc = pack_windows(windows)
+                seen[key] = len(wl_all)
+                wl_all.extend(wl.tolist())
+                wu_all.extend(wu.tolist())
+                wc_all.extend(wc.tolist())
+            first = seen[key]
+        table[k] = StreamDesc(int(in_col), out_col, int(sd), nw, first)
+        out_col += int(sd)
+    wl = np.ascontiguousarray(wl_all, dtype=np.int32)
+    wu = np.ascontiguousarray(wu_all, dtype=np.int32)
+    wc = np.ascontiguousarray(wc_all if wc_all else [0.0], dtype=np.float64)
+    out = torch.empty((B, T, out_col), dtype=mean.dtype, device=mean.device)
+    status = torch.empty((B, out_col), dtype=torch.int32, device=mean.device) if want_status else None
+    rc = lib().mlpg_hip_forward_streams(mean.device.index, _stream(mean.device), _dt(mean), algo, _p(mean), _p(var), mode,
+                                        ld, _p(lengths), B, T, len(streams), ctypes.addressof(table), len(wl_all),
+                                        _np(wl), _np(wu), _np(wc), _p(out), out_col, _p(status))
+    _check(rc, "mlpg_hip_forward_streams")
+    return out, status
+
+
 def backward(var, grad_out, windows, D, lengths=None, out_dtype=None, algo=ALGO_AUTO, want_status=True):
     """Batched MLPG gradient w.r.t. means on device tensors.
 
@@ -266,7 +327,7 @@ def gather_path(src, path, path_len, Tout):
 
 def raise_on_status(status, sd):
     """Raise the reference's LinAlgError for the first failing (utterance, dim) system."""
-    st = status.cpu().numpy()
+    st = status.cpu().numpy().ravel()
     bad = np.flatnonzero(st)
     if bad.size:
         k = int(st[bad[0]])

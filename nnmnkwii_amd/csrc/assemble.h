@@ -23,14 +23,15 @@ struct SysView {
   const TIN *mean;  // (Tmax, D) rows of utterance b (forward)
   const TIN *var;   // (Tmax, D) rows, or (D,), or nullptr
   const TIN *gout;  // (Tmax, sd) rows (backward)
-  int var_mode, D, sd, d, T, mw;
+  int var_mode, sd, d, T, mw;
+  long ld_in, ld_gout;  // row strides of mean/var and of gout
 
   __device__ __forceinline__ double tau(int w, int t) const {
     // zero precision on the edge frames of the dynamic windows; Python's
     // precisions[-0:] slice makes mw == 0 zero the whole column (_mlpg.py:191-193)
     if (w != 0 && (mw == 0 || t < mw || t >= T - mw)) return 0.0;
     if (var_mode == MLPG_HIP_VAR_UNIT) return 1.0;
-    const TIN v = (var_mode == MLPG_HIP_VAR_GLOBAL) ? var[w * sd + d] : var[(size_t)t * D + w * sd + d];
+    const TIN v = (var_mode == MLPG_HIP_VAR_GLOBAL) ? var[w * sd + d] : var[(size_t)t * ld_in + w * sd + d];
     return recip_in_dtype<TIN>(v);
   }
 };
@@ -38,12 +39,13 @@ struct SysView {
 template <typename TIN, bool BWD>
 __device__ __forceinline__ SysView<TIN, BWD> make_view(const Problem &p, const WinSet &ws, int b, int d, int T) {
   SysView<TIN, BWD> v;
-  v.mean = BWD ? nullptr : (const TIN *)p.mean + (size_t)b * p.Tmax * p.D;
+  v.mean = BWD ? nullptr : (const TIN *)p.mean + (size_t)b * p.Tmax * p.ld_in;
   v.var = (const TIN *)p.var;
-  if (p.var_mode == MLPG_HIP_VAR_FRAME) v.var += (size_t)b * p.Tmax * p.D;
-  v.gout = BWD ? (const TIN *)p.grad_out + (size_t)b * p.Tmax * p.sd : nullptr;
+  if (p.var_mode == MLPG_HIP_VAR_FRAME) v.var += (size_t)b * p.Tmax * p.ld_in;
+  v.gout = BWD ? (const TIN *)p.grad_out + (size_t)b * p.Tmax * p.ld_gout : nullptr;
   v.var_mode = p.var_mode;
-  v.D = p.D;
+  v.ld_in = p.ld_in;
+  v.ld_gout = p.ld_gout;
   v.sd = p.sd;
   v.d = d;
   v.T = T;
@@ -61,7 +63,7 @@ __device__ __forceinline__ void assemble_frame(const SysView<TIN, BWD> &v, const
                                                double &rhs) {
 #pragma unroll
   for (int k = 0; k <= Q; ++k) pk[k] = 0.0;
-  rhs = BWD ? (double)v.gout[(size_t)f * v.sd + v.d] : 0.0;
+  rhs = BWD ? (double)v.gout[(size_t)f * v.ld_gout + v.d] : 0.0;
   const int T = v.T;
   for (int w = 0; w < ws.nw; ++w) {
     const int l = ws.l[w], u = ws.u[w];
@@ -70,7 +72,7 @@ __device__ __forceinline__ void assemble_frame(const SysView<TIN, BWD> &v, const
     const int t1 = f + l > T - 1 ? T - 1 : f + l;
     for (int t = t0; t <= t1; ++t) {
       const double a = c[l + f - t] * v.tau(w, t);
-      if (!BWD) rhs += a * (double)v.mean[(size_t)t * v.D + w * v.sd + v.d];
+      if (!BWD) rhs += a * (double)v.mean[(size_t)t * v.ld_in + w * v.sd + v.d];
 #pragma unroll
       for (int k = 0; k <= Q; ++k) {
         const int idx = l + f + k - t;

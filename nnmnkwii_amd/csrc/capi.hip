@@ -155,6 +155,10 @@ int solve_entry(int device, void *stream, int in_dtype, int out_dtype, int algo,
   p.Tmax = Tmax;
   p.D = D;
   p.sd = D / nw;
+  p.ld_in = D;
+  p.ld_gout = backward ? D / nw : 0;
+  p.ld_out = backward ? D : D / nw;
+  p.ld_status = D / nw;
   hipStream_t st = (hipStream_t)stream;
   if (algo == MLPG_HIP_ALGO_WAVE && !wave_supported(p, ws)) {
     set_error("MLPG_HIP_ALGO_WAVE does not support this problem (T=%d, half-bandwidth %d)", Tmax, ws.q);
@@ -165,6 +169,46 @@ int solve_entry(int device, void *stream, int in_dtype, int out_dtype, int algo,
   return launch_generic(st, in_dtype, out_dtype, backward, p, ws, device);
 }
 
+// One stream of a multi-stream batch: a column slice [in_col, in_col + nw*sd) of the (B, Tmax, ld_in)
+// parameter matrices, trajectory written to columns [out_col, out_col + sd) of the (B, Tmax, ld_out) output.
+int stream_entry(int device, hipStream_t st, int dtype, int algo, const void *mean, const void *var, int var_mode,
+                 long ld_in, const int32_t *lengths, int B, int Tmax, const mlpg_hip_stream_t &sm, const int32_t *wl,
+                 const int32_t *wu, const double *wc, void *out, long ld_out, int32_t *status, int ld_status,
+                 int status_col) {
+  const size_t esz = dtype == MLPG_HIP_F32 ? 4 : 8;
+  const int sd = sm.static_dim, nw = sm.num_windows;
+  const char *mean_s = (const char *)mean + esz * (size_t)sm.in_col;
+  char *out_s = (char *)out + esz * (size_t)sm.out_col;
+  if (nw == 0) return launch_copy_cols(st, dtype, mean_s, ld_in, lengths, B, Tmax, sd, out_s, ld_out);
+  size_t coff = 0;
+  for (int w = 0; w < sm.win_first; ++w) coff += (size_t)(wl[w] + wu[w] + 1);
+  WinSet ws;
+  if (int rc = pack_windows(nw, wl + sm.win_first, wu + sm.win_first, wc + coff, &ws)) return rc;
+  Problem p;
+  p.mean = mean_s;
+  p.var = var ? (const char *)var + esz * (size_t)sm.in_col : nullptr;
+  p.grad_out = nullptr;
+  p.lengths = lengths;
+  p.out = out_s;
+  p.status = status ? status + status_col : nullptr;
+  p.var_mode = var_mode;
+  p.B = B;
+  p.Tmax = Tmax;
+  p.D = nw * sd;
+  p.sd = sd;
+  p.ld_in = ld_in;
+  p.ld_gout = 0;
+  p.ld_out = ld_out;
+  p.ld_status = ld_status;
+  if (algo == MLPG_HIP_ALGO_WAVE && !wave_supported(p, ws)) {
+    set_error("MLPG_HIP_ALGO_WAVE does not support this stream (T=%d, half-bandwidth %d)", Tmax, ws.q);
+    return MLPG_HIP_EINVAL;
+  }
+  const bool use_wave = algo == MLPG_HIP_ALGO_WAVE || (algo == MLPG_HIP_ALGO_AUTO && wave_supported(p, ws));
+  if (use_wave) return launch_wave(st, dtype, dtype, false, p, ws, device);
+  return launch_generic(st, dtype, dtype, false, p, ws, device);
+}
+
 }  // namespace
 }  // namespace mlpg
 
@@ -172,7 +216,7 @@ using namespace mlpg;
 
 extern "C" {
 
-__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 1; }
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 2; }
 
 __attribute__((visibility("default"))) const char *mlpg_hip_last_error(void) { return g_err; }
 
@@ -208,6 +252,74 @@ __attribute__((visibility("default"))) int mlpg_hip_forward(int device, void *st
                                                             void *out, int32_t *status) {
   return solve_entry(device, stream, dtype, dtype, algo, false, mean, var, var_mode, nullptr, lengths, B, Tmax, D,
                      num_windows, win_l_h, win_u_h, win_coef_h, out, status);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_forward_streams(
+    int device, void *stream, int dtype, int algo, const void *mean, const void *var, int var_mode, int64_t ld_in,
+    const int32_t *lengths, int B, int Tmax, int num_streams, const mlpg_hip_stream_t *streams_h, int total_windows,
+    const int32_t *win_l_h, const int32_t *win_u_h, const double *win_coef_h, void *out, int64_t ld_out,
+    int32_t *status) {
+  if (B < 0 || Tmax < 0 || num_streams < 0 || total_windows < 0 || ld_in < 0 || ld_out < 0 ||
+      ld_in > INT32_MAX || ld_out > INT32_MAX) {
+    set_error("forward_streams: negative or oversized size argument");
+    return MLPG_HIP_EINVAL;
+  }
+  if (dtype != MLPG_HIP_F32 && dtype != MLPG_HIP_F64) {
+    set_error("dtype must be MLPG_HIP_F32 or MLPG_HIP_F64");
+    return MLPG_HIP_EINVAL;
+  }
+  if (num_streams > 0 && !streams_h) {
+    set_error("forward_streams: NULL stream table");
+    return MLPG_HIP_EINVAL;
+  }
+  long sd_total = 0;
+  for (int k = 0; k < num_streams; ++k) {
+    const mlpg_hip_stream_t &sm = streams_h[k];
+    const long width = (long)(sm.num_windows > 0 ? sm.num_windows : 1) * sm.static_dim;
+    if (sm.static_dim < 0 || sm.num_windows < 0 || sm.in_col < 0 || sm.out_col < 0 || sm.win_first < 0 ||
+        sm.win_first + sm.num_windows > total_windows || sm.in_col + width > ld_in ||
+        (long)sm.out_col + sm.static_dim > ld_out) {
+      set_error("forward_streams: stream %d does not fit (in_col=%d, out_col=%d, static_dim=%d, num_windows=%d)", k,
+                sm.in_col, sm.out_col, sm.static_dim, sm.num_windows);
+      return MLPG_HIP_EINVAL;
+    }
+    sd_total += sm.static_dim;
+  }
+  if (var_mode < 0 || var_mode > 2 || (var_mode != MLPG_HIP_VAR_UNIT && !var)) {
+    set_error("bad var_mode %d / NULL var", var_mode);
+    return MLPG_HIP_EINVAL;
+  }
+  if (total_windows > 0 && (!win_l_h || !win_u_h || !win_coef_h)) {
+    set_error("forward_streams: NULL window tables");
+    return MLPG_HIP_EINVAL;
+  }
+  if (B == 0 || Tmax == 0 || sd_total == 0) return 0;
+  if (!mean || !out) {
+    set_error("NULL data pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  int status_col = 0;
+  for (int k = 0; k < num_streams; ++k) {
+    const mlpg_hip_stream_t &sm = streams_h[k];
+    if (sm.static_dim > 0) {
+      if (int rc = stream_entry(device, (hipStream_t)stream, dtype, algo, mean, var, var_mode, (long)ld_in, lengths, B,
+                                Tmax, sm, win_l_h, win_u_h, win_coef_h, out, (long)ld_out, status, (int)sd_total,
+                                status_col))
+        return rc;
+      if (sm.num_windows == 0 && status) {
+        // pass-through streams cannot fail: their status columns are cleared
+        MLPG_HIP_CHECK(hipMemset2DAsync(status + status_col, sizeof(int32_t) * (size_t)sd_total, 0,
+                                        sizeof(int32_t) * (size_t)sm.static_dim, (size_t)B, (hipStream_t)stream));
+      }
+    }
+    status_col += sm.static_dim;
+  }
+  return 0;
 }
 
 __attribute__((visibility("default"))) int mlpg_hip_backward(int device, void *stream, int in_dtype, int out_dtype,

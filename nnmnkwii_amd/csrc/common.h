@@ -34,6 +34,14 @@ struct Problem {
   int32_t *status;
   int var_mode;
   int B, Tmax, D, sd;
+  // Row strides in elements; the utterance stride is Tmax * row stride (the parent array is a
+  // densely packed (B, Tmax, ld) batch of which this problem is a column slice: one stream of a
+  // multi-stream acoustic feature matrix).  Dense problems: ld_in = D, ld_gout = sd,
+  // ld_out = sd (forward) | D (backward), ld_status = sd.
+  long ld_in;     // mean and per-frame var rows
+  long ld_gout;   // grad_out rows (backward)
+  long ld_out;    // out rows
+  int ld_status;  // status[b * ld_status + d]
 };
 
 void set_error(const char *fmt, ...);
@@ -46,6 +54,8 @@ int launch_generic(hipStream_t s, int dtype, int out_dtype, bool backward, const
 bool wave_supported(const Problem &p, const WinSet &w);
 int launch_wave(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
                 int device);
+int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,
+                     int ncols, void *dst, long ld_dst);
 int launch_delta(hipStream_t s, int dtype, const void *x, const int32_t *lengths, int B, int Tmax, int D,
                  const WinSet &w, void *out);
 int launch_trim(hipStream_t s, int dtype, const void *X, int N, int T, int D, double eps, int32_t *lengths);

@@ -24,12 +24,13 @@ template <int Q, typename TIN, typename TOUT, bool BWD>
 __global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, double *__restrict__ scratch, long S) {
   const long s = (long)blockIdx.x * 64 + threadIdx.x;
   if (s >= S) return;
-  const int sd = p.sd, D = p.D, Tmax = p.Tmax;
+  const int sd = p.sd, Tmax = p.Tmax;
+  const long ldo = p.ld_out;
   const int b = (int)(s / sd), d = (int)(s % sd);
   int T = p.lengths ? p.lengths[b] : Tmax;
   T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
   const SysView<TIN, BWD> view = make_view<TIN, BWD>(p, ws, b, d, T);
-  TOUT *out = (TOUT *)p.out + (size_t)b * Tmax * (BWD ? D : sd);
+  TOUT *out = (TOUT *)p.out + (size_t)b * Tmax * ldo;
   const int nw = ws.nw;
   auto tau = [&](int w, int t) -> double { return view.tau(w, t); };
 
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, doubl
     }
   }
 
-  if (p.status) p.status[s] = bad;
+  if (p.status) p.status[(size_t)b * p.ld_status + d] = bad;
   const int ncol = BWD ? nw : 1;
   if (bad) T = 0;  // failed system: zero-fill everything
 
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, doubl
     if (BWD)
       sc[(size_t)(Q + 1) * S] = x;
     else
-      out[(size_t)f * sd + d] = (TOUT)x;
+      out[(size_t)f * ldo + d] = (TOUT)x;
   }
 
   if (BWD) {
@@ -112,13 +113,13 @@ __global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, doubl
           const int tt = t + k;
           if (tt >= 0 && tt < T) g += c[l + k] * scratch[((size_t)tt * R + (Q + 1)) * S + s];
         }
-        out[(size_t)t * D + w * sd + d] = (TOUT)(tau(w, t) * g);
+        out[(size_t)t * ldo + w * sd + d] = (TOUT)(tau(w, t) * g);
       }
     }
   }
   // zero the padding frames (and everything, for a failed system)
   for (int t = T; t < Tmax; ++t)
-    for (int w = 0; w < ncol; ++w) out[(size_t)t * (BWD ? D : sd) + w * sd + d] = (TOUT)0;
+    for (int w = 0; w < ncol; ++w) out[(size_t)t * ldo + w * sd + d] = (TOUT)0;
 }
 
 template <int Q, typename TIN, typename TOUT, bool BWD>
@@ -173,7 +174,36 @@ __global__ void delta_kernel(const T *__restrict__ x, const int32_t *__restrict_
   }
 }
 
+// Pass-through of a stream without dynamic features: dst[b, t, c] = src[b, t, c] for t < len, else 0.
+template <typename T>
+__global__ void copy_cols_kernel(const T *__restrict__ src, long ld_src, const int32_t *__restrict__ lengths, int B,
+                                 int Tmax, int ncols, T *__restrict__ dst, long ld_dst) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)B * Tmax * ncols) return;
+  const int c = (int)(e % ncols);
+  const long bt = e / ncols;
+  const int t = (int)(bt % Tmax), b = (int)(bt / Tmax);
+  int len = lengths ? lengths[b] : Tmax;
+  len = len < 0 ? 0 : (len > Tmax ? Tmax : len);
+  dst[(size_t)bt * ld_dst + c] = t < len ? src[(size_t)bt * ld_src + c] : (T)0;
+}
+
 }  // namespace
+
+int launch_copy_cols(hipStream_t st, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,
+                     int ncols, void *dst, long ld_dst) {
+  const long total = (long)B * Tmax * ncols;
+  if (total == 0) return 0;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (dtype == MLPG_HIP_F32)
+    hipLaunchKernelGGL(copy_cols_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)src, ld_src, lengths, B,
+                       Tmax, ncols, (float *)dst, ld_dst);
+  else
+    hipLaunchKernelGGL(copy_cols_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)src, ld_src, lengths,
+                       B, Tmax, ncols, (double *)dst, ld_dst);
+  MLPG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 
 int launch_delta(hipStream_t st, int dtype, const void *x, const int32_t *lengths, int B, int Tmax, int D,
                  const WinSet &w, void *out) {

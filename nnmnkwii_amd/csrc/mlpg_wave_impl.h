@@ -408,7 +408,8 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
   if (slot >= nslots) return;
   const int b = (slot / ngrp) * 8 + xcd, dgrp = slot % ngrp;
   if (b >= p.B) return;
-  const int sd = p.sd, D = p.D, Tmax = p.Tmax;
+  const int sd = p.sd, Tmax = p.Tmax;
+  const int ldi = (int)p.ld_in, ldg = (int)p.ld_gout, ldo = (int)p.ld_out;  // row strides (elements)
   const int d0 = dgrp * kG, d = d0 + wv;
   const int gvalid = sd - d0 < kG ? sd - d0 : kG;
   const bool sys_valid = d < sd;
@@ -416,12 +417,12 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
   T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
   const int mw = ws.mw, nw = ws.nw;
   // paired output stores need every run start (b, t, [w], d0) to be 2-element aligned
-  const bool out_pairs_ok = (sd % 2 == 0) && (((uintptr_t)p.out & (2 * sizeof(TOUT) - 1)) == 0);
+  const bool out_pairs_ok = (ldo % 2 == 0) && (!BWD || sd % 2 == 0) && (((uintptr_t)p.out & (2 * sizeof(TOUT) - 1)) == 0);
 
-  const TIN *mean_b = BWD ? nullptr : (const TIN *)p.mean + (size_t)b * Tmax * D;
+  const TIN *mean_b = BWD ? nullptr : (const TIN *)p.mean + (size_t)b * Tmax * ldi;
   const TIN *var_b = (const TIN *)p.var;
-  if (kVarTile) var_b += (size_t)b * Tmax * D;
-  const TIN *gout_b = BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * sd : nullptr;
+  if (kVarTile) var_b += (size_t)b * Tmax * ldi;
+  const TIN *gout_b = BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * ldg : nullptr;
 
   const int f0 = lane * M;  // first frame of this lane's chunk
 #ifdef MLPG_WAVE_TIMING
@@ -457,12 +458,12 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
   if (BWD) {
     // right-hand side = grad_out[:, d]; runs of G columns with row stride sd
     if (DMA) {
-      load_tile_dma<M, TIN>(tileM, gout_b + d0, sd, T, gvalid, wv, lane);
+      load_tile_dma<M, TIN>(tileM, gout_b + d0, ldg, T, gvalid, wv, lane);
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < M; ++i) rhs[i] = ((liveS >> (i + 1)) & 1ull) ? (double)tileM[baseD + i * DL::ESTRIDE] : 0.0;
     } else {
-      load_tile_regs<M, TIN>(tileM, gout_b + d0, sd, T, gvalid, tid);
+      load_tile_regs<M, TIN>(tileM, gout_b + d0, ldg, T, gvalid, tid);
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < M; ++i) rhs[i] = ((liveS >> (i + 1)) & 1ull) ? (double)tileM[baseR + i] : 0.0;
@@ -472,8 +473,8 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
 
   MLPG_TICK(0);
   if (DMA && MLPG_WAVE_ABLATE != 2) {
-    if (kVarTile) load_tile_dma<M, TIN>(tileV, var_b + d0, D, T, gvalid, wv, lane);
-    if (!BWD) load_tile_dma<M, TIN>(tileM, mean_b + d0, D, T, gvalid, wv, lane);
+    if (kVarTile) load_tile_dma<M, TIN>(tileV, var_b + d0, ldi, T, gvalid, wv, lane);
+    if (!BWD) load_tile_dma<M, TIN>(tileM, mean_b + d0, ldi, T, gvalid, wv, lane);
   }
   MLPG_TICK(3);
   for (int w = 0; w < nw; ++w) {
@@ -506,14 +507,14 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
                         // the transfer runs behind this window's arithmetic
       MLPG_TICK(2);
       if (w + 1 < nw && MLPG_WAVE_ABLATE != 2) {
-        if (kVarTile) load_tile_dma<M, TIN>(tileV, var_b + (w + 1) * sd + d0, D, T, gvalid, wv, lane);
-        if (!BWD) load_tile_dma<M, TIN>(tileM, mean_b + (w + 1) * sd + d0, D, T, gvalid, wv, lane);
+        if (kVarTile) load_tile_dma<M, TIN>(tileV, var_b + (w + 1) * sd + d0, ldi, T, gvalid, wv, lane);
+        if (!BWD) load_tile_dma<M, TIN>(tileM, mean_b + (w + 1) * sd + d0, ldi, T, gvalid, wv, lane);
       }
       MLPG_TICK(3);
     } else {
       if (MLPG_WAVE_ABLATE != 2) {
-        if (kVarTile) load_tile_regs<M, TIN>(tileV, var_b + w * sd + d0, D, T, gvalid, tid);
-        if (!BWD) load_tile_regs<M, TIN>(tileM, mean_b + w * sd + d0, D, T, gvalid, tid);
+        if (kVarTile) load_tile_regs<M, TIN>(tileV, var_b + w * sd + d0, ldi, T, gvalid, tid);
+        if (!BWD) load_tile_regs<M, TIN>(tileM, mean_b + w * sd + d0, ldi, T, gvalid, tid);
       }
       __syncthreads();
       if (kVarTile) {
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
     }
     status = __shfl(status, 0);
   }
-  if (sys_valid && lane == 0 && p.status) p.status[(size_t)b * sd + d] = status;
+  if (sys_valid && lane == 0 && p.status) p.status[(size_t)b * p.ld_status + d] = status;
   const bool zero_out = status != 0;
 
   MLPG_TICK(6);
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
     for (int i = 0; i < M; ++i)
       if ((liveS >> (i + 1)) & 1ull) tileO[baseR + i] = zero_out ? (TOUT)0 : (TOUT)rhs[i];
     __syncthreads();
-    store_tile<M, TOUT>(tileO, (TOUT *)p.out + (size_t)b * Tmax * sd + d0, sd, T, Tmax, gvalid, tid, out_pairs_ok);
+    store_tile<M, TOUT>(tileO, (TOUT *)p.out + (size_t)b * Tmax * ldo + d0, ldo, T, Tmax, gvalid, tid, out_pairs_ok);
   } else {
     // grad[t, w*sd+d] = tau_w[t] * (cm x[t-1] + c0 x[t] + cp x[t+1])      (paramgen/_mlpg.py:202-281)
     double xl = __shfl_up(rhs[M - 1], 1), xr = __shfl_down(rhs[0], 1);
@@ -620,8 +621,8 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
       const unsigned long long live = w ? liveD : liveS;
       __syncthreads();  // previous store_tile / tile users done
       if (kVarTile) {
-        if (DMA) load_tile_dma<M, TIN>(tileV, var_b + w * sd + d0, D, T, gvalid, wv, lane);
-        else load_tile_regs<M, TIN>(tileV, var_b + w * sd + d0, D, T, gvalid, tid);
+        if (DMA) load_tile_dma<M, TIN>(tileV, var_b + w * sd + d0, ldi, T, gvalid, wv, lane);
+        else load_tile_regs<M, TIN>(tileV, var_b + w * sd + d0, ldi, T, gvalid, tid);
       }
       __syncthreads();
       double tau_glob = 1.0;
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
         }
       }
       __syncthreads();
-      store_tile<M, TOUT>(tileO, (TOUT *)p.out + (size_t)b * Tmax * D + w * sd + d0, D, T, Tmax, gvalid, tid, out_pairs_ok);
+      store_tile<M, TOUT>(tileO, (TOUT *)p.out + (size_t)b * Tmax * ldo + w * sd + d0, ldo, T, Tmax, gvalid, tid, out_pairs_ok);
     }
   }
 #ifdef MLPG_WAVE_TIMING
@@ -671,9 +672,9 @@ template <typename TIN>
 bool dma_ok(const Problem &p) {
   constexpr int epl = 16 / (int)sizeof(TIN);
   if (MLPG_WAVE_DMA == 0) return false;
-  if (kG % epl || p.D % epl || p.sd % epl) return false;
+  if (kG % epl || p.ld_in % epl || p.ld_gout % epl || p.sd % epl) return false;
   auto al = [](const void *q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
-  return al(p.mean) && al(p.var) && al(p.grad_out);
+  return al(p.mean) && (p.var_mode != MLPG_HIP_VAR_FRAME || al(p.var)) && al(p.grad_out);
 }
 
 template <int M, typename TIN, typename TOUT, bool BWD, bool DMA>

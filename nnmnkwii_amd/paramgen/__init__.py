@@ -5,6 +5,7 @@ from ._mlpg import (  # noqa: F401
     mlpg,
     mlpg_batch,
     mlpg_grad,
+    multi_stream_mlpg,
     reshape_means,
     unit_variance_mlpg_matrix,
 )
@@ -17,4 +18,5 @@ __all__ = [
     "reshape_means",
     "full_window_mat",
     "mlpg_batch",
+    "multi_stream_mlpg",
 ]

@@ -18,6 +18,7 @@ __all__ = [
     "reshape_means",
     "full_window_mat",
     "mlpg_batch",
+    "multi_stream_mlpg",
 ]
 
 
@@ -121,6 +122,67 @@ def mlpg_batch(means, variances, windows, lengths=None, algo=_hip.ALGO_AUTO, che
     if is_np:
         return out.cpu().numpy()
     return out
+
+
+def multi_stream_mlpg(inputs, variances, windows, stream_sizes, has_dynamic_features, lengths=None,
+                      algo=_hip.ALGO_AUTO, check=True, device=None):
+    """MLPG over every stream of a multi-stream acoustic feature matrix in ONE call.
+
+    The Merlin-style layout the reference's data sources use (util/files.py:90-115): the feature
+    axis is ``[stream 0 | stream 1 | ...]`` with ``stream_sizes`` columns each (e.g. mgc 180 | lf0 3 |
+    vuv 1 | bap 15); a stream with dynamic features is window-major (static, delta, delta-delta) and
+    is replaced by its maximum-likelihood static trajectory ``paramgen.mlpg(stream, var, windows)``;
+    a stream without (``has_dynamic_features[k]`` False, e.g. vuv) is copied through.  This is the
+    per-stream, per-utterance loop users write with ``util.apply_each2d_padded`` (util/__init__.py:
+    44-66), done on the GPU directly on the padded ``(N, Tmax, D)`` batch, each stream consumed in
+    place (no slicing copies).
+
+    inputs: ``(T, D)`` or ``(N, Tmax, D)`` numpy array / CUDA tensor; variances: same shape, a
+    global ``(D,)`` or None (unit); windows: one window list for all dynamic streams or a list of
+    window lists, one per stream; lengths: valid frames per utterance (3-D input).  Returns the
+    static features of all streams side by side, same kind and rank as ``inputs``.
+    """
+    torch = _hip.torch_mod()
+    is_np = not torch.is_tensor(inputs)
+    dev = _hip.require_gpu(device if is_np or not inputs.is_cuda else inputs.device)
+    m = torch.from_numpy(np.ascontiguousarray(_as_float(inputs))).to(dev) if is_np else inputs.to(dev).contiguous()
+    two_d = m.dim() == 2
+    if two_d:
+        m = m[None]
+    assert m.dim() == 3
+    D = m.shape[-1]
+    assert len(stream_sizes) == len(has_dynamic_features) and sum(stream_sizes) == D
+    if variances is None:
+        v = None
+    elif torch.is_tensor(variances):
+        v = variances.to(device=dev, dtype=m.dtype).contiguous()
+    else:
+        v = torch.from_numpy(np.ascontiguousarray(np.asarray(variances))).to(device=dev, dtype=m.dtype)
+    if v is not None and v.dim() != 1:
+        if two_d and v.dim() == 2:
+            v = v[None]
+        assert v.shape == m.shape
+    per_stream = len(windows) > 0 and len(windows[0]) > 0 and isinstance(windows[0][0], (tuple, list))
+    assert not per_stream or len(windows) == len(stream_sizes)
+    streams, col = [], 0
+    for k, (size, dyn) in enumerate(zip(stream_sizes, has_dynamic_features)):
+        if dyn:
+            w = windows[k] if per_stream else windows
+            assert size % len(w) == 0
+            streams.append((col, size // len(w), w))
+        else:
+            streams.append((col, size, None))
+        col += size
+    L = None
+    if lengths is not None:
+        L = torch.as_tensor(np.asarray(lengths) if not torch.is_tensor(lengths) else lengths).to(
+            device=dev, dtype=torch.int32).contiguous()
+    out, status = _hip.forward_streams(m, v, streams, L, algo=algo, want_status=check)
+    if check:
+        _hip.raise_on_status(status, out.shape[-1])
+    if two_d:
+        out = out[0]
+    return out.cpu().numpy() if is_np else out
 
 
 def mlpg(mean_frames, variance_frames, windows):

@@ -138,6 +138,32 @@ def main():
     out["delta/plain/x"] = x
     out["delta/plain/y"] = delta_features(x, [np.array([1.0]), np.array([0.25, 0.5, -1.0, 2.0]), np.array([-0.5, 0.0, 0.5])])
 
+    # --- Merlin-style multi-stream utterance from the reference's own example data (util/files.py:90-115:
+    #     mgc 180 | lf0 3 | vuv 1 | bap 3, float32), cropped to 160 frames; per-stream paramgen.mlpg with the
+    #     global variance of the file, exactly the loop a user of the reference writes
+    from nnmnkwii.util import example_file_data_sources_for_acoustic_model
+    _, Ysrc = example_file_data_sources_for_acoustic_model()
+    feats = Ysrc.collect_features(Ysrc.collect_files()[0])[100:260].astype(np.float32)
+    gvar = feats.var(axis=0).astype(np.float32) + np.float32(1e-3)
+    out["merlin/feats"] = feats
+    out["merlin/var"] = gvar
+    sizes, dyn = [180, 3, 1, 3], [True, True, False, True]
+    cols, c0 = [], 0
+    for size, d_ in zip(sizes, dyn):
+        blk = feats[:, c0:c0 + size]
+        cols.append(G.mlpg(blk, gvar[c0:c0 + size], WINDOW_SETS["std3"]) if d_ else blk)
+        c0 += size
+    out["merlin/y"] = np.concatenate(cols, axis=1)
+    # the same with per-frame variances (float64)
+    f64 = feats.astype(np.float64)
+    v64 = np.tile(gvar.astype(np.float64), (len(f64), 1)) * (1.0 + 0.5 * np.random.RandomState(3).rand(*f64.shape))
+    out["merlin/v64"] = v64
+    cols, c0 = [], 0
+    for size, d_ in zip(sizes, dyn):
+        cols.append(G.mlpg(f64[:, c0:c0 + size], v64[:, c0:c0 + size], WINDOW_SETS["std3"]) if d_ else f64[:, c0:c0 + size])
+        c0 += size
+    out["merlin/y64"] = np.concatenate(cols, axis=1)
+
     # --- error behaviour: negative variance -> LinAlgError text
     m, v, _ = rand_case("std3", "f64", 10, 1)
     v = v.copy()

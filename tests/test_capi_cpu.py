@@ -29,7 +29,7 @@ def test_exports_match_header(L):
     assert declared == set(_hip.EXPORTS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.mlpg_hip_abi_version() == 1
+    assert L.mlpg_hip_abi_version() == 2
 
 
 def test_argument_validation_without_gpu(L):
@@ -50,6 +50,14 @@ def test_argument_validation_without_gpu(L):
     assert rc == -1 and b"extents" in L.mlpg_hip_last_error()
     # empty batch is a no-op
     rc = L.mlpg_hip_forward(0, None, 1, 0, None, fake, 0, None, 0, 4, 4, 2, p(wl), p(wu), p(wc), None, None)
+    assert rc == 0
+    # multi-stream entry: a stream that does not fit the row, and an empty table
+    from nnmnkwii_amd._hip import StreamDesc
+    tab = (StreamDesc * 1)(StreamDesc(4, 0, 1, 2, 0))
+    rc = L.mlpg_hip_forward_streams(0, None, 1, 0, fake, fake, 0, 5, None, 1, 4, 1, ctypes.addressof(tab), 2,
+                                    p(wl), p(wu), p(wc), fake, 1, None)
+    assert rc == -1 and b"does not fit" in L.mlpg_hip_last_error()
+    rc = L.mlpg_hip_forward_streams(0, None, 1, 0, fake, fake, 0, 5, None, 1, 4, 0, None, 0, None, None, None, fake, 1, None)
     assert rc == 0
     rc = L.mlpg_hip_fastdtw_l2(0, None, fake, fake, fake, fake, 1, 4, 4, 2, 0, fake, fake, fake, fake)
     assert rc == -1

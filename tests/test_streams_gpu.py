@@ -1,0 +1,118 @@
+"""multi-stream MLPG on the padded (N, Tmax, D) batch, streams consumed in place
+(mlpg_hip_forward_streams).  Checked against the reference's per-stream paramgen.mlpg on its own example
+data (golden), against the oracle per stream on random ragged batches, and against the dense entry point."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.dirname(HERE))
+from cases import WINDOW_SETS  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+STD3 = WINDOW_SETS["std3"]
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(HERE, "golden", "mlpg_golden.npz"))
+
+
+def test_merlin_example_utterance_matches_reference(golden):
+    from nnmnkwii_amd import paramgen as G
+    feats, gvar = golden["merlin/feats"], golden["merlin/var"]
+    sizes, dyn = [180, 3, 1, 3], [True, True, False, True]
+    y = G.multi_stream_mlpg(feats, gvar, STD3, sizes, dyn)
+    ref = golden["merlin/y"]
+    assert y.shape == ref.shape == (feats.shape[0], 60 + 1 + 1 + 1) and y.dtype == np.float32
+    scale = np.abs(ref).max(axis=0)
+    assert (np.abs(y - ref).max(axis=0) <= 2e-6 * scale + 1e-7).all()       # float32 outputs of float64 solves
+    np.testing.assert_array_equal(y[:, 61], feats[:, 183])                  # vuv passes through untouched
+    # per-frame float64 variances
+    y64 = G.multi_stream_mlpg(feats.astype(np.float64), golden["merlin/v64"], STD3, sizes, dyn)
+    r64 = golden["merlin/y64"]
+    assert (np.abs(y64 - r64).max(axis=0) <= 1e-10 * np.abs(r64).max(axis=0) + 1e-14).all()
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("vmode", ["frame", "global", "unit"])
+def test_streams_vs_oracle_ragged_batch(dt, vmode):
+    """C5 layout mgc 180 | lf0 3 | bap 15 (+ a pass-through column), ragged lengths, both kernels' paths."""
+    import torch
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd import paramgen as G
+    from oracle import mlpg as O
+    rng = np.random.RandomState(11)
+    B, T = 5, 300
+    sizes, dyn = [180, 3, 1, 15], [True, True, False, True]
+    D = sum(sizes)
+    m = rng.randn(B, T, D).astype(dt)
+    lengths = np.array([300, 1, 257, 64, 2], dtype=np.int32)
+    for b in range(B):
+        m[b, lengths[b]:] = 0
+    if vmode == "frame":
+        v = (rng.rand(B, T, D) + 0.1).astype(dt)
+    elif vmode == "global":
+        v = (rng.rand(D) + 0.1).astype(dt)
+    else:
+        v = None
+    y = G.multi_stream_mlpg(m, v, STD3, sizes, dyn, lengths=lengths)
+    assert y.shape == (B, T, 60 + 1 + 1 + 5) and y.dtype == dt
+    c0, o0 = 0, 0
+    tol = 1e-9 if dt == np.float64 else 2e-6
+    for size, d_ in zip(sizes, dyn):
+        if d_:
+            sd = size // 3
+            vs = None if v is None else (v[c0:c0 + size] if v.ndim == 1 else np.ascontiguousarray(v[:, :, c0:c0 + size]))
+            if vs is None:
+                vs = np.ones(size, dtype=dt)
+            ref, st, rc = O.mlpg_batch(np.ascontiguousarray(m[:, :, c0:c0 + size]), vs, STD3, lengths)
+            assert rc == 0
+            got = y[:, :, o0:o0 + sd]
+            assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max())
+            o0 += sd
+        else:
+            ref = m[:, :, c0:c0 + size].copy()
+            np.testing.assert_array_equal(y[:, :, o0:o0 + size], ref)
+            o0 += size
+        c0 += size
+    for b in range(B):
+        assert not y[b, lengths[b]:].any()           # padding frames zero-filled
+    # the in-place stream slice equals the dense entry point on a contiguous copy (bit for bit: same kernel)
+    md = torch.from_numpy(m).cuda()
+    vd = None if v is None else torch.from_numpy(v).cuda()
+    Ld = torch.from_numpy(lengths).cuda()
+    out, st = _hip.forward_streams(md, vd, [(0, 60, STD3), (180, 1, STD3), (183, 1, None), (184, 5, STD3)], Ld)
+    assert int(st.abs().sum().item()) == 0
+    dense_v = None if vd is None else (vd[:180].contiguous() if vd.dim() == 1 else vd[:, :, :180].contiguous())
+    dense, _ = _hip.forward(md[:, :, :180].contiguous(), dense_v, STD3, Ld)
+    assert torch.equal(out[:, :, :60], dense)
+
+
+def test_streams_status_and_errors():
+    import torch
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(5)
+    m = rng.randn(2, 40, 9)
+    v = rng.rand(2, 40, 9) + 0.1
+    v[1, 7, 6] = -1e-3                                 # stream 1 = cols 6..8 (sd = 1): static variance of frame 7 negative
+    sizes, dyn = [6, 3], [True, True]
+    with pytest.raises(np.linalg.LinAlgError, match="leading minor not positive definite"):
+        G.multi_stream_mlpg(m, v, STD3, sizes, dyn)
+    out, st = _hip.forward_streams(torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), [(0, 2, STD3), (6, 1, STD3)])
+    st = st.cpu().numpy()
+    assert st.shape == (2, 3) and (st[0] == 0).all() and (st[1, :2] == 0).all() and st[1, 2] > 0
+    assert not out[1, :, 2].cpu().numpy().any()       # the failing system is zero-filled
+    # per-stream window lists, one of them wide (generic kernel) and a 2-D (T, D) input
+    x = rng.randn(50, 4 + 6)
+    y = G.multi_stream_mlpg(x, None, [WINDOW_SETS["std2"], WINDOW_SETS["wide3"]], [4, 6], [True, True])
+    from oracle import mlpg as O
+    r0 = O.mlpg(np.ascontiguousarray(x[:, :4]), np.ones(4), WINDOW_SETS["std2"])
+    r1 = O.mlpg(np.ascontiguousarray(x[:, 4:]), np.ones(6), WINDOW_SETS["wide3"])
+    np.testing.assert_allclose(y, np.concatenate([r0, r1], axis=1), rtol=1e-9, atol=1e-11)
+    with pytest.raises(_hip.HipExtensionError):
+        _hip.forward_streams(torch.zeros(1, 4, 6, dtype=torch.float64).cuda(), None, [(4, 1, STD3)])   # does not fit

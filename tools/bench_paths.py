@@ -7,7 +7,8 @@
   c3  : autograd.unit_variance_mlpg forward+backward, B=64 x T=500 x 180, float32 tensors on the GPU
   c3m : autograd.mlpg (generic variances) forward+backward, one utterance T=500 x 180 float32
   c4  : DTWAligner on 128 pairs (1 GPU share of config 4), T in [700, 900], 25-dim, radius 1
-  c5  : Merlin-style acoustic paramgen mgc(60)+lf0(1)+bap(5), T=2000, B=512 (1 GPU share of config 5), float64
+  c5  : Merlin-style acoustic paramgen mgc(60)+lf0(1)+bap(5), T=2000, B=512 (1 GPU share of config 5), float64;
+        per-stream dense tensors, and the three streams in place from one (B, T, 198) batch (forward_streams)
 
 Each line carries the GPU time (HIP events on the launch stream), the algorithmic bytes, GB/s, and a
 bounded CPU baseline from the oracle on the same host (the checker, timed like bench.py's cpu_baseline).
@@ -182,6 +183,14 @@ def main():
             del m, v
         emit(path="c5-all-streams", batch=B, ms=tot_ms, frames_per_s=B * T / tot_ms * 1e3, alg_bytes=tot_by,
              GBps=tot_by / tot_ms / 1e6)
+        # the same three streams consumed in place from ONE (B, T, 198) batch: mlpg_hip_forward_streams
+        m = torch.randn(B, T, 198, dtype=torch.float64, device=dev, generator=gen)
+        v = torch.rand(B, T, 198, dtype=torch.float64, device=dev, generator=gen) + 0.1
+        streams = [(0, 60, WINDOWS), (180, 1, WINDOWS), (183, 5, WINDOWS)]
+        ms = gpu_time(lambda: _hip.forward_streams(m, v, streams, want_status=False), steps=5)
+        emit(path="c5-forward_streams-one-call", batch=B, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=tot_by,
+             GBps=tot_by / ms / 1e6)
+        del m, v
 
 
 if __name__ == "__main__":
