@@ -15,15 +15,23 @@
 //        a. the chunk's x rows and y rows are staged in LDS (contiguous,
 //           coalesced copies) and the local cost of every window cell is
 //           computed by all lanes;
-//        b. the DP recurrence is swept along ANTI-DIAGONALS: lane r owns row
-//           i0 + r and at step s handles column s - r, so one step is exactly
+//        b. the DP recurrence is swept along ANTI-DIAGONALS: lane r >= 1 owns row
+//           i0 + r - 1 and at step s handles column s - r, so one step is exactly
 //           one anti-diagonal.  Rows hand their values down with a DPP
 //           wave_shr:1 register move -- no LDS round trip, no barrier inside
-//           the sweep; only the first row of a chunk reads the previous
-//           chunk's last row from LDS (prefetched one step ahead);
-//        c. 2-bit back-pointers are packed 32 cells per 64-bit word in LDS;
-//   3. back-trace by one lane (one LDS word per row, next row prefetched), new
-//      path kept in LDS for the next level.
+//           the sweep.  Lane 0 is the FEEDER: it replays the previous chunk's
+//           last row (or the virtual row -1 of the level) through the same
+//           instruction stream, so the first row of a chunk needs no special
+//           case;
+//        c. one back-pointer byte per window cell in LDS;
+//   3. back-trace, parallel over SEGMENTS of 32 rows: every (segment, entry
+//      column of its bottom row) pair is traced by its own thread up to the
+//      segment's top (exit column + cell count); one thread stitches the
+//      segments from the bottom-right corner upwards; one thread per segment
+//      re-traces its actual piece and writes it at its final position.  ~100
+//      dependent steps per level instead of tx + ty.  (Windows too wide for the
+//      candidate table fall back to a sequential wave-uniform walk.)  The new
+//      path stays in LDS for the next level.
 // Everything except the pyramid lives in LDS.
 //
 // Arithmetic is bit-compatible with the oracle: cost = sqrt(sum_k (x-y)^2)
@@ -57,12 +65,12 @@ struct DtwParams {
   size_t pyr_stride;  // (Tx + Ty) * D
   int cellcap;        // window cells per level (bound)
   int chunkcap;       // cost cells per DP chunk
-  int wordcap;        // 64-bit back-pointer words per level
   int ycap;           // y rows staged per chunk
 };
 
 constexpr int kMaxLevels = 20;
-constexpr int kRows = 64;  // rows per chunk = lanes of the sweeping wavefront
+constexpr int kRows = 63;  // rows per chunk: lanes 1..63 of the sweeping wavefront (lane 0 feeds the row above)
+constexpr int kSeg = 32;    // rows per back-trace segment
 constexpr int kThreads = 256;  // 4 wavefronts per pair: all of them stage/halve/compute local costs, wavefront 0 sweeps
 
 __device__ __forceinline__ double l2_cost(const double *__restrict__ a, const double *__restrict__ b, int D) {
@@ -107,18 +115,23 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
   double *dprevB = dprevA + Ty;                    //                                  (pong)
   double *xs = dprevB + Ty;                        // staged x rows of the chunk   [kRows][D]
   double *ys = xs + kRows * D;                     // staged y rows of the chunk   [ycap][D]
-  unsigned long long *bpw = (unsigned long long *)(ys + (size_t)p.ycap * D);  // packed back-pointers
-  int *off = (int *)(bpw + p.wordcap);             // cell offset of each row (prefix sum of widths)
-  int *woff = off + (Tx + 1);                      // back-pointer word offset of each row
-  int *lvl_x = woff + (Tx + 1);
+  unsigned long long *rinfo = (unsigned long long *)(ys + (size_t)p.ycap * D);  // per row: lo | hi << 16 | off << 32
+  int *off = (int *)(rinfo + Tx);                  // cell offset of each row (prefix sum of widths)
+  int *lvl_x = off + (Tx + 1);
   int *lvl_y = lvl_x + kMaxLevels;
   int *bcast = lvl_y + kMaxLevels;  // [8]
-  unsigned short *lo = (unsigned short *)(bcast + 8);
+  const int segcap = Tx / kSeg + 3;
+  int *segoff = bcast + 8;          // candidate-table offset of each back-trace segment
+  int *segent = segoff + segcap;    // entry column (relative to the bottom row's window) chosen by the stitch
+  int *segend = segent + segcap;    // end (exclusive) of the segment's piece in the path arrays
+  unsigned short *lo = (unsigned short *)(segend + segcap);
   unsigned short *hi = lo + Tx;
   unsigned short *cfirst = hi + Tx;
   unsigned short *clast = cfirst + (Tx / 2 + 2);
   unsigned short *pth_i = clast + (Tx / 2 + 2);
   unsigned short *pth_j = pth_i + pcap;
+  unsigned char *bp = (unsigned char *)(pth_j + pcap);  // back-pointer of every window cell, then a dummy row for the feeder
+  const int bp_dummy = p.cellcap;
 
   const int tx = p.lenx[n], ty = p.leny[n];
   int32_t *out_i = p.path_i + (size_t)n * pcap;
@@ -208,31 +221,24 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     }
     __syncthreads();
 
-    // ---- 2b. row offsets: cells (off) and back-pointer words (woff); wavefront 0 ----
+    // ---- 2b. row offsets: cells (off); wavefront 0 ----
     if (w0) {
       const int rpl = (ltx + 63) / 64;
       const int b0 = lane * rpl < ltx ? lane * rpl : ltx;
       const int b1 = b0 + rpl < ltx ? b0 + rpl : ltx;
-      int sum = 0, wsum = 0;
-      for (int i = b0; i < b1; ++i) {
-        const int wdt = (int)hi[i] - (int)lo[i] + 1;
-        sum += wdt;
-        wsum += (wdt + 31) >> 5;
-      }
-      int total, wtotal;
+      int sum = 0;
+      for (int i = b0; i < b1; ++i) sum += (int)hi[i] - (int)lo[i] + 1;
+      int total;
       int run = wave_excl_scan(sum, lane, &total);
-      int wrun = wave_excl_scan(wsum, lane, &wtotal);
       for (int i = b0; i < b1; ++i) {
-        const int wdt = (int)hi[i] - (int)lo[i] + 1;
         off[i] = run;
-        woff[i] = wrun;
-        run += wdt;
-        wrun += (wdt + 31) >> 5;
+        rinfo[i] = (unsigned long long)lo[i] | ((unsigned long long)hi[i] << 16) | ((unsigned long long)(unsigned)run << 32);
+        run += (int)hi[i] - (int)lo[i] + 1;
       }
       if (lane == 0) {
         off[ltx] = total;
-        woff[ltx] = wtotal;
-        bcast[3] = (total > p.cellcap || wtotal > p.wordcap) ? 1 : 0;
+        bcast[3] = (total > p.cellcap) ? 1 : 0;
+        dprevA[0] = 0.0;  // virtual row -1 of the level: D[-1][-1] = 0, nothing else
       }
     }
     __syncthreads();
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     DTW_TICK(1);
     // ---- 2c. DP over chunks of rows ----
     int i0 = 0;
-    int prevlo = 0, prevhi = -1;
+    int prevlo = -1, prevhi = -1;  // the virtual row -1 has the single cell (-1, -1)
     double *dprev = dprevA, *dnext = dprevB;
     double last_val = INFINITY;
     while (i0 < ltx) {
@@ -250,10 +256,10 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       const int ylo = (int)lo[i0];
       const bool wide = ((int)hi[i0] - ylo + 1) > p.ycap;  // a single row wider than the y stage
       if (w0) {
-        const bool fits = (i0 + lane < ltx) && (off[i0 + lane + 1] - base <= p.chunkcap) &&
+        const bool fits = (lane < kRows) && (i0 + lane < ltx) && (off[i0 + lane + 1] - base <= p.chunkcap) &&
                           (wide || ((int)hi[i0 + lane] - ylo + 1) <= p.ycap);
         const unsigned long long m = __ballot(fits);
-        if (lane == 0) bcast[2] = (~m == 0ull) ? 64 : (__ffsll((long long)~m) - 1);
+        if (lane == 0) bcast[2] = __ffsll((long long)~m) - 1;  // bit 63 is never set: R <= 63
       }
       __syncthreads();
       const int R = bcast[2];
@@ -283,75 +289,61 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       __syncthreads();
       DTW_TICK(3);
 
-      // anti-diagonal sweep (wavefront 0): lane = row, step s handles column s - lane
+      // anti-diagonal sweep (wavefront 0): lane r >= 1 owns row i0 + r - 1, lane 0 feeds the row above;
+      // at step s every lane handles column s - lane of its row
       if (w0) {
-      const bool act = lane < R;
-      const int i = i0 + lane;
-      const int mylo = act ? (int)lo[i] : 0, myhi = act ? (int)hi[i] : -1;
-      const int cbase = act ? off[i] - base : 0;
-      const int wbase = act ? woff[i] : 0;
-      const int s0 = (int)lo[i0];
-      const int s1 = (int)hi[i0 + R - 1] + R - 1;
-      const bool first_row = (i == 0);           // virtual row -1: only D[-1][-1] = 0
-      const bool is_last = act && lane == R - 1;  // hands its row to the next chunk
-      double pub = INFINITY;      // this lane's D at the column it handled in the previous step (INF if none)
-      // row above at column j-1: rows >= 1 of the chunk collect it from the sweep itself; the chunk's
-      // first row needs the previous chunk's last row at column s0 - 1
-      double up_old = (lane == 0 && s0 - 1 >= prevlo && s0 - 1 <= prevhi) ? dprev[s0 - 1 - prevlo] : INFINITY;
-      double left = INFINITY;
-      unsigned long long word = 0ull;
-      const int wmax = myhi > mylo ? myhi - mylo : 0;
-      const int pmax = prevhi > prevlo ? prevhi - prevlo : 0;
-      // The only loop-carried chain is add -> compare -> select -> DPP; everything the step needs
-      // from LDS (its local cost and, for the chunk's first row, the previous chunk's last row) is
-      // fetched TWO steps ahead so that no step waits on an LDS round trip.
-      auto fetch_dt = [&](int jj) {
-        int c = jj - mylo;
+      const bool feeder = lane == 0;
+      const bool real = lane >= 1 && lane <= R;
+      const int i = i0 + lane - 1;
+      int mylo = 0, width = 0, bbase = bp_dummy;
+      const double *src = dchunk;
+      if (feeder) {
+        mylo = prevlo;
+        width = prevhi - prevlo + 1;
+        src = dprev;
+      } else if (real) {
+        mylo = (int)lo[i];
+        width = (int)hi[i] - mylo + 1;
+        src = dchunk + (off[i] - base);
+        bbase = off[i];
+      }
+      const bool is_last = lane == R;  // hands its row to the next chunk
+      const int s0 = (int)lo[i0] - 1;  // two steps of lead-in: the feeder emits columns lo-1 and lo first
+      const int s1 = (int)hi[i0 + R - 1] + R;
+      const int wmax = width > 0 ? width - 1 : 0;
+      // The only loop-carried chain is add -> compare -> select -> DPP; the local cost is fetched TWO
+      // steps ahead so that no step waits on an LDS round trip.
+      auto fetch = [&](int c) {
         c = c < 0 ? 0 : (c > wmax ? wmax : c);
-        return dchunk[cbase + c];
+        return src[c];
       };
-      auto fetch_pv = [&](int jj) {
-        int c = jj - prevlo;
-        const bool in = c >= 0 && c <= prevhi - prevlo;
-        c = c < 0 ? 0 : (c > pmax ? pmax : c);
-        const double v = dprev[c];
-        return in ? v : INFINITY;
-      };
-      double dt_a = fetch_dt(s0 - lane), dt_b = fetch_dt(s0 + 1 - lane);
-      double pv_a = fetch_pv(s0 - lane), pv_b = fetch_pv(s0 + 1 - lane);
-      for (int s = s0; s <= s1; ++s) {
-        const int j = s - lane;
+      int cpos = s0 - lane - mylo;  // column of this step relative to the row's window
+      double dt_a = fetch(cpos), dt_b = fetch(cpos + 1);
+      double pub = INFINITY;     // this lane's D at the column of the previous step (INF outside the window)
+      double up_old = INFINITY;  // row above at the previous column
+      double left = INFINITY;    // this row at the previous column (stays INF until the window starts)
+      for (int s = s0; s <= s1; ++s, ++cpos) {
         const double dt = dt_a;
-        double up_new = wave_shr1(pub);
-        up_new = (lane == 0) ? pv_a : up_new;
         dt_a = dt_b;
-        pv_a = pv_b;
-        dt_b = fetch_dt(j + 2);
-        pv_b = fetch_pv(j + 2);
-        const bool inwin = act && j >= mylo && j <= myhi;
-        double up = first_row ? INFINITY : up_new;
-        double dg = first_row ? ((j == 0) ? 0.0 : INFINITY) : up_old;
-        const double lf = (j - 1 >= mylo) ? left : INFINITY;
-        const double cu = __dadd_rn(up, dt), cl = __dadd_rn(lf, dt), cd = __dadd_rn(dg, dt);
+        dt_b = fetch(cpos + 2);
+        const double up = wave_shr1(pub);
+        const bool inwin = (unsigned)cpos < (unsigned)width;
+        const double cu = __dadd_rn(up, dt), cl = __dadd_rn(left, dt), cd = __dadd_rn(up_old, dt);
         double best = cu;
-        unsigned long long code = 0ull;
-        if (cl < best) { best = cl; code = 1ull; }
-        if (cd < best) { best = cd; code = 2ull; }
-        const int cpos = j - mylo;
+        unsigned code = 0u;
+        if (cl < best) { best = cl; code = 1u; }
+        if (cd < best) { best = cd; code = 2u; }
+        best = feeder ? dt : best;  // the feeder replays stored D values
         if (inwin) {
           left = best;
-          word |= code << (2 * (cpos & 31));
-          if ((cpos & 31) == 31 || j == myhi) {
-            bpw[wbase + (cpos >> 5)] = word;
-            word = 0ull;
-          }
+          bp[bbase + cpos] = (unsigned char)code;
           if (is_last) dnext[cpos] = best;
         }
         pub = inwin ? best : INFINITY;
-        up_old = up_new;
+        up_old = up;
       }
       // value of the chunk's last cell (bottom-right corner of the level if this is the last chunk)
-      last_val = __shfl(left, R - 1);
+      last_val = __shfl(left, R);
       }  // w0
       prevlo = (int)lo[i0 + R - 1];
       prevhi = (int)hi[i0 + R - 1];
@@ -365,59 +357,132 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     if (fail) break;
     level_cost = (prevhi == lty - 1) ? last_val : INFINITY;
 
-    // ---- 3. back-trace: every lane walks the same (wave-uniform) path; the (lo, hi, first
-    // back-pointer word) of 64 rows at a time are cached one row per lane and read with
-    // v_readlane, so a step costs a handful of scalar instructions instead of LDS round trips ----
-    if (w0) {
-      int bi = ltx - 1, bj = lty - 1, pos = pcap;
-      int ok = __builtin_amdgcn_readfirstlane((level_cost < INFINITY) ? 1 : 0);
-      int rb = ltx;  // base row of the cached block (forces the first load)
-      int vlo = 0, vhi = -1, vwo = 0;
-      unsigned vw_lo = 0u, vw_hi = 0u;
-      while (ok) {
-        if (bi < rb) {
-          rb = bi - 63 < 0 ? 0 : bi - 63;
-          const int idx = rb + lane;
-          const bool v = idx <= bi;
-          vlo = v ? (int)lo[idx] : 0;
-          vhi = v ? (int)hi[idx] : -1;
-          vwo = v ? woff[idx] : 0;
-          const unsigned long long w = v ? bpw[vwo] : 0ull;
-          vw_lo = (unsigned)w;
-          vw_hi = (unsigned)(w >> 32);
+    // ---- 3. back-trace ----
+    // One walk from a cell up to (excluding) row `top`: follows the back-pointers, optionally
+    // writing the cells at positions wpos-1, wpos-2, ...; returns the column reached in row top-1
+    // (-2 if the walk leaves the window) and the number of cells visited.
+    auto walk = [&](int bi, int bj, int top, int wpos, bool write, int *ncells) {
+      unsigned long long ri = rinfo[bi];
+      int rl = (int)(ri & 0xffffu), ro = (int)(ri >> 32);
+      int cnt = 0;
+      while (true) {
+        ++cnt;
+        if (write) {
+          --wpos;
+          pth_i[wpos] = (unsigned short)bi;
+          pth_j[wpos] = (unsigned short)bj;
         }
-        const int L = bi - rb;
-        const int rl = __builtin_amdgcn_readlane(vlo, L), rh = __builtin_amdgcn_readlane(vhi, L);
-        const int rwo = __builtin_amdgcn_readlane(vwo, L);
-        const unsigned long long w0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vw_hi, L) << 32) |
-                                      (unsigned)__builtin_amdgcn_readlane((int)vw_lo, L);
+        const unsigned code = bp[ro + bj - rl];
+        if (code == 1u) {  // left: stay in the row
+          bj -= 1;
+          if (bj < rl) { bj = -2; break; }
+          continue;
+        }
+        if (code == 2u) bj -= 1;
+        bi -= 1;
+        if (bi < top) break;
+        ri = rinfo[bi];
+        rl = (int)(ri & 0xffffu);
+        ro = (int)(ri >> 32);
+        if (bj < rl || bj > (int)((ri >> 16) & 0xffffu)) { bj = -2; break; }
+      }
+      *ncells = cnt;
+      return bj;
+    };
+    const int G = (ltx + kSeg - 1) / kSeg;  // segment g = rows [g*kSeg, min((g+1)*kSeg, ltx))
+    unsigned short *exitcol = (unsigned short *)dchunk;  // exit column + 2 (the DP's cost buffer is idle now)
+    unsigned short *cnts = (unsigned short *)(exitcol + 2 * p.chunkcap);
+    if (w0) {  // candidate-table offsets: one entry per cell of every segment's bottom row
+      const int gpl = (G + 63) / 64;
+      const int g0 = lane * gpl < G ? lane * gpl : G;
+      const int g1 = g0 + gpl < G ? g0 + gpl : G;
+      int sum = 0;
+      for (int g = g0; g < g1; ++g) {
+        const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
+        sum += (int)hi[bot] - (int)lo[bot] + 1;
+      }
+      int total;
+      int run = wave_excl_scan(sum, lane, &total);
+      for (int g = g0; g < g1; ++g) {
+        const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
+        segoff[g] = run;
+        run += (int)hi[bot] - (int)lo[bot] + 1;
+      }
+      if (lane == 0) segoff[G] = total;
+    }
+    __syncthreads();
+    const int ntask = segoff[G];
+    if (ntask <= 2 * p.chunkcap && G < segcap) {
+      // pass 1: every (segment, entry column) candidate
+      for (int task = tid; task < ntask; task += kThreads) {
+        int a = 0, b = G;
+        while (b - a > 1) {
+          const int mid = (a + b) >> 1;
+          if (segoff[mid] <= task) a = mid; else b = mid;
+        }
+        const int bot = ((a + 1) * kSeg < ltx ? (a + 1) * kSeg : ltx) - 1;
+        int nc;
+        const int ex = walk(bot, (int)lo[bot] + (task - segoff[a]), a * kSeg, 0, false, &nc);
+        exitcol[task] = (unsigned short)(ex + 2);
+        cnts[task] = (unsigned short)nc;
+      }
+      __syncthreads();
+      // stitch from the bottom-right corner upwards
+      if (tid == 0) {
+        int ok = (level_cost < INFINITY) ? 1 : 0;
+        int bj = lty - 1, total = 0;
+        for (int g = G - 1; g >= 0 && ok; --g) {
+          const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
+          const int e = bj - (int)lo[bot];
+          if (e < 0 || bj > (int)hi[bot]) { ok = 0; break; }
+          const int task = segoff[g] + e;
+          segent[g] = e;
+          segend[g] = (int)cnts[task];
+          total += (int)cnts[task];
+          bj = (int)exitcol[task] - 2;
+          if (bj == -2) ok = 0;
+        }
+        if (ok && (bj != -1 || total > pcap)) ok = 0;
+        int run = pcap - total;
+        for (int g = 0; g < G && ok; ++g) {
+          run += segend[g];
+          segend[g] = run;
+        }
+        bcast[0] = pcap - total;
+        bcast[1] = ok;
+      }
+      __syncthreads();
+      // pass 2: every segment writes its piece of the path
+      if (bcast[1]) {
+        for (int g = tid; g < G; g += kThreads) {
+          const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
+          int nc;
+          (void)walk(bot, (int)lo[bot] + segent[g], g * kSeg, segend[g], true, &nc);
+        }
+      }
+    } else if (w0) {
+      // sequential fallback (very wide windows): the walk is wave-uniform, so the loaded values are
+      // made scalar (readfirstlane) and the control flow runs on the scalar unit
+      auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+      int bi = ltx - 1, bj = lty - 1, pos = pcap;
+      int ok = uni((level_cost < INFINITY) ? 1 : 0);
+      while (ok) {
+        const int rl = uni((int)lo[bi]), rh = uni((int)hi[bi]), ro = uni(off[bi]);
         if (bj < rl || bj > rh) { ok = 0; break; }
-        // cells of this row on the path: move left while the back-pointer says so
-        while (true) {
-          if (pos == 0) { ok = 0; break; }
+        bool up = false;
+        while (!up) {  // cells of this row on the path
+          if (pos == 0 || bj < rl) { ok = 0; break; }
+          const int code = uni((int)bp[ro + bj - rl]);
           --pos;
           if (lane == 0) {
             pth_i[pos] = (unsigned short)bi;
             pth_j[pos] = (unsigned short)bj;
           }
-          const int cpos = bj - rl;
-          unsigned long long w = w0;
-          if (cpos >= 32) {  // wide row: the word is not the cached one
-            const unsigned long long wl = bpw[rwo + (cpos >> 5)];
-            w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wl >> 32)) << 32) |
-                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wl);
-          }
-          const unsigned code = (unsigned)((w >> (2 * (cpos & 31))) & 3ull);
-          if (code == 1u) {
-            bj -= 1;
-            if (bj < rl) { ok = 0; break; }
-            continue;
-          }
-          if (code == 2u) bj -= 1;
-          bi -= 1;
-          break;
+          if (code != 0) bj -= 1;
+          up = code != 1;
         }
         if (!ok) break;
+        bi -= 1;
         if (bi < 0) {
           if (bj != -1) ok = 0;
           break;
@@ -462,9 +527,10 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
 size_t lds_bytes(int Tx, int Ty, int D, const DtwParams &p) {
   size_t b = 0;
   b += sizeof(double) * ((size_t)p.chunkcap + 2 * (size_t)Ty + (size_t)kRows * D + (size_t)p.ycap * D);
-  b += sizeof(unsigned long long) * (size_t)p.wordcap;
-  b += sizeof(int) * ((size_t)2 * (Tx + 1) + 2 * kMaxLevels + 8);
+  b += sizeof(unsigned long long) * (size_t)Tx;
+  b += sizeof(int) * ((size_t)(Tx + 1) + 2 * kMaxLevels + 8 + 3 * (size_t)(Tx / kSeg + 3));
   b += sizeof(unsigned short) * ((size_t)2 * Tx + 2 * (Tx / 2 + 2) + 2 * (size_t)(Tx + Ty));
+  b += (size_t)p.cellcap + (size_t)Ty + 16;  // back-pointer bytes + the feeder's dummy row
   return (b + 15) & ~(size_t)15;
 }
 
@@ -473,8 +539,8 @@ size_t lds_bytes(int Tx, int Ty, int D, const DtwParams &p) {
 int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, const int32_t *lenx,
                    const int32_t *leny, int N, int Tx, int Ty, int D, int radius, int32_t *path_i,
                    int32_t *path_j, int32_t *path_len, double *cost) {
-  if (Tx > 65535 || Ty > 65535) {
-    set_error("fastdtw: sequences longer than 65535 frames are not supported");
+  if (Tx > 65000 || Ty > 65000) {
+    set_error("fastdtw: sequences longer than 65000 frames are not supported");
     return MLPG_HIP_EINVAL;
   }
   DtwParams p;
@@ -489,7 +555,6 @@ int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, 
   if (full < cc) cc = full + 64;
   p.cellcap = (int)cc;
   p.chunkcap = Ty > 1024 ? Ty : 1024;
-  p.wordcap = (int)(cc / 32) + Tx + 8;
   // y rows staged per chunk: 64 rows of x at unit slope span ~64 + window width rows of y
   p.ycap = 128;
   while (p.ycap > 16 && lds_bytes(Tx, Ty, D, p) > 150 * 1024) p.ycap /= 2;
