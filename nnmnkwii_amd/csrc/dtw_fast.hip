@@ -11,10 +11,10 @@
 //   2. from the coarsest level (full DTW) down to level 0: per-row windows
 //      [lo_i, hi_i] from the coarser path (interval form of __expand_window:
 //      the union of (2r+1)^2 neighbourhoods along a monotone path is one
-//      interval per row), then, in chunks of <= 64 rows:
-//        a. the chunk's x rows and y rows are staged in LDS (contiguous,
-//           coalesced copies) and the local cost of every window cell is
-//           computed by all lanes;
+//      interval per row), then, in chunks of <= 63 rows:
+//        a. the local cost of every window cell of chunk c+1 is computed by
+//           wavefronts 1..3 (rows read through L1/L2) WHILE wavefront 0 sweeps
+//           chunk c: two cost buffers, one barrier per chunk;
 //        b. the DP recurrence is swept along ANTI-DIAGONALS: lane r >= 1 owns row
 //           i0 + r - 1 and at step s handles column s - r, so one step is exactly
 //           one anti-diagonal.  Rows hand their values down with a DPP
@@ -65,7 +65,6 @@ struct DtwParams {
   size_t pyr_stride;  // (Tx + Ty) * D
   int cellcap;        // window cells per level (bound)
   int chunkcap;       // cost cells per DP chunk
-  int ycap;           // y rows staged per chunk
 };
 
 constexpr int kMaxLevels = 20;
@@ -93,12 +92,18 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total) {
   return incl - v;
 }
 
-// lane r receives lane r-1's value (lane 0 keeps its own): one DPP move per 32-bit half
-__device__ __forceinline__ double wave_shr1(double v) {
+// lane r receives lane r-1's value, lane 0 receives +0.0 (bound_ctrl): one DPP move per 32-bit half
+__device__ __forceinline__ double wave_shr1z(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int clamp_idx(int c, int hi) {  // median(c, 0, hi), hi >= 0
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(c), "v"(hi));
+  return r;
 }
 
 __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
@@ -110,12 +115,10 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
   const int pcap = Tx + Ty;
 
   // ---- LDS carve (doubles / 64-bit words, ints, shorts) ----
-  double *dchunk = (double *)smem;                 // local costs of the chunk's window cells
-  double *dprevA = dchunk + p.chunkcap;            // last row of the previous chunk (ping)
+  double *dchunk = (double *)smem;                 // local costs of a chunk's window cells, two buffers
+  double *dprevA = dchunk + 2 * p.chunkcap;        // last row of the previous chunk (ping)
   double *dprevB = dprevA + Ty;                    //                                  (pong)
-  double *xs = dprevB + Ty;                        // staged x rows of the chunk   [kRows][D]
-  double *ys = xs + kRows * D;                     // staged y rows of the chunk   [ycap][D]
-  unsigned long long *rinfo = (unsigned long long *)(ys + (size_t)p.ycap * D);  // per row: lo | hi << 16 | off << 32
+  unsigned long long *rinfo = (unsigned long long *)(dprevB + Ty);  // per row: lo | hi << 16 | off << 32
   int *off = (int *)(rinfo + Tx);                  // cell offset of each row (prefix sum of widths)
   int *lvl_x = off + (Tx + 1);
   int *lvl_y = lvl_x + kMaxLevels;
@@ -246,49 +249,59 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     if (fail) break;
 
     DTW_TICK(1);
-    // ---- 2c. DP over chunks of rows ----
-    int i0 = 0;
-    int prevlo = -1, prevhi = -1;  // the virtual row -1 has the single cell (-1, -1)
-    double *dprev = dprevA, *dnext = dprevB;
-    double last_val = INFINITY;
-    while (i0 < ltx) {
-      const int base = off[i0];
-      const int ylo = (int)lo[i0];
-      const bool wide = ((int)hi[i0] - ylo + 1) > p.ycap;  // a single row wider than the y stage
-      if (w0) {
-        const bool fits = (lane < kRows) && (i0 + lane < ltx) && (off[i0 + lane + 1] - base <= p.chunkcap) &&
-                          (wide || ((int)hi[i0 + lane] - ylo + 1) <= p.ycap);
+    // ---- 2c. chunk table (wavefront 0): chunk c = rows [cstart[c], cstart[c+1]), at most 63 rows and
+    // chunkcap cells; the table lives where the coarse-path scratch was (free until the next level) ----
+    unsigned short *cstart = cfirst;
+    if (w0) {
+      int i0 = 0, nc = 0, bad = 0;
+      while (i0 < ltx) {
+        const int base = off[i0];
+        const bool fits = (lane < kRows) && (i0 + lane < ltx) && (off[i0 + lane + 1] - base <= p.chunkcap);
         const unsigned long long m = __ballot(fits);
-        if (lane == 0) bcast[2] = __ffsll((long long)~m) - 1;  // bit 63 is never set: R <= 63
+        const int R = __ffsll((long long)~m) - 1;  // bit 63 is never set: R <= 63
+        if (R < 1) { bad = 1; break; }
+        if (lane == 0) cstart[nc] = (unsigned short)i0;
+        ++nc;
+        i0 += R;
       }
-      __syncthreads();
-      const int R = bcast[2];
-      if (R < 1) {
-        fail = true;
-        break;
+      if (lane == 0) {
+        cstart[nc] = (unsigned short)ltx;
+        bcast[2] = nc;
+        bcast[3] = bad;
       }
+    }
+    __syncthreads();
+    if (bcast[3]) fail = true;
+    if (fail) break;
+    const int nchunk = bcast[2];
+
+    // local costs of every window cell of chunk c into dst, by threads [t0, t0 + nthr)
+    auto chunk_costs = [&](int c, double *dst, int t0, int nthr) {
+      const int i0 = (int)cstart[c], R = (int)cstart[c + 1] - i0, base = off[i0];
       const int ncell = off[i0 + R] - base;
-      const int yhi = (int)hi[i0 + R - 1];
-      // stage the chunk's x rows (and y rows unless `wide`): contiguous coalesced copies
-      for (int e = tid; e < R * D; e += kThreads) xs[e] = xk[(size_t)i0 * D + e];
-      if (!wide)
-        for (int e = tid; e < (yhi - ylo + 1) * D; e += kThreads) ys[e] = yk[(size_t)ylo * D + e];
-      __syncthreads();
-      DTW_TICK(2);
-      // local costs of every window cell of the chunk
-      for (int c = tid; c < ncell; c += kThreads) {
+      for (int cc = tid - t0; cc < ncell; cc += nthr) {
         int a = 0, b = R;
         while (b - a > 1) {
           const int mid = (a + b) >> 1;
-          if (off[i0 + mid] - base <= c) a = mid; else b = mid;
+          if (off[i0 + mid] - base <= cc) a = mid; else b = mid;
         }
         const int row = i0 + a;
-        const int j = (int)lo[row] + c - (off[row] - base);
-        dchunk[c] = wide ? l2_cost(xs + a * D, yk + (size_t)j * D, D) : l2_cost(xs + a * D, ys + (j - ylo) * D, D);
+        const int j = (int)lo[row] + cc - (off[row] - base);
+        dst[cc] = l2_cost(xk + (size_t)row * D, yk + (size_t)j * D, D);
       }
-      __syncthreads();
-      DTW_TICK(3);
+    };
+    chunk_costs(0, dchunk, 0, kThreads);
+    __syncthreads();
+    DTW_TICK(3);
 
+    // ---- 2d. DP: wavefront 0 sweeps chunk c while wavefronts 1..3 prepare the costs of chunk c+1 ----
+    int prevlo = -1, prevhi = -1;  // the virtual row -1 has the single cell (-1, -1)
+    double *dprev = dprevA, *dnext = dprevB;
+    double last_val = INFINITY;
+    for (int c = 0; c < nchunk; ++c) {
+      const int i0 = (int)cstart[c], R = (int)cstart[c + 1] - i0, base = off[i0];
+      const double *dcur = dchunk + (c & 1) * p.chunkcap;
+      if (!w0 && c + 1 < nchunk) chunk_costs(c + 1, dchunk + ((c + 1) & 1) * p.chunkcap, 64, kThreads - 64);
       // anti-diagonal sweep (wavefront 0): lane r >= 1 owns row i0 + r - 1, lane 0 feeds the row above;
       // at step s every lane handles column s - lane of its row
       if (w0) {
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       const bool real = lane >= 1 && lane <= R;
       const int i = i0 + lane - 1;
       int mylo = 0, width = 0, bbase = bp_dummy;
-      const double *src = dchunk;
+      const double *src = dcur;
       if (feeder) {
         mylo = prevlo;
         width = prevhi - prevlo + 1;
@@ -304,19 +317,17 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       } else if (real) {
         mylo = (int)lo[i];
         width = (int)hi[i] - mylo + 1;
-        src = dchunk + (off[i] - base);
+        src = dcur + (off[i] - base);
         bbase = off[i];
       }
       const bool is_last = lane == R;  // hands its row to the next chunk
-      const int s0 = (int)lo[i0] - 1;  // two steps of lead-in: the feeder emits columns lo-1 and lo first
-      const int s1 = (int)hi[i0 + R - 1] + R;
+      // two steps of lead-in: the feeder emits columns lo-1 and lo first
+      const int s0 = __builtin_amdgcn_readfirstlane((int)lo[i0]) - 1;
+      const int s1 = __builtin_amdgcn_readfirstlane((int)hi[i0 + R - 1]) + R;
       const int wmax = width > 0 ? width - 1 : 0;
       // The only loop-carried chain is add -> compare -> select -> DPP; the local cost is fetched TWO
       // steps ahead so that no step waits on an LDS round trip.
-      auto fetch = [&](int c) {
-        c = c < 0 ? 0 : (c > wmax ? wmax : c);
-        return src[c];
-      };
+      auto fetch = [&](int c) { return src[clamp_idx(c, wmax)]; };
       int cpos = s0 - lane - mylo;  // column of this step relative to the row's window
       double dt_a = fetch(cpos), dt_b = fetch(cpos + 1);
       double pub = INFINITY;     // this lane's D at the column of the previous step (INF outside the window)
@@ -326,14 +337,15 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         const double dt = dt_a;
         dt_a = dt_b;
         dt_b = fetch(cpos + 2);
-        const double up = wave_shr1(pub);
+        // row above at this column; the feeder receives +0.0, which makes it replay its stored row:
+        // cu = 0 + dt = dt exactly, and neither left + dt nor up_old + dt (>= dt, D >= 0) is smaller
+        const double up = wave_shr1z(pub);
         const bool inwin = (unsigned)cpos < (unsigned)width;
         const double cu = __dadd_rn(up, dt), cl = __dadd_rn(left, dt), cd = __dadd_rn(up_old, dt);
         double best = cu;
         unsigned code = 0u;
         if (cl < best) { best = cl; code = 1u; }
         if (cd < best) { best = cd; code = 2u; }
-        best = feeder ? dt : best;  // the feeder replays stored D values
         if (inwin) {
           left = best;
           bp[bbase + cpos] = (unsigned char)code;
@@ -352,9 +364,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       dnext = tsw;
       __syncthreads();
       DTW_TICK(4);
-      i0 += R;
     }
-    if (fail) break;
     level_cost = (prevhi == lty - 1) ? last_val : INFINITY;
 
     // ---- 3. back-trace ----
@@ -363,6 +373,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     // (-2 if the walk leaves the window) and the number of cells visited.
     auto walk = [&](int bi, int bj, int top, int wpos, bool write, int *ncells) {
       unsigned long long ri = rinfo[bi];
+      unsigned long long rnext = bi > 0 ? rinfo[bi - 1] : 0ull;  // the row above is fetched one row ahead
       int rl = (int)(ri & 0xffffu), ro = (int)(ri >> 32);
       int cnt = 0;
       while (true) {
@@ -381,7 +392,8 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         if (code == 2u) bj -= 1;
         bi -= 1;
         if (bi < top) break;
-        ri = rinfo[bi];
+        ri = rnext;
+        rnext = bi > 0 ? rinfo[bi - 1] : 0ull;
         rl = (int)(ri & 0xffffu);
         ro = (int)(ri >> 32);
         if (bj < rl || bj > (int)((ri >> 16) & 0xffffu)) { bj = -2; break; }
@@ -526,7 +538,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
 
 size_t lds_bytes(int Tx, int Ty, int D, const DtwParams &p) {
   size_t b = 0;
-  b += sizeof(double) * ((size_t)p.chunkcap + 2 * (size_t)Ty + (size_t)kRows * D + (size_t)p.ycap * D);
+  b += sizeof(double) * (2 * (size_t)p.chunkcap + 2 * (size_t)Ty);
   b += sizeof(unsigned long long) * (size_t)Tx;
   b += sizeof(int) * ((size_t)(Tx + 1) + 2 * kMaxLevels + 8 + 3 * (size_t)(Tx / kSeg + 3));
   b += sizeof(unsigned short) * ((size_t)2 * Tx + 2 * (Tx / 2 + 2) + 2 * (size_t)(Tx + Ty));
@@ -555,9 +567,6 @@ int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, 
   if (full < cc) cc = full + 64;
   p.cellcap = (int)cc;
   p.chunkcap = Ty > 1024 ? Ty : 1024;
-  // y rows staged per chunk: 64 rows of x at unit slope span ~64 + window width rows of y
-  p.ycap = 128;
-  while (p.ycap > 16 && lds_bytes(Tx, Ty, D, p) > 150 * 1024) p.ycap /= 2;
   const size_t lds = lds_bytes(Tx, Ty, D, p);
   if (lds > 160 * 1024) {
     set_error("fastdtw: Tx=%d, Ty=%d, D=%d, radius=%d needs %zu bytes of LDS (> 160 KiB)", Tx, Ty, D, radius, lds);
