@@ -24,12 +24,13 @@
 //           instruction stream, so the first row of a chunk needs no special
 //           case;
 //        c. one back-pointer byte per window cell in LDS;
-//   3. back-trace, parallel over SEGMENTS of 32 rows: every (segment, entry
-//      column of its bottom row) pair is traced by its own thread up to the
-//      segment's top (exit column + cell count); one thread stitches the
-//      segments from the bottom-right corner upwards; one thread per segment
-//      re-traces its actual piece and writes it at its final position.  ~100
-//      dependent steps per level instead of tx + ty.  (Windows too wide for the
+//   3. back-trace, parallel over SEGMENTS of 16 rows: every (segment, entry
+//      column of its bottom row) candidate is traced by its own thread up to
+//      the segment's top (which candidate of the segment above it reaches +
+//      cell count); the candidates actually on the path are found by pointer
+//      doubling over those links; one thread per segment re-traces its piece
+//      and writes it at its final position.  ~100 dependent steps per level
+//      instead of tx + ty.  (Windows too wide for the
 //      candidate table fall back to a sequential wave-uniform walk.)  The new
 //      path stays in LDS for the next level.
 // Everything except the pyramid lives in LDS.
@@ -69,7 +70,7 @@ struct DtwParams {
 
 constexpr int kMaxLevels = 20;
 constexpr int kRows = 63;  // rows per chunk: lanes 1..63 of the sweeping wavefront (lane 0 feeds the row above)
-constexpr int kSeg = 32;    // rows per back-trace segment
+constexpr int kSeg = 16;    // rows per back-trace segment
 constexpr int kThreads = 256;  // 4 wavefronts per pair: all of them stage/halve/compute local costs, wavefront 0 sweeps
 
 __device__ __forceinline__ double l2_cost(const double *__restrict__ a, const double *__restrict__ b, int D) {
@@ -117,8 +118,8 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
   // ---- LDS carve (doubles / 64-bit words, ints, shorts) ----
   double *dchunk = (double *)smem;                 // local costs of a chunk's window cells, two buffers
   double *dprevA = dchunk + 2 * p.chunkcap;        // last row of the previous chunk (ping)
-  double *dprevB = dprevA + Ty;                    //                                  (pong)
-  unsigned long long *rinfo = (unsigned long long *)(dprevB + Ty);  // per row: lo | hi << 16 | off << 32
+  double *dprevB = dprevA + Ty + 64;               //                                  (pong); + 64 dummy slots each
+  unsigned long long *rinfo = (unsigned long long *)(dprevB + Ty + 64);  // per row: lo | hi << 16 | off << 32
   int *off = (int *)(rinfo + Tx);                  // cell offset of each row (prefix sum of widths)
   int *lvl_x = off + (Tx + 1);
   int *lvl_y = lvl_x + kMaxLevels;
@@ -170,21 +171,22 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     }
   }
   __syncthreads();
-  for (int side = 0; side < 2; ++side) {
-    const double *src = side ? y0 : x0;
-    double *base = side ? py : px;
-    const int *lvl = side ? lvl_y : lvl_x;
-    const int len0 = side ? ty : tx;
+  {
+    const double *srcx = x0, *srcy = y0;  // both series advance one level per round
     for (int k = 1; k <= K; ++k) {
-      double *dst = base + lvl[k];
-      const int cnt = (len0 >> k) * D;
-      for (int e = tid; e < cnt; e += kThreads) {
-        const int row = e / D, c = e - row * D;
-        dst[e] = __dadd_rn(src[(size_t)(2 * row) * D + c], src[(size_t)(2 * row + 1) * D + c]) * 0.5;
+      double *dstx = px + lvl_x[k], *dsty = py + lvl_y[k];
+      const int cntx = (tx >> k) * D, cnty = (ty >> k) * D;
+      for (int e = tid; e < cntx + cnty; e += kThreads) {
+        const bool isx = e < cntx;
+        const int ee = isx ? e : e - cntx;
+        const double *src = isx ? srcx : srcy;
+        const int row = ee / D, c = ee - row * D;
+        (isx ? dstx : dsty)[ee] = __dadd_rn(src[(size_t)(2 * row) * D + c], src[(size_t)(2 * row + 1) * D + c]) * 0.5;
       }
       __threadfence_block();
       __syncthreads();
-      src = dst;
+      srcx = dstx;
+      srcy = dsty;
     }
   }
 
@@ -256,7 +258,9 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       int i0 = 0, nc = 0, bad = 0;
       while (i0 < ltx) {
         const int base = off[i0];
-        const bool fits = (lane < kRows) && (i0 + lane < ltx) && (off[i0 + lane + 1] - base <= p.chunkcap);
+        // short first chunks: the pipeline (costs of chunk c+1 behind the sweep of chunk c) starts sooner
+        const int rowcap = nc == 0 ? 8 : (nc == 1 ? 24 : kRows);
+        const bool fits = (lane < rowcap) && (i0 + lane < ltx) && (off[i0 + lane + 1] - base <= p.chunkcap);
         const unsigned long long m = __ballot(fits);
         const int R = __ffsll((long long)~m) - 1;  // bit 63 is never set: R <= 63
         if (R < 1) { bad = 1; break; }
@@ -328,13 +332,21 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       // The only loop-carried chain is add -> compare -> select -> DPP; the local cost is fetched TWO
       // steps ahead so that no step waits on an LDS round trip.
       auto fetch = [&](int c) { return src[clamp_idx(c, wmax)]; };
+      const int dummy_b = bp_dummy + Ty + lane;  // dummy back-pointer byte of this lane
+      double *dnext_all = dnext;                 // dnext[Ty + lane] is this lane's dummy slot
+      const int dummy_d = Ty + lane;
       int cpos = s0 - lane - mylo;  // column of this step relative to the row's window
       double dt_a = fetch(cpos), dt_b = fetch(cpos + 1);
       double pub = INFINITY;     // this lane's D at the column of the previous step (INF outside the window)
       double up_old = INFINITY;  // row above at the previous column
       double left = INFINITY;    // this row at the previous column (stays INF until the window starts)
+      int st_b = dummy_b, st_d = dummy_d;
+      unsigned st_code = 0u;
+      double st_best = 0.0;
       for (int s = s0; s <= s1; ++s, ++cpos) {
         const double dt = dt_a;
+        bp[st_b] = (unsigned char)st_code;  // stores of the previous step
+        dnext_all[st_d] = st_best;
         dt_a = dt_b;
         dt_b = fetch(cpos + 2);
         // row above at this column; the feeder receives +0.0, which makes it replay its stored row:
@@ -346,14 +358,20 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         unsigned code = 0u;
         if (cl < best) { best = cl; code = 1u; }
         if (cd < best) { best = cd; code = 2u; }
-        if (inwin) {
-          left = best;
-          bp[bbase + cpos] = (unsigned char)code;
-          if (is_last) dnext[cpos] = best;
-        }
+        // No branches and a fixed number of LDS operations per step (so that the prefetch above is the
+        // only thing a step ever waits for): stores outside the window go to per-lane dummy slots.
+        // The stores of a step are issued at the top of the NEXT step, right after the wait for the
+        // prefetched cost, so that the in-order LDS counter never makes a step wait for its own stores.
+        left = inwin ? best : left;
         pub = inwin ? best : INFINITY;
+        st_b = inwin ? bbase + cpos : dummy_b;
+        st_code = code;
+        st_d = (inwin && is_last) ? cpos : dummy_d;
+        st_best = best;
         up_old = up;
       }
+      bp[st_b] = (unsigned char)st_code;
+      dnext_all[st_d] = st_best;
       // value of the chunk's last cell (bottom-right corner of the level if this is the last chunk)
       last_val = __shfl(left, R);
       }  // w0
@@ -402,8 +420,6 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       return bj;
     };
     const int G = (ltx + kSeg - 1) / kSeg;  // segment g = rows [g*kSeg, min((g+1)*kSeg, ltx))
-    unsigned short *exitcol = (unsigned short *)dchunk;  // exit column + 2 (the DP's cost buffer is idle now)
-    unsigned short *cnts = (unsigned short *)(exitcol + 2 * p.chunkcap);
     if (w0) {  // candidate-table offsets: one entry per cell of every segment's bottom row
       const int gpl = (G + 63) / 64;
       const int g0 = lane * gpl < G ? lane * gpl : G;
@@ -424,8 +440,16 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     }
     __syncthreads();
     const int ntask = segoff[G];
-    if (ntask <= 2 * p.chunkcap && G < segcap) {
-      // pass 1: every (segment, entry column) candidate
+    // candidate tables in the (now idle) cost buffers: cnts, then `nlev` hop tables of ntask entries
+    // each; hop table k maps a candidate to the candidate reached 2^k segments further up
+    int nlev = 1;
+    while ((1 << nlev) < G) ++nlev;
+    unsigned short *cnts = (unsigned short *)dchunk;
+    unsigned short *hop = cnts + ntask;
+    constexpr unsigned kInvalid = 0xffffu, kTerminal = 0xfffeu;
+    if ((size_t)ntask * (size_t)(nlev + 1) * sizeof(unsigned short) <= sizeof(double) * 2 * (size_t)p.chunkcap &&
+        ntask < 0xfff0 && G < segcap) {
+      // pass 1: every (segment, entry column) candidate walks to the top of its segment
       for (int task = tid; task < ntask; task += kThreads) {
         int a = 0, b = G;
         while (b - a > 1) {
@@ -435,33 +459,68 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         const int bot = ((a + 1) * kSeg < ltx ? (a + 1) * kSeg : ltx) - 1;
         int nc;
         const int ex = walk(bot, (int)lo[bot] + (task - segoff[a]), a * kSeg, 0, false, &nc);
-        exitcol[task] = (unsigned short)(ex + 2);
         cnts[task] = (unsigned short)nc;
+        unsigned nx = kInvalid;
+        if (a == 0) {
+          if (ex == -1) nx = kTerminal;
+        } else if (ex >= 0) {
+          const int up = a * kSeg - 1;  // bottom row of the segment above
+          if (ex >= (int)lo[up] && ex <= (int)hi[up]) nx = (unsigned)(segoff[a - 1] + ex - (int)lo[up]);
+        }
+        hop[task] = (unsigned short)nx;
+      }
+      if (tid == 0) bcast[1] = 1;
+      __syncthreads();
+      // hop tables by doubling
+      for (int k = 1; k < nlev; ++k) {
+        const unsigned short *hp = hop + (size_t)(k - 1) * ntask;
+        unsigned short *hn = hop + (size_t)k * ntask;
+        for (int task = tid; task < ntask; task += kThreads) {
+          const unsigned j = hp[task];
+          hn[task] = j >= kTerminal ? (unsigned short)j : hp[j];
+        }
+        __syncthreads();
+      }
+      // the candidate of every segment on the path from the bottom-right corner: segment g is
+      // G-1-g hops above the start
+      {
+        const int last = ltx - 1;
+        const bool start_ok = (level_cost < INFINITY) && lty - 1 >= (int)lo[last] && lty - 1 <= (int)hi[last];
+        for (int g = tid; g < G; g += kThreads) {
+          unsigned t = start_ok ? (unsigned)(segoff[G - 1] + lty - 1 - (int)lo[last]) : kInvalid;
+          const int h = G - 1 - g;
+          for (int k = 0; k < nlev && t < kTerminal; ++k)
+            if ((h >> k) & 1) t = hop[(size_t)k * ntask + t];
+          bool good = t < kTerminal;
+          if (good && g == 0) good = hop[t] == kTerminal;  // the path must end in (-1, -1)
+          if (good) {
+            segent[g] = (int)t - segoff[g];
+            segend[g] = (int)cnts[t];
+          } else {
+            segend[g] = 0;
+            bcast[1] = 0;
+          }
+        }
       }
       __syncthreads();
-      // stitch from the bottom-right corner upwards
-      if (tid == 0) {
-        int ok = (level_cost < INFINITY) ? 1 : 0;
-        int bj = lty - 1, total = 0;
-        for (int g = G - 1; g >= 0 && ok; --g) {
-          const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
-          const int e = bj - (int)lo[bot];
-          if (e < 0 || bj > (int)hi[bot]) { ok = 0; break; }
-          const int task = segoff[g] + e;
-          segent[g] = e;
-          segend[g] = (int)cnts[task];
-          total += (int)cnts[task];
-          bj = (int)exitcol[task] - 2;
-          if (bj == -2) ok = 0;
-        }
-        if (ok && (bj != -1 || total > pcap)) ok = 0;
-        int run = pcap - total;
-        for (int g = 0; g < G && ok; ++g) {
+      // positions: inclusive prefix sum of the per-segment cell counts (wavefront 0)
+      if (w0) {
+        const int gpl = (G + 63) / 64;
+        const int g0 = lane * gpl < G ? lane * gpl : G;
+        const int g1 = g0 + gpl < G ? g0 + gpl : G;
+        int sum = 0;
+        for (int g = g0; g < g1; ++g) sum += segend[g];
+        int total;
+        int run = wave_excl_scan(sum, lane, &total);
+        const int first = pcap - total;
+        for (int g = g0; g < g1; ++g) {
           run += segend[g];
-          segend[g] = run;
+          segend[g] = first + run;
         }
-        bcast[0] = pcap - total;
-        bcast[1] = ok;
+        if (lane == 0) {
+          bcast[0] = first;
+          if (total > pcap) bcast[1] = 0;
+        }
       }
       __syncthreads();
       // pass 2: every segment writes its piece of the path
@@ -538,11 +597,11 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
 
 size_t lds_bytes(int Tx, int Ty, int D, const DtwParams &p) {
   size_t b = 0;
-  b += sizeof(double) * (2 * (size_t)p.chunkcap + 2 * (size_t)Ty);
+  b += sizeof(double) * (2 * (size_t)p.chunkcap + 2 * (size_t)(Ty + 64));
   b += sizeof(unsigned long long) * (size_t)Tx;
   b += sizeof(int) * ((size_t)(Tx + 1) + 2 * kMaxLevels + 8 + 3 * (size_t)(Tx / kSeg + 3));
   b += sizeof(unsigned short) * ((size_t)2 * Tx + 2 * (Tx / 2 + 2) + 2 * (size_t)(Tx + Ty));
-  b += (size_t)p.cellcap + (size_t)Ty + 16;  // back-pointer bytes + the feeder's dummy row
+  b += (size_t)p.cellcap + (size_t)Ty + 64 + 16;  // back-pointer bytes + the feeder's dummy row + per-lane dummy bytes
   return (b + 15) & ~(size_t)15;
 }
 
