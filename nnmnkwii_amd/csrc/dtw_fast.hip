@@ -107,6 +107,43 @@ __device__ __forceinline__ int clamp_idx(int c, int hi) {  // median(c, 0, hi), 
   return r;
 }
 
+// One back-trace walk from cell (bi, bj) up to (excluding) row `top`: follows the back-pointer
+// bytes, WRITE: stores the visited cells at positions wpos-1, wpos-2, ...  Returns the column
+// reached in row top-1 (-2 if the walk leaves the window); *ncells = cells visited.
+template <bool WRITE>
+__device__ __forceinline__ int dtw_walk(const unsigned long long *__restrict__ rinfo, const unsigned char *__restrict__ bp,
+                                        unsigned short *__restrict__ pth_i, unsigned short *__restrict__ pth_j, int bi,
+                                        int bj, int top, int wpos, int *ncells) {
+  unsigned long long ri = rinfo[bi];
+  unsigned long long rnext = bi > 0 ? rinfo[bi - 1] : 0ull;  // the row above is fetched one row ahead
+  int rl = (int)(ri & 0xffffu);
+  const unsigned char *row = bp + (int)(ri >> 32) - rl;      // row[bj] = back-pointer of (bi, bj)
+  int cnt = 0;
+  while (true) {
+    ++cnt;
+    const unsigned code = row[bj];
+    if (WRITE) {
+      --wpos;
+      pth_i[wpos] = (unsigned short)bi;
+      pth_j[wpos] = (unsigned short)bj;
+    }
+    if (code != 0u) bj -= 1;  // left or diagonal
+    if (code == 1u) {         // left: stay in the row
+      if (bj < rl) { bj = -2; break; }
+      continue;
+    }
+    bi -= 1;
+    if (bi < top) break;
+    ri = rnext;
+    rnext = bi > 0 ? rinfo[bi - 1] : 0ull;
+    rl = (int)(ri & 0xffffu);
+    row = bp + (int)(ri >> 32) - rl;
+    if (bj < rl || bj > (int)((ri >> 16) & 0xffffu)) { bj = -2; break; }
+  }
+  *ncells = cnt;
+  return bj;
+}
+
 __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -386,39 +423,6 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     level_cost = (prevhi == lty - 1) ? last_val : INFINITY;
 
     // ---- 3. back-trace ----
-    // One walk from a cell up to (excluding) row `top`: follows the back-pointers, optionally
-    // writing the cells at positions wpos-1, wpos-2, ...; returns the column reached in row top-1
-    // (-2 if the walk leaves the window) and the number of cells visited.
-    auto walk = [&](int bi, int bj, int top, int wpos, bool write, int *ncells) {
-      unsigned long long ri = rinfo[bi];
-      unsigned long long rnext = bi > 0 ? rinfo[bi - 1] : 0ull;  // the row above is fetched one row ahead
-      int rl = (int)(ri & 0xffffu), ro = (int)(ri >> 32);
-      int cnt = 0;
-      while (true) {
-        ++cnt;
-        if (write) {
-          --wpos;
-          pth_i[wpos] = (unsigned short)bi;
-          pth_j[wpos] = (unsigned short)bj;
-        }
-        const unsigned code = bp[ro + bj - rl];
-        if (code == 1u) {  // left: stay in the row
-          bj -= 1;
-          if (bj < rl) { bj = -2; break; }
-          continue;
-        }
-        if (code == 2u) bj -= 1;
-        bi -= 1;
-        if (bi < top) break;
-        ri = rnext;
-        rnext = bi > 0 ? rinfo[bi - 1] : 0ull;
-        rl = (int)(ri & 0xffffu);
-        ro = (int)(ri >> 32);
-        if (bj < rl || bj > (int)((ri >> 16) & 0xffffu)) { bj = -2; break; }
-      }
-      *ncells = cnt;
-      return bj;
-    };
     const int G = (ltx + kSeg - 1) / kSeg;  // segment g = rows [g*kSeg, min((g+1)*kSeg, ltx))
     if (w0) {  // candidate-table offsets: one entry per cell of every segment's bottom row
       const int gpl = (G + 63) / 64;
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         }
         const int bot = ((a + 1) * kSeg < ltx ? (a + 1) * kSeg : ltx) - 1;
         int nc;
-        const int ex = walk(bot, (int)lo[bot] + (task - segoff[a]), a * kSeg, 0, false, &nc);
+        const int ex = dtw_walk<false>(rinfo, bp, pth_i, pth_j, bot, (int)lo[bot] + (task - segoff[a]), a * kSeg, 0, &nc);
         cnts[task] = (unsigned short)nc;
         unsigned nx = kInvalid;
         if (a == 0) {
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         for (int g = tid; g < G; g += kThreads) {
           const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
           int nc;
-          (void)walk(bot, (int)lo[bot] + segent[g], g * kSeg, segend[g], true, &nc);
+          (void)dtw_walk<true>(rinfo, bp, pth_i, pth_j, bot, (int)lo[bot] + segent[g], g * kSeg, segend[g], &nc);
         }
       }
     } else if (w0) {
