@@ -50,6 +50,39 @@ def test_paths_bit_exact_vs_oracle(radius):
         assert abs(cost[n] - d) <= 1e-12 * max(d, 1e-300), (n, sizes[n])
 
 
+@pytest.mark.parametrize("radius,sizes", [
+    (30, [(300, 280), (257, 300), (64, 300)]),       # windows too wide for the candidate tables: sequential back-trace
+    (8, [(500, 9), (9, 500), (12, 13), (700, 650)]),  # one side shorter than radius + 2: full DTW at level 0 / 1
+    (1, [(900, 450), (450, 900), (1000, 1000)]),      # slope 2 windows, 16+ chunks, 63 segments
+])
+def test_paths_bit_exact_wide_and_lopsided(radius, sizes):
+    rng = np.random.RandomState(100 + radius)
+    pairs = [(_tracks(rng, tx, 3), _tracks(rng, ty, 3)) for tx, ty in sizes]
+    pi, pj, pl, cost = _run_pairs(pairs, radius)
+    for n, (x, y) in enumerate(pairs):
+        d, path = OD.fastdtw(x, y, radius)
+        assert pl[n] == len(path), (n, sizes[n])
+        assert np.array_equal(pi[n, :pl[n]], path[:, 0]) and np.array_equal(pj[n, :pl[n]], path[:, 1]), (n, sizes[n])
+        assert abs(cost[n] - d) <= 1e-12 * max(d, 1e-300)
+
+
+def test_paths_bit_exact_on_tie_heavy_data():
+    """Quantised tracks: many exactly equal candidate costs; the kernel must break ties like the oracle
+    (compare after the add, first minimum of up / left / diagonal)."""
+    rng = np.random.RandomState(77)
+    pairs = []
+    for tx, ty in [(60, 60), (130, 97), (200, 230), (64, 64)]:
+        pairs.append((np.round(_tracks(rng, tx, 2) * 4) / 4, np.round(_tracks(rng, ty, 2) * 4) / 4))
+    pairs.append((np.zeros((50, 2)) + 1.0, np.zeros((70, 2)) + 1.0))     # all costs zero
+    for radius in (1, 2):
+        pi, pj, pl, cost = _run_pairs(pairs, radius)
+        for n, (x, y) in enumerate(pairs):
+            d, path = OD.fastdtw(x, y, radius)
+            assert pl[n] == len(path), (radius, n)
+            assert np.array_equal(pi[n, :pl[n]], path[:, 0]) and np.array_equal(pj[n, :pl[n]], path[:, 1]), (radius, n)
+            assert cost[n] == d
+
+
 def test_baseline_config4_shape():
     """BASELINE configs[3] shape at reduced batch: T in [700, 900], 25-dim, radius 1."""
     rng = np.random.RandomState(1234)
