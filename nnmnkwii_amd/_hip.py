@@ -12,6 +12,7 @@ import threading
 import numpy as np
 
 F32, F64 = 0, 1
+ABI_VERSION = 2               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE = 0, 1, 2
 
@@ -81,6 +82,9 @@ def lib():
         L.mlpg_hip_fastdtw_l2.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
         L.mlpg_hip_gather_path.restype = ci
         L.mlpg_hip_gather_path.argtypes = [ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+        if L.mlpg_hip_abi_version() != ABI_VERSION:
+            raise HipExtensionError("nnmnkwii_amd: %s has ABI version %d, this binding needs %d -- rebuild it with "
+                                    "`python nnmnkwii_amd/csrc/build.py`" % (SO_PATH, L.mlpg_hip_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 
