@@ -575,7 +575,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
 
   // ---- 2-4. solve ----
 #if MLPG_WAVE_ABLATE != 1 && MLPG_WAVE_ABLATE != 4
-  constexpr bool kPark = (M >= 16) && MINW >= 2 && MLPG_WAVE_PARK;
+  constexpr bool kPark = (M >= 16) && MLPG_WAVE_PARK;
   // parking rows live in the (now idle) tiles, register layout footprint
   const bool bad = solve_chunk<M, kPark>(Pd, P1, P2, rhs, lane, (double *)tileA + wv * RL::TPAD + lane * (M + kSkew),
                                          (double *)tileB + wv * RL::TPAD + lane * (M + kSkew));
