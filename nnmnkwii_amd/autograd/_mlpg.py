@@ -98,10 +98,12 @@ def _identify_R(R):
 class UnitVarianceMLPG(Function):
     """MLPG for unit-variance inputs, ``y = R mu`` (autograd/_impl/mlpg.py:70-172).
 
-    ``R`` must come from :func:`nnmnkwii_amd.paramgen.unit_variance_mlpg_matrix`;
-    it is recognised by content, and the product ``R mu`` (and ``R^T g`` in the
-    backward) is then evaluated by the banded unit-variance kernels -- O(T) per
-    column and no dense ``(T, nw*T)`` traffic.  Accepts ``(T, D)``,
+    An ``R`` that comes from :func:`nnmnkwii_amd.paramgen.unit_variance_mlpg_matrix` is
+    recognised by content, and the product ``R mu`` (and ``R^T g`` in the backward) is
+    then evaluated by the banded unit-variance kernels -- O(T) per column and no dense
+    ``(T, nw*T)`` traffic.  Any other ``R`` (hand-made or modified) is just a matrix: it is
+    multiplied densely on the GPU (one rocBLAS batched GEMM through ``torch.einsum``), which
+    is what the reference does on the CPU (:138, :158).  Accepts ``(T, D)``,
     ``(T*nw, static_dim)``, ``(B, T, D)`` and ``(B, T*nw, static_dim)`` means.
     """
 
@@ -111,12 +113,8 @@ class UnitVarianceMLPG(Function):
         ctx.num_windows = R.shape[-1] // R.shape[0]
         T = R.shape[0]
         ident = _identify_R(R)
-        if ident is None:
-            raise _hip.HipExtensionError(
-                "unit_variance_mlpg: R was not produced by nnmnkwii_amd.paramgen.unit_variance_mlpg_matrix "
-                "(or was modified); the banded MI355X kernels need the window set it was built from")
-        windows, _ = ident
-        ctx.windows = windows
+        ctx.windows = ident[0] if ident is not None else None
+        windows = ctx.windows
         nw = ctx.num_windows
         dim = means.dim()
         if dim == 2:
@@ -131,12 +129,19 @@ class UnitVarianceMLPG(Function):
         m3 = _to_gpu(m3, dev)
         if m3.dtype not in (torch.float32, torch.float64):
             m3 = m3.to(torch.float32)
+        static_dim = D if reshaped else D // nw
+        if windows is None:
+            # foreign R: out[b, t, d] = sum_{w, s} R[t, w*T + s] mu_w[b, s, d]
+            R3 = _to_gpu(R, dev).to(m3.dtype).view(T, nw, T)
+            if reshaped:
+                out = torch.einsum("tws,bwsd->btd", R3, m3.view(B, nw, T, static_dim))
+            else:
+                out = torch.einsum("tws,bswd->btd", R3, m3.view(B, T, nw, static_dim))
+            out = out.to(device=means.device, dtype=means.dtype)
+            return out.reshape(-1, static_dim) if dim == 2 else out
         if reshaped:
             # (B, nw*T, sd) -> frame-major (B, T, nw*sd), the layout the kernels read
-            static_dim = D
             m3 = m3.view(B, nw, T, static_dim).transpose(1, 2).contiguous().view(B, T, nw * static_dim)
-        else:
-            static_dim = D // nw
         out, _ = _hip.forward(m3, None, windows, want_status=False)
         out = out.to(device=means.device, dtype=means.dtype)
         if dim == 2:
@@ -161,6 +166,15 @@ class UnitVarianceMLPG(Function):
         if go.dtype not in (torch.float32, torch.float64):
             go = go.to(torch.float32)
         sd = go.shape[-1]
+        if ctx.windows is None:
+            # foreign R: grad_w[b, s, d] = sum_t R[t, w*T + s] g[b, t, d]
+            R3 = _to_gpu(R, dev).to(go.dtype).view(T, nw, T)
+            if reshaped:
+                grad = torch.einsum("tws,btd->bwsd", R3, go).reshape(B, nw * T, sd)
+            else:
+                grad = torch.einsum("tws,btd->bswd", R3, go).reshape(B, T, nw * sd)
+            grad = grad.to(device=means.device, dtype=means.dtype)
+            return (grad.reshape(-1, D), None) if dim == 2 else (grad, None)
         grad, _ = _hip.backward(None, go, ctx.windows, nw * sd, out_dtype=go.dtype, want_status=False)
         if reshaped:
             grad = grad.view(B, T, nw, sd).transpose(1, 2).contiguous().view(B, nw * T, sd)

@@ -114,9 +114,34 @@ def test_batched_unit_variance():
         assert torch.allclose(mb.grad, means.grad[b], atol=1e-6)
 
 
-def test_foreign_R_rejected_loudly():
-    from nnmnkwii_amd import HipExtensionError
+def test_foreign_R_is_multiplied_densely():
+    """An R that did not come from unit_variance_mlpg_matrix (here: random, and a modified genuine one) is
+    just a matrix: y = R @ reshape(means), grads = R^T @ g, exactly the reference's dense definition
+    (autograd/_impl/mlpg.py:138,158), for all four input layouts."""
     from nnmnkwii_amd import autograd as AF
-    R = torch.rand(5, 15, device="cuda")
-    with pytest.raises(HipExtensionError):
-        AF.unit_variance_mlpg(R, torch.rand(5, 6, device="cuda"))
+    from nnmnkwii_amd import paramgen as G
+    torch.manual_seed(3)
+    T, nw, sd, B = 7, 3, 2, 2
+    WINDOWS = WINDOW_SETS["std3"]
+    Rg = torch.from_numpy(G.unit_variance_mlpg_matrix(WINDOWS, T)).cuda()
+    for R in (torch.rand(T, nw * T, device="cuda"), Rg * 1.5):
+        for batched in (False, True):
+            for reshaped in (False, True):
+                shape = ((B,) if batched else ()) + ((nw * T, sd) if reshaped else (T, nw * sd))
+                means = torch.rand(*shape, device="cuda", requires_grad=True)
+                y = AF.unit_variance_mlpg(R, means)
+                m3 = means.detach().reshape((B if batched else 1,) + shape[-2:])
+                rm = m3 if reshaped else m3.view(-1, T, nw, sd).transpose(1, 2).reshape(-1, nw * T, sd)
+                ref = torch.matmul(R, rm)
+                assert y.shape == ((B, T, sd) if batched else (T, sd))
+                assert torch.allclose(y.reshape(ref.shape), ref, atol=1e-5)
+                g = torch.rand_like(y)
+                y.backward(g)
+                gr = torch.matmul(R.t(), g.reshape(ref.shape))                   # (b, nw*T, sd)
+                if not reshaped:
+                    gr = gr.view(-1, nw, T, sd).transpose(1, 2).reshape(-1, T, nw * sd)
+                assert torch.allclose(means.grad.reshape(gr.shape), gr, atol=1e-5)
+    # the genuine matrix still takes the banded kernels and agrees with its own dense product
+    means = torch.rand(B, T, nw * sd, device="cuda")
+    dense = torch.matmul(Rg, means.view(B, T, nw, sd).transpose(1, 2).reshape(B, nw * T, sd))
+    assert torch.allclose(AF.unit_variance_mlpg(Rg, means), dense, atol=1e-5)
