@@ -162,6 +162,36 @@ int mlpg_hip_delta_features(int device, void *stream, int dtype, const void *x,
                             void *out);
 
 /*
+ * Modulation spectrum of parameter trajectories (the step
+ * after MLPG).  Replace preprocessing/modspec.py: modspec (:6-53: power of the
+ * rfft along time), inv_modspec (:62-100: irfft of sqrt(ms) * phase),
+ * modspec_smoothing (:103-167: remove the modulation-frequency bins >= limit_bin
+ * -- in the log domain the removed log-power is set to 0, i.e. unit magnitude
+ * with the original phase -- and transform back), and the gradient of the
+ * power spectrum of autograd/_impl/modspec.py:30-60 (a Python loop over feature
+ * dimensions with dense (n/2+1, T) cos/sin tables).
+ * One workgroup per (utterance, feature column); the n-point FFT (n a power of
+ * two <= 4096) lives in LDS.  All arrays float64, row-major; `ortho` selects
+ * numpy's norm="ortho".
+ *   x     : (B, T, D), T <= n, zero-padded to n internally
+ *   ms    : (B, n/2+1, D)            phase : (B, n/2+1, D, 2) (re, im), may be NULL
+ *   inv_modspec output (B, n, D); smoothing / backward output (B, T, D)
+ *   backward: grad_x[t] = C * sum_k grad_ms[k] (Re S_k cos(2 pi k t/n) - Im S_k sin(2 pi k t/n)),
+ *             C = 2 (2/sqrt(n) for ortho), as modspec.py's analytic gradient.
+ */
+int mlpg_hip_modspec(int device, void *stream, const double *x, int B, int T,
+                     int D, int n, int ortho, double *ms, double *phase);
+int mlpg_hip_inv_modspec(int device, void *stream, const double *ms,
+                         const double *phase, int B, int n, int D, int ortho,
+                         double *x);
+int mlpg_hip_modspec_smoothing(int device, void *stream, const double *x,
+                               int B, int T, int D, int n, int ortho,
+                               int limit_bin, int log_domain, double *out);
+int mlpg_hip_modspec_backward(int device, void *stream, const double *x,
+                              const double *grad_ms, int B, int T, int D,
+                              int n, int ortho, double *grad_x);
+
+/*
  * Trailing-zero trim.  Replaces preprocessing.trim_zeros_frames with trim="b"
  * (preprocessing/generic.py:291-332) applied to every utterance of a padded
  * (N, T, D) batch: lengths[n] = number of frames left after dropping trailing

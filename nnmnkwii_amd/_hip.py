@@ -12,7 +12,7 @@ import threading
 import numpy as np
 
 F32, F64 = 0, 1
-ABI_VERSION = 2               # mlpg_hip_abi_version() of the library this binding was written for
+ABI_VERSION = 3               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE = 0, 1, 2
 
@@ -28,6 +28,10 @@ EXPORTS = (
     "mlpg_hip_forward_streams",
     "mlpg_hip_backward",
     "mlpg_hip_delta_features",
+    "mlpg_hip_modspec",
+    "mlpg_hip_inv_modspec",
+    "mlpg_hip_modspec_smoothing",
+    "mlpg_hip_modspec_backward",
     "mlpg_hip_trim_lengths",
     "mlpg_hip_fastdtw_l2",
     "mlpg_hip_gather_path",
@@ -76,6 +80,14 @@ def lib():
         L.mlpg_hip_backward.argtypes = [ci, vp, ci, ci, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
         L.mlpg_hip_delta_features.restype = ci
         L.mlpg_hip_delta_features.argtypes = [ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp]
+        L.mlpg_hip_modspec.restype = ci
+        L.mlpg_hip_modspec.argtypes = [ci, vp, vp, ci, ci, ci, ci, ci, vp, vp]
+        L.mlpg_hip_inv_modspec.restype = ci
+        L.mlpg_hip_inv_modspec.argtypes = [ci, vp, vp, vp, ci, ci, ci, ci, vp]
+        L.mlpg_hip_modspec_smoothing.restype = ci
+        L.mlpg_hip_modspec_smoothing.argtypes = [ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.mlpg_hip_modspec_backward.restype = ci
+        L.mlpg_hip_modspec_backward.argtypes = [ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
         L.mlpg_hip_trim_lengths.restype = ci
         L.mlpg_hip_trim_lengths.argtypes = [ci, vp, ci, vp, ci, ci, ci, cd, vp]
         L.mlpg_hip_fastdtw_l2.restype = ci
@@ -283,6 +295,62 @@ def delta_features(x, windows, lengths=None):
     rc = lib().mlpg_hip_delta_features(x.device.index, _stream(x.device), _dt(x), _p(x), _p(lengths), B, T, D, nw,
                                        _np(wl), _np(wu), _np(wc), _p(out))
     _check(rc, "mlpg_hip_delta_features")
+    return out
+
+
+def _f64_3d(x):
+    torch = torch_mod()
+    assert x.is_cuda and x.dim() == 3
+    return x.to(torch.float64).contiguous()
+
+
+def modspec(x, n, ortho=False, want_phase=False):
+    """Power of the n-point DFT along time of a (B, T, D) CUDA batch: (ms (B, n/2+1, D), phase (B, n/2+1, D, 2) | None)."""
+    torch = torch_mod()
+    x = _f64_3d(x)
+    B, T, D = x.shape
+    ms = torch.empty((B, n // 2 + 1, D), dtype=torch.float64, device=x.device)
+    ph = torch.empty((B, n // 2 + 1, D, 2), dtype=torch.float64, device=x.device) if want_phase else None
+    _check(lib().mlpg_hip_modspec(x.device.index, _stream(x.device), _p(x), B, T, D, int(n), int(bool(ortho)), _p(ms), _p(ph)),
+           "mlpg_hip_modspec")
+    return ms, ph
+
+
+def inv_modspec(ms, phase, ortho=False):
+    """irfft of sqrt(ms) * phase: ms (B, nb, D), phase (B, nb, D, 2) float64 CUDA -> (B, 2*(nb-1), D)."""
+    torch = torch_mod()
+    ms = _f64_3d(ms)
+    phase = phase.to(torch.float64).contiguous()
+    B, nb, D = ms.shape
+    assert phase.shape == (B, nb, D, 2)
+    n = 2 * (nb - 1)
+    out = torch.empty((B, n, D), dtype=torch.float64, device=ms.device)
+    _check(lib().mlpg_hip_inv_modspec(ms.device.index, _stream(ms.device), _p(ms), _p(phase), B, n, D, int(bool(ortho)), _p(out)),
+           "mlpg_hip_inv_modspec")
+    return out
+
+
+def modspec_smoothing(x, n, limit_bin, log_domain=True, ortho=False):
+    """Remove the modulation bins >= limit_bin of every column of a (B, T, D) CUDA batch; returns (B, T, D) float64."""
+    torch = torch_mod()
+    x = _f64_3d(x)
+    B, T, D = x.shape
+    out = torch.empty((B, T, D), dtype=torch.float64, device=x.device)
+    _check(lib().mlpg_hip_modspec_smoothing(x.device.index, _stream(x.device), _p(x), B, T, D, int(n), int(bool(ortho)),
+                                            int(limit_bin), int(bool(log_domain)), _p(out)), "mlpg_hip_modspec_smoothing")
+    return out
+
+
+def modspec_backward(x, grad_ms, n, ortho=False):
+    """Gradient of the power spectrum w.r.t. the trajectory: x (B, T, D), grad_ms (B, n/2+1, D) -> (B, T, D)."""
+    torch = torch_mod()
+    x = _f64_3d(x)
+    g = _f64_3d(grad_ms)
+    B, T, D = x.shape
+    assert g.shape == (B, n // 2 + 1, D)
+    out = torch.empty((B, T, D), dtype=torch.float64, device=x.device)
+    _check(lib().mlpg_hip_modspec_backward(x.device.index, _stream(x.device), _p(x), _p(g), B, T, D, int(n), int(bool(ortho)),
+                                           _p(out)), "mlpg_hip_modspec_backward")
     return out
 
 

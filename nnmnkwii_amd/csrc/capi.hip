@@ -216,7 +216,7 @@ using namespace mlpg;
 
 extern "C" {
 
-__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 2; }
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 3; }
 
 __attribute__((visibility("default"))) const char *mlpg_hip_last_error(void) { return g_err; }
 
@@ -355,6 +355,58 @@ __attribute__((visibility("default"))) int mlpg_hip_delta_features(int device, v
     return MLPG_HIP_ERUNTIME;
   }
   return launch_delta((hipStream_t)stream, dtype, x, lengths, B, Tmax, D, ws, out);
+}
+
+namespace {
+int modspec_entry(int device, void *stream, int mode, const double *x, const double *ms, const double *ph, double *out,
+                  double *out_ph, int B, int T, int D, int n, int ortho, int limit_bin, int log_domain) {
+  if (B < 0 || T < 0 || D < 0 || n < 1) {
+    set_error("modspec: negative size");
+    return MLPG_HIP_EINVAL;
+  }
+  if (n < 2 || n > 4096 || (n & (n - 1))) {
+    set_error("modspec: the DFT length must be a power of two in [2, 4096] (got %d)", n);
+    return MLPG_HIP_EINVAL;
+  }
+  if (T > n) {
+    set_error("modspec: DFT length %d must not be smaller than the time length %d", n, T);
+    return MLPG_HIP_EINVAL;
+  }
+  if ((long)B * D == 0) return 0;
+  if (!out || (mode == 1 ? (!ms || !ph) : !x) || (mode == 3 && !ms)) {
+    set_error("modspec: NULL pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  return launch_modspec((hipStream_t)stream, mode, x, ms, ph, out, out_ph, B, T, D, n, ortho, limit_bin, log_domain);
+}
+}  // namespace
+
+__attribute__((visibility("default"))) int mlpg_hip_modspec(int device, void *stream, const double *x, int B, int T,
+                                                            int D, int n, int ortho, double *ms, double *phase) {
+  return modspec_entry(device, stream, 0, x, nullptr, nullptr, ms, phase, B, T, D, n, ortho, 0, 0);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_inv_modspec(int device, void *stream, const double *ms,
+                                                                const double *phase, int B, int n, int D, int ortho,
+                                                                double *x) {
+  return modspec_entry(device, stream, 1, nullptr, ms, phase, x, nullptr, B, 0, D, n, ortho, 0, 0);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_modspec_smoothing(int device, void *stream, const double *x, int B,
+                                                                      int T, int D, int n, int ortho, int limit_bin,
+                                                                      int log_domain, double *out) {
+  return modspec_entry(device, stream, 2, x, nullptr, nullptr, out, nullptr, B, T, D, n, ortho, limit_bin, log_domain);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_modspec_backward(int device, void *stream, const double *x,
+                                                                     const double *grad_ms, int B, int T, int D,
+                                                                     int n, int ortho, double *grad_x) {
+  return modspec_entry(device, stream, 3, x, grad_ms, nullptr, grad_x, nullptr, B, T, D, n, ortho, 0, 0);
 }
 
 __attribute__((visibility("default"))) int mlpg_hip_trim_lengths(int device, void *stream, int dtype, const void *X,

@@ -164,6 +164,40 @@ def main():
         c0 += size
     out["merlin/y64"] = np.concatenate(cols, axis=1)
 
+    # --- modulation spectrum (preprocessing/modspec.py, autograd/_impl/modspec.py)
+    from nnmnkwii.preprocessing import inv_modspec, modspec, modspec_smoothing
+    for T, n in ((10, 16), (64, 64), (50, 128), (300, 1024), (1000, 4096)):
+        x = np.random.RandomState(_seed_for("modspec", T, n)).rand(T, 3)
+        out["modspec/T%d-n%d/x" % (T, n)] = x
+        for norm in (None, "ortho"):
+            key = "modspec/T%d-n%d/%s" % (T, n, norm or "none")
+            ms, ph = modspec(x, n=n, norm=norm, return_phase=True)
+            out[key + "/ms"] = ms
+            out[key + "/phase"] = ph
+            out[key + "/inv"] = inv_modspec(ms, ph, norm=norm)
+            for log_domain in (True, False):
+                for cutoff in (100, 25, 60):
+                    out[key + "/smooth-log%d-c%s" % (log_domain, cutoff)] = modspec_smoothing(
+                        x, 200, n=n, norm=norm, cutoff=cutoff, log_domain=log_domain)
+    x32 = np.random.RandomState(8).rand(40, 2).astype(np.float32)
+    out["modspec/f32/x"] = x32
+    out["modspec/f32/ms"] = modspec(x32, n=64)
+    out["modspec/f32/smooth"] = modspec_smoothing(x32, 200, n=64, cutoff=30)
+    import torch
+    from nnmnkwii.autograd import modspec as modspec_t
+    for T, n in ((16, 16), (12, 32), (40, 256)):
+        for norm in (None, "ortho"):
+            torch.manual_seed(T + n)
+            y = torch.rand(T, 4, requires_grad=True)
+            w = torch.rand(n // 2 + 1, 4)
+            ms_t = modspec_t(y, n=n, norm=norm)
+            (ms_t * w).sum().backward()
+            key = "modspec_grad/T%d-n%d-%s" % (T, n, norm or "none")
+            out[key + "/y"] = y.detach().numpy().copy()
+            out[key + "/w"] = w.numpy().copy()
+            out[key + "/ms"] = ms_t.detach().numpy().copy()
+            out[key + "/grad"] = y.grad.numpy().copy()
+
     # --- error behaviour: negative variance -> LinAlgError text
     m, v, _ = rand_case("std3", "f64", 10, 1)
     v = v.copy()

@@ -7,6 +7,7 @@
   c3  : autograd.unit_variance_mlpg forward+backward, B=64 x T=500 x 180, float32 tensors on the GPU
   c3m : autograd.mlpg (generic variances) forward+backward, one utterance T=500 x 180 float32
   c4  : DTWAligner on 128 pairs (1 GPU share of config 4), T in [700, 900], 25-dim, radius 1
+  ms  : modspec_smoothing / modspec (n = 4096) of a config-2 sized trajectory batch 256 x 1000 x 60, float64
   c5  : Merlin-style acoustic paramgen mgc(60)+lf0(1)+bap(5), T=2000, B=512 (1 GPU share of config 5), float64;
         per-stream dense tensors, and the three streams in place from one (B, T, 198) batch (forward_streams)
 
@@ -167,6 +168,28 @@ def main():
         ms_full = gpu_time(lambda: DTWAligner().transform((X, Y)), steps=3, warmup=1)
         emit(path="c4-fastdtw-kernel", pairs=N, ms=ms, pairs_per_s=N / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6,
              cpu_oracle_c_pairs_per_s=1.0 / cpu_s, transform_numpy_to_numpy_ms=ms_full)
+
+    # ---- ms: modulation-spectrum smoothing of the config-2 output batch (the step after MLPG) ----
+    if want("ms"):
+        B, T, sd, n = 256, 1000, 60, 4096
+        x = torch.randn(B, T, sd, dtype=torch.float64, device=dev, generator=gen)
+        ms = gpu_time(lambda: _hip.modspec_smoothing(x, n, 500, True), steps=5)
+        by = 16.0 * B * T * sd                      # read + write the trajectory once
+        # FFT arithmetic: 2 transforms x 5 n log2 n flops per column
+        fl = 2 * 5.0 * n * 12 * B * sd
+        xc = x[:4].cpu().numpy()
+        t0 = time.perf_counter()
+        for b_ in range(4):
+            s_ = np.fft.rfft(xc[b_], n=n, axis=0)
+            a_ = np.abs(s_)
+            a_[500:] = 1.0
+            np.fft.irfft(a_ * np.exp(1j * np.angle(s_)), n=n, axis=0)[:T]
+        cpu_s = (time.perf_counter() - t0) / 4
+        emit(path="ms-modspec_smoothing-n4096", ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6,
+             fft_GFLOPs=fl / ms / 1e6, cpu_numpy_fft_frames_per_s=T / cpu_s)
+        ms2 = gpu_time(lambda: _hip.modspec(x, n), steps=5)
+        emit(path="ms-modspec-n4096", ms=ms2, frames_per_s=B * T / ms2 * 1e3)
+        del x
 
     # ---- c5: Merlin-style multi-stream ----
     if want("c5"):
