@@ -17,7 +17,8 @@ VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libmlpg_hip.so")
+# NNMNKWII_AMD_SO selects another build of the same library (kernel experiments); default: the in-tree build
+SO_PATH = os.environ.get("NNMNKWII_AMD_SO") or os.path.join(_HERE, "csrc", "libmlpg_hip.so")
 
 EXPORTS = (
     "mlpg_hip_abi_version",
