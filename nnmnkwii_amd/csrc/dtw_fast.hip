@@ -1,6 +1,6 @@
 // fastdtw (Salvador & Chan 2007; semantics of slaypni/fastdtw's pure-Python
 // implementation, restated in oracle/dtw_oracle.c) with the Euclidean local
-// cost, one workgroup (one 64-lane wavefront) per utterance pair.
+// cost, one workgroup (8 wavefronts) per utterance pair.
 //
 // Replaces the per-pair fastdtw(x, y, radius, dist) call of
 // DTWAligner.transform (reference: preprocessing/alignment.py:50).
@@ -13,7 +13,7 @@
 //      the union of (2r+1)^2 neighbourhoods along a monotone path is one
 //      interval per row), then, in chunks of <= 63 rows:
 //        a. the local cost of every window cell of chunk c+1 is computed by
-//           wavefronts 1..3 (rows read through L1/L2) WHILE wavefront 0 sweeps
+//           the other wavefronts (rows read through L1/L2) WHILE wavefront 0 sweeps
 //           chunk c: two cost buffers, one barrier per chunk;
 //        b. the DP recurrence is swept along ANTI-DIAGONALS: lane r >= 1 owns row
 //           i0 + r - 1 and at step s handles column s - r, so one step is exactly
@@ -71,7 +71,7 @@ struct DtwParams {
 constexpr int kMaxLevels = 20;
 constexpr int kRows = 63;  // rows per chunk: lanes 1..63 of the sweeping wavefront (lane 0 feeds the row above)
 constexpr int kSeg = 16;    // rows per back-trace segment
-constexpr int kThreads = 256;  // 4 wavefronts per pair: all of them stage/halve/compute local costs, wavefront 0 sweeps
+constexpr int kThreads = 512;  // 8 wavefronts per pair: wavefront 0 sweeps, all of them halve, compute local costs and back-trace
 
 __device__ __forceinline__ double l2_cost(const double *__restrict__ a, const double *__restrict__ b, int D) {
   double acc = 0.0;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     __syncthreads();
     DTW_TICK(3);
 
-    // ---- 2d. DP: wavefront 0 sweeps chunk c while wavefronts 1..3 prepare the costs of chunk c+1 ----
+    // ---- 2d. DP: wavefront 0 sweeps chunk c while the other wavefronts prepare the costs of chunk c+1 ----
     int prevlo = -1, prevhi = -1;  // the virtual row -1 has the single cell (-1, -1)
     double *dprev = dprevA, *dnext = dprevB;
     double last_val = INFINITY;
