@@ -131,3 +131,25 @@ def test_dtw_custom_dist_rejected():
         a.transform((np.zeros((1, 3, 2)), np.zeros((1, 3, 2))))
     d = DTWAligner()
     assert d.radius == 1 and d.verbose == 0 and callable(d.dist)
+
+
+def test_compat_install_provides_the_reference_names():
+    """nnmnkwii_amd.compat: user code written against ``nnmnkwii`` resolves to the HIP path (no GPU needed to import)."""
+    import sys
+    import nnmnkwii_amd.compat as compat
+    from nnmnkwii_amd import paramgen as G
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    assert "nnmnkwii" not in sys.modules
+    compat.install()
+    try:
+        from nnmnkwii.paramgen import mlpg, unit_variance_mlpg_matrix   # noqa: F401
+        from nnmnkwii.preprocessing.alignment import DTWAligner as D2, IterativeDTWAligner   # noqa: F401
+        from nnmnkwii.baseline.gmm import MLPG   # noqa: F401
+        from nnmnkwii.autograd import unit_variance_mlpg   # noqa: F401
+        from nnmnkwii.util import apply_each2d_padded   # noqa: F401
+        import nnmnkwii.preprocessing as P
+        assert mlpg is G.mlpg and D2 is DTWAligner and P.modspec_smoothing is not None
+        compat.install()          # idempotent
+    finally:
+        compat.uninstall()
+    assert "nnmnkwii" not in sys.modules and "nnmnkwii.paramgen" not in sys.modules
