@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       int cpos = s0 - lane - mylo;  // column of this step relative to the row's window
       double dt_a = fetch(cpos), dt_b = fetch(cpos + 1);
       double pub = INFINITY;     // this lane's D at the column of the previous step (INF outside the window)
-      double cd = INFINITY;      // diagonal candidate of the coming step: (row above at the previous column) + its cost
+      double up_old = INFINITY;  // row above at the previous column
       double left = INFINITY;    // this row at the previous column (stays INF until the window starts)
       int st_b = dummy_b, st_d = dummy_d;
       unsigned st_code = 0u;
@@ -387,19 +387,14 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         dt_a = dt_b;
         dt_b = fetch(cpos + 2);
         // row above at this column; the feeder receives +0.0, which makes it replay its stored row:
-        // cu = 0 + dt = dt exactly, and neither left + dt nor the diagonal candidate (>= dt, D >= 0) is smaller
+        // cu = 0 + dt = dt exactly, and neither left + dt nor up_old + dt (>= dt, D >= 0) is smaller
         const double up = wave_shr1z(pub);
         const bool inwin = (unsigned)cpos < (unsigned)width;
-        // best = first minimum of (up, left, diagonal) + dt.  The diagonal candidate cd was formed one step
-        // ago (its operands were known then); the three comparisons are independent of each other, so the
-        // loop-carried chain is add -> compare -> select -> select instead of add -> cmp -> sel -> cmp -> sel.
-        const double cu = __dadd_rn(up, dt), cl = __dadd_rn(left, dt);
-        const bool f1 = cl < cu, f2 = cd < cu, f3 = cd < cl;
-        const bool take_d = f1 ? f3 : f2;           // cd < min-so-far
-        const double m1 = f1 ? cl : cu;
-        const double best = take_d ? cd : m1;
-        const unsigned code = take_d ? 2u : (f1 ? 1u : 0u);
-        cd = __dadd_rn(up, dt_a);                   // next step's diagonal candidate: this step's "up" + next cost
+        const double cu = __dadd_rn(up, dt), cl = __dadd_rn(left, dt), cd = __dadd_rn(up_old, dt);
+        double best = cu;
+        unsigned code = 0u;
+        if (cl < best) { best = cl; code = 1u; }
+        if (cd < best) { best = cd; code = 2u; }
         // No branches and a fixed number of LDS operations per step (so that the prefetch above is the
         // only thing a step ever waits for): stores outside the window go to per-lane dummy slots.
         // The stores of a step are issued at the top of the NEXT step, right after the wait for the
@@ -410,6 +405,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         st_code = code;
         st_d = (inwin && is_last) ? cpos : dummy_d;
         st_best = best;
+        up_old = up;
       }
       bp[st_b] = (unsigned char)st_code;
       dnext_all[st_d] = st_best;
