@@ -101,9 +101,9 @@ __device__ __forceinline__ double wave_shr1z(double v) {
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ int clamp_idx(int c, int hi) {  // median(c, 0, hi), hi >= 0
+__device__ __forceinline__ int clamp_idx(int c, int hi) {  // median(c, -1, hi), hi >= 0
   int r;
-  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(c), "v"(hi));
+  asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(c), "v"(hi));
   return r;
 }
 
@@ -153,10 +153,13 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
   const int pcap = Tx + Ty;
 
   // ---- LDS carve (doubles / 64-bit words, ints, shorts) ----
-  double *dchunk = (double *)smem;                 // local costs of a chunk's window cells, two buffers
-  double *dprevA = dchunk + 2 * p.chunkcap;        // last row of the previous chunk (ping)
-  double *dprevB = dprevA + Ty + 64;               //                                  (pong); + 64 dummy slots each
-  unsigned long long *rinfo = (unsigned long long *)(dprevB + Ty + 64);  // per row: lo | hi << 16 | off << 32
+  // local costs of a chunk's window cells, two buffers; every row is framed by one +INF cell on each side
+  // (a lane that is outside its window then computes +INF without any select)
+  const int dstride = p.chunkcap + 2 * kRows + 2;
+  double *dchunk = (double *)smem;
+  double *dprevA = dchunk + 2 * dstride;           // last row of the previous chunk, framed the same way (ping)
+  double *dprevB = dprevA + Ty + 72;               //                                  (pong); + 64 dummy slots each
+  unsigned long long *rinfo = (unsigned long long *)(dprevB + Ty + 72);  // per row: lo | hi << 16 | off << 32
   int *off = (int *)(rinfo + Tx);                  // cell offset of each row (prefix sum of widths)
   int *lvl_x = off + (Tx + 1);
   int *lvl_y = lvl_x + kMaxLevels;
@@ -280,7 +283,9 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       if (lane == 0) {
         off[ltx] = total;
         bcast[3] = (total > p.cellcap) ? 1 : 0;
-        dprevA[0] = 0.0;  // virtual row -1 of the level: D[-1][-1] = 0, nothing else
+        dprevA[0] = INFINITY;  // virtual row -1 of the level: D[-1][-1] = 0, nothing else
+        dprevA[1] = 0.0;
+        dprevA[2] = INFINITY;
       }
     }
     __syncthreads();
@@ -328,7 +333,11 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         }
         const int row = i0 + a;
         const int j = (int)lo[row] + cc - (off[row] - base);
-        dst[cc] = l2_cost(xk + (size_t)row * D, yk + (size_t)j * D, D);
+        dst[cc + 2 * a + 1] = l2_cost(xk + (size_t)row * D, yk + (size_t)j * D, D);
+      }
+      for (int a = tid - t0; a < R; a += nthr) {  // the +INF frame of every row
+        dst[off[i0 + a] - base + 2 * a] = INFINITY;
+        dst[off[i0 + a + 1] - base + 2 * a + 1] = INFINITY;
       }
     };
     chunk_costs(0, dchunk, 0, kThreads);
@@ -341,8 +350,8 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     double last_val = INFINITY;
     for (int c = 0; c < nchunk; ++c) {
       const int i0 = (int)cstart[c], R = (int)cstart[c + 1] - i0, base = off[i0];
-      const double *dcur = dchunk + (c & 1) * p.chunkcap;
-      if (!w0 && c + 1 < nchunk) chunk_costs(c + 1, dchunk + ((c + 1) & 1) * p.chunkcap, 64, kThreads - 64);
+      const double *dcur = dchunk + (c & 1) * dstride;
+      if (!w0 && c + 1 < nchunk) chunk_costs(c + 1, dchunk + ((c + 1) & 1) * dstride, 64, kThreads - 64);
       // anti-diagonal sweep (wavefront 0): lane r >= 1 owns row i0 + r - 1, lane 0 feeds the row above;
       // at step s every lane handles column s - lane of its row
       if (w0) {
@@ -350,28 +359,26 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       const bool real = lane >= 1 && lane <= R;
       const int i = i0 + lane - 1;
       int mylo = 0, width = 0, bbase = bp_dummy;
-      const double *src = dcur;
+      const double *src = dprev + 1;  // src[-1] and src[width] are the +INF frame of the row
       if (feeder) {
         mylo = prevlo;
         width = prevhi - prevlo + 1;
-        src = dprev;
       } else if (real) {
         mylo = (int)lo[i];
         width = (int)hi[i] - mylo + 1;
-        src = dcur + (off[i] - base);
+        src = dcur + (off[i] - base) + 2 * (lane - 1) + 1;
         bbase = off[i];
       }
       const bool is_last = lane == R;  // hands its row to the next chunk
       // two steps of lead-in: the feeder emits columns lo-1 and lo first
       const int s0 = __builtin_amdgcn_readfirstlane((int)lo[i0]) - 1;
       const int s1 = __builtin_amdgcn_readfirstlane((int)hi[i0 + R - 1]) + R;
-      const int wmax = width > 0 ? width - 1 : 0;
       // The only loop-carried chain is add -> compare -> select -> DPP; the local cost is fetched TWO
       // steps ahead so that no step waits on an LDS round trip.
-      auto fetch = [&](int c) { return src[clamp_idx(c, wmax)]; };
+      auto fetch = [&](int c) { return src[clamp_idx(c, width)]; };  // median(c, -1, width)
       const int dummy_b = bp_dummy + Ty + lane;  // dummy back-pointer byte of this lane
-      double *dnext_all = dnext;                 // dnext[Ty + lane] is this lane's dummy slot
-      const int dummy_d = Ty + lane;
+      double *dnext_all = dnext;                 // dnext[Ty + 2 + lane] is this lane's dummy slot
+      const int dummy_d = Ty + 2 + lane;
       int cpos = s0 - lane - mylo;  // column of this step relative to the row's window
       double dt_a = fetch(cpos), dt_b = fetch(cpos + 1);
       double pub = INFINITY;     // this lane's D at the column of the previous step (INF outside the window)
@@ -397,18 +404,24 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         if (cd < best) { best = cd; code = 2u; }
         // No branches and a fixed number of LDS operations per step (so that the prefetch above is the
         // only thing a step ever waits for): stores outside the window go to per-lane dummy slots.
-        // The stores of a step are issued at the top of the NEXT step, right after the wait for the
-        // prefetched cost, so that the in-order LDS counter never makes a step wait for its own stores.
-        left = inwin ? best : left;
-        pub = inwin ? best : INFINITY;
+        // Outside the window dt is the +INF frame, so best is +INF there by itself: no select for the
+        // values the neighbours see.  The stores of a step are issued at the top of the NEXT step, right
+        // after the wait for the prefetched cost, so that the in-order LDS counter never makes a step wait
+        // for its own stores.
+        left = best;
+        pub = best;
         st_b = inwin ? bbase + cpos : dummy_b;
         st_code = code;
-        st_d = (inwin && is_last) ? cpos : dummy_d;
+        st_d = (inwin && is_last) ? cpos + 1 : dummy_d;
         st_best = best;
         up_old = up;
       }
       bp[st_b] = (unsigned char)st_code;
       dnext_all[st_d] = st_best;
+      if (is_last) {  // +INF frame of the row handed to the next chunk
+        dnext[0] = INFINITY;
+        dnext[width + 1] = INFINITY;
+      }
       // value of the chunk's last cell (bottom-right corner of the level if this is the last chunk)
       last_val = __shfl(left, R);
       }  // w0
@@ -601,7 +614,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
 
 size_t lds_bytes(int Tx, int Ty, int D, const DtwParams &p) {
   size_t b = 0;
-  b += sizeof(double) * (2 * (size_t)p.chunkcap + 2 * (size_t)(Ty + 64));
+  b += sizeof(double) * (2 * ((size_t)p.chunkcap + 2 * kRows + 2) + 2 * (size_t)(Ty + 72));
   b += sizeof(unsigned long long) * (size_t)Tx;
   b += sizeof(int) * ((size_t)(Tx + 1) + 2 * kMaxLevels + 8 + 3 * (size_t)(Tx / kSeg + 3));
   b += sizeof(unsigned short) * ((size_t)2 * Tx + 2 * (Tx / 2 + 2) + 2 * (size_t)(Tx + Ty));
