@@ -384,20 +384,26 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       double pub = INFINITY;     // this lane's D at the column of the previous step (INF outside the window)
       double up_old = INFINITY;  // row above at the previous column
       double left = INFINITY;    // this row at the previous column (stays INF until the window starts)
-      int st_b = dummy_b, st_d = dummy_d;
-      unsigned st_code = 0u;
-      double st_best = 0.0;
-      for (int s = s0; s <= s1; ++s, ++cpos) {
-        const double dt = dt_a;
-        bp[st_b] = (unsigned char)st_code;  // stores of the previous step
-        dnext_all[st_d] = st_best;
-        dt_a = dt_b;
-        dt_b = fetch(cpos + 2);
+      // One step.  dt_use: this step's cost slot (refilled with the cost two steps ahead); up_w / up_r: where
+      // "row above at this column" is written / where the previous step left it (the diagonal); st_w / st_r:
+      // the stores this step prepares / the ones the previous step prepared.  The loop body is two steps
+      // with the roles of the slots exchanged, so nothing has to be rotated through registers.
+      struct Stores {
+        int b, d;
+        unsigned code;
+        double best;
+      };
+      auto step = [&](double &dt_use, double &up_w, const double &up_r, Stores &st_w, const Stores &st_r) {
+        const double dt = dt_use;
+        bp[st_r.b] = (unsigned char)st_r.code;  // stores of the previous step
+        dnext_all[st_r.d] = st_r.best;
+        dt_use = fetch(cpos + 2);
         // row above at this column; the feeder receives +0.0, which makes it replay its stored row:
-        // cu = 0 + dt = dt exactly, and neither left + dt nor up_old + dt (>= dt, D >= 0) is smaller
+        // cu = 0 + dt = dt exactly, and neither left + dt nor the diagonal + dt (>= dt, D >= 0) is smaller
         const double up = wave_shr1z(pub);
+        up_w = up;
         const bool inwin = (unsigned)cpos < (unsigned)width;
-        const double cu = __dadd_rn(up, dt), cl = __dadd_rn(left, dt), cd = __dadd_rn(up_old, dt);
+        const double cu = __dadd_rn(up, dt), cl = __dadd_rn(left, dt), cd = __dadd_rn(up_r, dt);
         double best = cu;
         unsigned code = 0u;
         if (cl < best) { best = cl; code = 1u; }
@@ -410,14 +416,27 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         // for its own stores.
         left = best;
         pub = best;
-        st_b = inwin ? bbase + cpos : dummy_b;
-        st_code = code;
-        st_d = (inwin && is_last) ? cpos + 1 : dummy_d;
-        st_best = best;
-        up_old = up;
+        st_w.b = inwin ? bbase + cpos : dummy_b;
+        st_w.code = code;
+        st_w.d = (inwin && is_last) ? cpos + 1 : dummy_d;
+        st_w.best = best;
+        ++cpos;
+      };
+      Stores stA = {dummy_b, dummy_d, 0u, 0.0}, stB = stA;
+      double upA = INFINITY, upB = up_old;
+      int nsteps = s1 - s0 + 1;
+      if (nsteps & 1) {  // an odd count gets one more (harmless) lead-in step
+        --cpos;
+        ++nsteps;
+        dt_b = dt_a;
+        dt_a = fetch(cpos);
       }
-      bp[st_b] = (unsigned char)st_code;
-      dnext_all[st_d] = st_best;
+      for (int k = 0; k < nsteps; k += 2) {
+        step(dt_a, upA, upB, stA, stB);
+        step(dt_b, upB, upA, stB, stA);
+      }
+      bp[stB.b] = (unsigned char)stB.code;
+      dnext_all[stB.d] = stB.best;
       if (is_last) {  // +INF frame of the row handed to the next chunk
         dnext[0] = INFINITY;
         dnext[width + 1] = INFINITY;
