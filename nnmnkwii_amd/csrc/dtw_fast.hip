@@ -397,13 +397,13 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         const double dt = dt_use;
         bp[st_r.b] = (unsigned char)st_r.code;  // stores of the previous step
         dnext_all[st_r.d] = st_r.best;
-        dt_use = fetch(cpos + 2);
         // row above at this column; the feeder receives +0.0, which makes it replay its stored row:
         // cu = 0 + dt = dt exactly, and neither left + dt nor the diagonal + dt (>= dt, D >= 0) is smaller
         const double up = wave_shr1z(pub);
         up_w = up;
         const bool inwin = (unsigned)cpos < (unsigned)width;
         const double cu = __dadd_rn(up, dt), cl = __dadd_rn(left, dt), cd = __dadd_rn(up_r, dt);
+        dt_use = fetch(cpos + 2);  // after the last use of dt: the slot's register is refilled in place
         double best = cu;
         unsigned code = 0u;
         if (cl < best) { best = cl; code = 1u; }
