@@ -375,12 +375,28 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       const int s1 = __builtin_amdgcn_readfirstlane((int)hi[i0 + R - 1]) + R;
       // The only loop-carried chain is add -> compare -> select -> DPP; the local cost is fetched TWO
       // steps ahead so that no step waits on an LDS round trip.
-      auto fetch = [&](int c) { return src[clamp_idx(c, width)]; };  // median(c, -1, width)
-      const int dummy_b = bp_dummy + Ty + lane;  // dummy back-pointer byte of this lane
-      double *dnext_all = dnext;                 // dnext[Ty + 2 + lane] is this lane's dummy slot
-      const int dummy_d = Ty + 2 + lane;
+      // Everything the step touches in LDS is addressed by RUNNING BYTE OFFSETS from the start of the
+      // workgroup's LDS (one add per step each) instead of being re-derived from the column index:
+      //   f_off  cost cell two steps ahead (clamped to the row's +INF frame [f_lo, f_hi])
+      //   b_off  this step's back-pointer byte      d_off  this step's cell in the hand-over row
+      // (absolute LDS addresses, dereferenced through address_space(3) pointers: no base add per access)
+      typedef __attribute__((address_space(3))) unsigned char lds_u8;
+      typedef __attribute__((address_space(3))) double lds_f64;
+      const int lbase = (int)(unsigned)(uintptr_t)(lds_u8 *)smem;
       int cpos = s0 - lane - mylo;  // column of this step relative to the row's window
-      double dt_a = fetch(cpos), dt_b = fetch(cpos + 1);
+      const int src_off = lbase + (int)((const unsigned char *)src - smem);
+      const int f_lo = src_off - 8, f_hi = src_off + 8 * width;
+      auto fetch_at = [&](int o) {
+        int c;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(o), "v"(f_lo), "v"(f_hi));
+        return *(const lds_f64 *)(uintptr_t)(unsigned)c;
+      };
+      const int dummy_b = lbase + (int)(bp - smem) + bp_dummy + Ty + lane;             // this lane's dummy byte
+      const int dummy_d = lbase + (int)((const unsigned char *)(dnext + Ty + 2 + lane) - smem);  // and dummy hand-over slot
+      int f_off = src_off + 8 * (cpos + 2);
+      int b_off = lbase + (int)(bp - smem) + bbase + cpos;
+      int d_off = lbase + (int)((const unsigned char *)(dnext + 1) - smem) + 8 * cpos;
+      double dt_a = fetch_at(f_off - 16), dt_b = fetch_at(f_off - 8);
       double pub = INFINITY;     // this lane's D at the column of the previous step (INF outside the window)
       double up_old = INFINITY;  // row above at the previous column
       double left = INFINITY;    // this row at the previous column (stays INF until the window starts)
@@ -395,15 +411,15 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       };
       auto step = [&](double &dt_use, double &up_w, const double &up_r, Stores &st_w, const Stores &st_r) {
         const double dt = dt_use;
-        bp[st_r.b] = (unsigned char)st_r.code;  // stores of the previous step
-        dnext_all[st_r.d] = st_r.best;
+        *(lds_u8 *)(uintptr_t)(unsigned)st_r.b = (unsigned char)st_r.code;  // stores of the previous step
+        *(lds_f64 *)(uintptr_t)(unsigned)st_r.d = st_r.best;
         // row above at this column; the feeder receives +0.0, which makes it replay its stored row:
         // cu = 0 + dt = dt exactly, and neither left + dt nor the diagonal + dt (>= dt, D >= 0) is smaller
         const double up = wave_shr1z(pub);
         up_w = up;
         const bool inwin = (unsigned)cpos < (unsigned)width;
         const double cu = __dadd_rn(up, dt), cl = __dadd_rn(left, dt), cd = __dadd_rn(up_r, dt);
-        dt_use = fetch(cpos + 2);  // after the last use of dt: the slot's register is refilled in place
+        dt_use = fetch_at(f_off);  // after the last use of dt: the slot's register is refilled in place
         double best = cu;
         unsigned code = 0u;
         if (cl < best) { best = cl; code = 1u; }
@@ -416,27 +432,33 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         // for its own stores.
         left = best;
         pub = best;
-        st_w.b = inwin ? bbase + cpos : dummy_b;
+        st_w.b = inwin ? b_off : dummy_b;
         st_w.code = code;
-        st_w.d = (inwin && is_last) ? cpos + 1 : dummy_d;
+        st_w.d = (inwin && is_last) ? d_off : dummy_d;
         st_w.best = best;
         ++cpos;
+        f_off += 8;
+        b_off += 1;
+        d_off += 8;
       };
       Stores stA = {dummy_b, dummy_d, 0u, 0.0}, stB = stA;
       double upA = INFINITY, upB = up_old;
       int nsteps = s1 - s0 + 1;
       if (nsteps & 1) {  // an odd count gets one more (harmless) lead-in step
         --cpos;
+        f_off -= 8;
+        b_off -= 1;
+        d_off -= 8;
         ++nsteps;
         dt_b = dt_a;
-        dt_a = fetch(cpos);
+        dt_a = fetch_at(f_off - 16);
       }
       for (int k = 0; k < nsteps; k += 2) {
         step(dt_a, upA, upB, stA, stB);
         step(dt_b, upB, upA, stB, stA);
       }
-      bp[stB.b] = (unsigned char)stB.code;
-      dnext_all[stB.d] = stB.best;
+      *(lds_u8 *)(uintptr_t)(unsigned)stB.b = (unsigned char)stB.code;
+      *(lds_f64 *)(uintptr_t)(unsigned)stB.d = stB.best;
       if (is_last) {  // +INF frame of the row handed to the next chunk
         dnext[0] = INFINITY;
         dnext[width + 1] = INFINITY;
