@@ -3,6 +3,7 @@
 
     python tools/bench_paths.py [--quick]
 
+  c2h : config 2 end to end from host memory (numpy -> numpy), PCIe-inclusive wall clock
   c2g : config 2 with global (D,) variances and with unit variances (32 B per (frame, dim))
   c3  : autograd.unit_variance_mlpg forward+backward, B=64 x T=500 x 180, float32 tensors on the GPU
   c3m : autograd.mlpg (generic variances) forward+backward, one utterance T=500 x 180 float32
@@ -75,6 +76,23 @@ def main():
             by = 32.0 * sd * B * T
             emit(path="c2g-" + name, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
         del m
+
+    # ---- c2h: config 2 end to end from host memory (numpy in -> numpy out through paramgen.mlpg_batch): PCIe-inclusive ----
+    if want("c2h"):
+        B, T, sd = 256, 1000, 60
+        rng = np.random.RandomState(1234)
+        mh = rng.randn(B, T, 3 * sd)
+        vh = rng.rand(B, T, 3 * sd) + 0.1
+        G.mlpg_batch(mh[:8], vh[:8], WINDOWS)
+        t0 = time.perf_counter()
+        nrep = 2
+        for _ in range(nrep):
+            yh = G.mlpg_batch(mh, vh, WINDOWS)
+        wall = (time.perf_counter() - t0) / nrep
+        by = 56.0 * sd * B * T
+        emit(path="c2h-numpy-to-numpy-mlpg_batch", ms=wall * 1e3, frames_per_s=B * T / wall, alg_bytes=by,
+             GBps=by / wall / 1e9, note="pageable host arrays: H2D of 737 MB + kernel + D2H of 123 MB + status check")
+        del mh, vh, yh
 
     # ---- c2b: backward (mlpg_hip_backward) at config-2 scale, float64 and float32 ----
     if want("c2b"):
