@@ -7,6 +7,11 @@
 // wave-per-system kernel in mlpg_wave.hip is the fast path for the common case.
 // The banded factor does not fit on chip at one system per lane, so it goes to
 // an HBM scratch laid out [frame][row][system] (system fastest = coalesced).
+// Three stages: the assembly of P and b is embarrassingly parallel (one thread
+// per (frame, system)); only the factorisation + substitutions are sequential
+// in time (one thread per system, scratch rows prefetched four frames ahead so
+// that the recurrence never waits for memory); the backward's epilogue is
+// parallel again.
 //
 // Math (reference: paramgen/_mlpg.py:92-199, _bandmat/linalg.pyx:36-176):
 //   P[f+k, f] = sum_w sum_t c_w[l_w+f-t] c_w[l_w+f+k-t] tau_w[t]
@@ -20,6 +25,35 @@
 namespace mlpg {
 namespace {
 
+// ---- stage 1: assembly, fully parallel: one thread per (frame, system) ----
+// scratch[(f * R + k) * S + s], R = Q + 2:  k = 0..Q -> P[f+k, f],  k = Q+1 -> right-hand side of frame f
+template <int Q, typename TIN, bool BWD>
+__global__ __launch_bounds__(256) void generic_assemble_kernel(Problem p, WinSet ws, double *__restrict__ scratch, long S) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= S * p.Tmax) return;
+  const long s = e % S;
+  const int f = (int)(e / S);
+  const int sd = p.sd;
+  const int b = (int)(s / sd), d = (int)(s % sd);
+  int T = p.lengths ? p.lengths[b] : p.Tmax;
+  T = T < 0 ? 0 : (T > p.Tmax ? p.Tmax : T);
+  if (f >= T) return;
+  const SysView<TIN, BWD> view = make_view<TIN, BWD>(p, ws, b, d, T);
+  double pk[Q + 1], rhs;
+  assemble_frame<Q, TIN, BWD>(view, ws, f, pk, rhs);
+  constexpr int R = Q + 2;
+  double *sc = scratch + ((size_t)f * R) * S + s;
+#pragma unroll
+  for (int k = 0; k <= Q; ++k) sc[(size_t)k * S] = pk[k];
+  sc[(size_t)(Q + 1) * S] = rhs;
+}
+
+// ---- stage 2: the sequential part, one thread per system: right-looking banded Cholesky fused with the
+// forward substitution, then the reverse sweep.  The rows of the next kPF frames are loaded while the current
+// ones are processed (the recurrence itself never waits for memory).  Overwrites the scratch in place:
+// k = 0 -> 1 / L_ff, k = 1..Q -> L[f+k, f], k = Q+1 -> z_f, and after the reverse sweep x_f (backward only).
+constexpr int kPF = 4;
+
 template <int Q, typename TIN, typename TOUT, bool BWD>
 __global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, double *__restrict__ scratch, long S) {
   const long s = (long)blockIdx.x * 64 + threadIdx.x;
@@ -29,12 +63,10 @@ __global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, doubl
   const int b = (int)(s / sd), d = (int)(s % sd);
   int T = p.lengths ? p.lengths[b] : Tmax;
   T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
-  const SysView<TIN, BWD> view = make_view<TIN, BWD>(p, ws, b, d, T);
   TOUT *out = (TOUT *)p.out + (size_t)b * Tmax * ldo;
   const int nw = ws.nw;
-  auto tau = [&](int w, int t) -> double { return view.tau(w, t); };
 
-  constexpr int R = Q + 2;  // scratch rows per frame: 1/L_ff, L_{f+1..f+Q, f}, z_f
+  constexpr int R = Q + 2;
   double pend[Q + 1][Q + 1];
   double rp[Q + 1];
 #pragma unroll
@@ -43,83 +75,130 @@ __global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, doubl
 #pragma unroll
     for (int k = 0; k <= Q; ++k) pend[j][k] = 0.0;
   }
+  auto load_rows = [&](double (&dst)[kPF][R], int f0) {
+#pragma unroll
+    for (int q = 0; q < kPF; ++q)
+#pragma unroll
+      for (int k = 0; k < R; ++k) dst[q][k] = (f0 + q < T) ? scratch[((size_t)(f0 + q) * R + k) * S + s] : 0.0;
+  };
 
   int bad = 0;
-  for (int f = 0; f < T; ++f) {
-    double pk[Q + 1], rhs;
-    assemble_frame<Q, TIN, BWD>(view, ws, f, pk, rhs);
-    double v[Q + 1];
+  double cur[kPF][R], nxt[kPF][R];
+  load_rows(cur, 0);
+  for (int f0 = 0; f0 < T && !bad; f0 += kPF) {
+    load_rows(nxt, f0 + kPF);
 #pragma unroll
-    for (int k = 0; k <= Q; ++k) v[k] = pk[k] + pend[0][k];
-    if (v[0] <= 0.0) {  // NaN passes, as in linalg.pyx:78
-      bad = f + 1;
-      break;
-    }
-    const double iv0 = 1.0 / v[0];
-    const double siv0 = sqrt(iv0);
-    const double zf = (rhs + rp[0]) * siv0;
-    double *sc = scratch + ((size_t)f * R) * S + s;
-    sc[0] = siv0;
+    for (int q = 0; q < kPF; ++q) {
+      const int f = f0 + q;
+      if (f >= T || bad) break;
+      double v[Q + 1];
 #pragma unroll
-    for (int k = 1; k <= Q; ++k) {
-      const double Lk = v[k] * siv0;
-      sc[(size_t)k * S] = Lk;
-      rp[k - 1] = rp[k] - Lk * zf;
-    }
-    sc[(size_t)(Q + 1) * S] = zf;
-    // trailing update of the next Q columns (linalg.pyx:93-95), shifted one
-    // column to the left so that pend[0] is always "the current frame"
+      for (int k = 0; k <= Q; ++k) v[k] = cur[q][k] + pend[0][k];
+      if (v[0] <= 0.0) {  // NaN passes, as in linalg.pyx:78
+        bad = f + 1;
+        break;
+      }
+      const double iv0 = 1.0 / v[0];
+      const double siv0 = sqrt(iv0);
+      const double zf = (cur[q][Q + 1] + rp[0]) * siv0;
+      double *sc = scratch + ((size_t)f * R) * S + s;
+      sc[0] = siv0;
 #pragma unroll
-    for (int k = 0; k < Q; ++k) {
+      for (int k = 1; k <= Q; ++k) {
+        const double Lk = v[k] * siv0;
+        sc[(size_t)k * S] = Lk;
+        rp[k - 1] = rp[k] - Lk * zf;
+      }
+      sc[(size_t)(Q + 1) * S] = zf;
+      // trailing update of the next Q columns (linalg.pyx:93-95), shifted one
+      // column to the left so that pend[0] is always "the current frame"
 #pragma unroll
-      for (int l = 0; l <= Q; ++l) {
-        double nv = pend[k + 1][l];
-        if (l + k + 1 <= Q) nv -= v[l + k + 1] * v[k + 1] * iv0;
-        pend[k][l] = nv;
+      for (int k = 0; k < Q; ++k) {
+#pragma unroll
+        for (int l = 0; l <= Q; ++l) {
+          double nv = pend[k + 1][l];
+          if (l + k + 1 <= Q) nv -= v[l + k + 1] * v[k + 1] * iv0;
+          pend[k][l] = nv;
+        }
       }
     }
+#pragma unroll
+    for (int q = 0; q < kPF; ++q)
+#pragma unroll
+      for (int k = 0; k < R; ++k) cur[q][k] = nxt[q][k];
   }
 
   if (p.status) p.status[(size_t)b * p.ld_status + d] = bad;
   const int ncol = BWD ? nw : 1;
   if (bad) T = 0;  // failed system: zero-fill everything
 
-  // reverse sweep: L^T x = z
+  // reverse sweep: L^T x = z, rows prefetched kPF frames ahead (downwards)
   double xw[Q + 1];
 #pragma unroll
   for (int k = 0; k <= Q; ++k) xw[k] = 0.0;
-  for (int f = T - 1; f >= 0; --f) {
-    double *sc = scratch + ((size_t)f * R) * S + s;
-    double x = sc[(size_t)(Q + 1) * S];
+  auto load_rows_rev = [&](double (&dst)[kPF][R], int ftop) {  // frames ftop, ftop-1, ...
 #pragma unroll
-    for (int k = 1; k <= Q; ++k) x -= sc[(size_t)k * S] * xw[k];
-    x *= sc[0];
+    for (int q = 0; q < kPF; ++q)
 #pragma unroll
-    for (int k = Q; k >= 2; --k) xw[k] = xw[k - 1];
-    if constexpr (Q >= 1) xw[1] = x;
-    if (BWD)
-      sc[(size_t)(Q + 1) * S] = x;
-    else
-      out[(size_t)f * ldo + d] = (TOUT)x;
+      for (int k = 0; k < R; ++k) dst[q][k] = (ftop - q >= 0 && ftop - q < T) ? scratch[((size_t)(ftop - q) * R + k) * S + s] : 0.0;
+  };
+  load_rows_rev(cur, T - 1);
+  for (int f0 = T - 1; f0 >= 0; f0 -= kPF) {
+    load_rows_rev(nxt, f0 - kPF);
+#pragma unroll
+    for (int q = 0; q < kPF; ++q) {
+      const int f = f0 - q;
+      if (f < 0) break;
+      double x = cur[q][Q + 1];
+#pragma unroll
+      for (int k = 1; k <= Q; ++k) x -= cur[q][k] * xw[k];
+      x *= cur[q][0];
+#pragma unroll
+      for (int k = Q; k >= 2; --k) xw[k] = xw[k - 1];
+      if constexpr (Q >= 1) xw[1] = x;
+      if (BWD)
+        scratch[((size_t)f * R + (Q + 1)) * S + s] = x;
+      else
+        out[(size_t)f * ldo + d] = (TOUT)x;
+    }
+#pragma unroll
+    for (int q = 0; q < kPF; ++q)
+#pragma unroll
+      for (int k = 0; k < R; ++k) cur[q][k] = nxt[q][k];
   }
 
-  if (BWD) {
-    for (int t = 0; t < T; ++t) {
-      for (int w = 0; w < nw; ++w) {
-        const int l = ws.l[w], u = ws.u[w];
-        const double *c = ws.c + ws.off[w];
-        double g = 0.0;
-        for (int k = -l; k <= u; ++k) {
-          const int tt = t + k;
-          if (tt >= 0 && tt < T) g += c[l + k] * scratch[((size_t)tt * R + (Q + 1)) * S + s];
-        }
-        out[(size_t)t * ldo + w * sd + d] = (TOUT)(tau(w, t) * g);
-      }
-    }
-  }
-  // zero the padding frames (and everything, for a failed system)
+  // zero the padding frames (and everything, for a failed system); the backward's valid frames are written
+  // by the epilogue kernel
   for (int t = T; t < Tmax; ++t)
     for (int w = 0; w < ncol; ++w) out[(size_t)t * ldo + w * sd + d] = (TOUT)0;
+}
+
+// ---- stage 3 (backward only): grad[t, w*sd+d] = tau_w[t] * sum_k c_w[l_w+k] x[t+k], one thread per (frame, system) ----
+template <int Q, typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void generic_epilogue_kernel(Problem p, WinSet ws, const double *__restrict__ scratch, long S) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= S * p.Tmax) return;
+  const long s = e % S;
+  const int t = (int)(e / S);
+  const int sd = p.sd;
+  const int b = (int)(s / sd), d = (int)(s % sd);
+  int T = p.lengths ? p.lengths[b] : p.Tmax;
+  T = T < 0 ? 0 : (T > p.Tmax ? p.Tmax : T);
+  if (t >= T) return;
+  if (p.status && p.status[(size_t)b * p.ld_status + d] != 0) return;  // failed system: already zero-filled
+  constexpr int R = Q + 2;
+  const SysView<TIN, true> view = make_view<TIN, true>(p, ws, b, d, T);
+  TOUT *out = (TOUT *)p.out + (size_t)b * p.Tmax * p.ld_out;
+  for (int w = 0; w < ws.nw; ++w) {
+    const int l = ws.l[w], u = ws.u[w];
+    const double *c = ws.c + ws.off[w];
+    double g = 0.0;
+    for (int k = -l; k <= u; ++k) {
+      const int tt = t + k;
+      if (tt >= 0 && tt < T) g += c[l + k] * scratch[((size_t)tt * R + (Q + 1)) * S + s];
+    }
+    out[(size_t)t * p.ld_out + w * sd + d] = (TOUT)(view.tau(w, t) * g);
+  }
 }
 
 template <int Q, typename TIN, typename TOUT, bool BWD>
@@ -129,8 +208,19 @@ int launch_q(hipStream_t st, const Problem &p, const WinSet &w, int device) {
   const size_t bytes = sizeof(double) * (size_t)(Q + 2) * (size_t)p.Tmax * (size_t)S;
   double *sc = (double *)scratch(device, 0, bytes);
   if (!sc) return MLPG_HIP_ENOMEM;
+  Problem q = p;
+  if (BWD && !q.status) {
+    // the epilogue needs to know which systems failed even when the caller does not ask for the status
+    q.status = (int32_t *)scratch(device, 2, sizeof(int32_t) * (size_t)S);
+    if (!q.status) return MLPG_HIP_ENOMEM;
+    q.ld_status = p.sd;
+  }
+  const long cells = S * p.Tmax;
+  const unsigned gcells = (unsigned)((cells + 255) / 256);
+  hipLaunchKernelGGL((generic_assemble_kernel<Q, TIN, BWD>), dim3(gcells), dim3(256), 0, st, q, w, sc, S);
   const unsigned grid = (unsigned)((S + 63) / 64);
-  hipLaunchKernelGGL((generic_kernel<Q, TIN, TOUT, BWD>), dim3(grid), dim3(64), 0, st, p, w, sc, S);
+  hipLaunchKernelGGL((generic_kernel<Q, TIN, TOUT, BWD>), dim3(grid), dim3(64), 0, st, q, w, sc, S);
+  if (BWD) hipLaunchKernelGGL((generic_epilogue_kernel<Q, TIN, TOUT>), dim3(gcells), dim3(256), 0, st, q, w, sc, S);
   MLPG_HIP_CHECK(hipGetLastError());
   return 0;
 }
