@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void generic_assemble_kernel(Problem p, WinSet
 // forward substitution, then the reverse sweep.  The rows of the next kPF frames are loaded while the current
 // ones are processed (the recurrence itself never waits for memory).  Overwrites the scratch in place:
 // k = 0 -> 1 / L_ff, k = 1..Q -> L[f+k, f], k = Q+1 -> z_f, and after the reverse sweep x_f (backward only).
-constexpr int kPF = 4;
+template <int Q>
+constexpr int prefetch_depth() { return Q <= 2 ? 8 : 4; }  // frames in flight per thread (register budget)
 
 template <int Q, typename TIN, typename TOUT, bool BWD>
 __global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, double *__restrict__ scratch, long S) {
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(64) void generic_kernel(Problem p, WinSet ws, doubl
   const int nw = ws.nw;
 
   constexpr int R = Q + 2;
+  constexpr int kPF = prefetch_depth<Q>();
   double pend[Q + 1][Q + 1];
   double rp[Q + 1];
 #pragma unroll
