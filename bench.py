@@ -7,8 +7,10 @@ independent shards, no data-path collective).
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (one mlpg_hip_forward launch through the C
-ABI) over the rank's resident batch.  Rank 0 prints ONE JSON line.
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks (it
+re-executes itself under torch.distributed.run on 127.0.0.1) and fails loudly if the node has
+fewer than N GPUs.  A "step" is one pass of the hot path (one mlpg_hip_forward launch through the
+C ABI) over the rank's resident batch.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -38,7 +40,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--static-dim", type=int, default=60)
-    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 generic, 2 wave")
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 generic, 2 wave-per-system, 3 strip")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="plumbing test only (no GPU, gloo): the launch / barrier / reduction / JSON path with a no-op step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-check", action="store_true", help="profiling/ablation only: skip status and parity checks")
@@ -54,11 +58,11 @@ G = ref.load()
 n, T, D, seed = (int(a) for a in sys.argv[2:6])
 W = [(0, 0, np.array([1.0])), (1, 1, np.array([-0.5, 0.0, 0.5])), (1, 1, np.array([1.0, -2.0, 1.0]))]
 rng = np.random.RandomState(seed)
-m = rng.randn(T, D); v = rng.rand(T, D) + 0.1
-G.mlpg(m, v, W)
+utts = [(rng.randn(T, D), rng.rand(T, D) + 0.1) for _ in range(n)]      # distinct utterances
+G.mlpg(*utts[0], W)
 sys.stdin.readline()              # start gun
 t0 = time.perf_counter()
-for _ in range(n):
+for m, v in utts:
     G.mlpg(m, v, W)
 print(time.perf_counter() - t0)
 """
@@ -73,7 +77,7 @@ def _reference_pool(n_per_proc, T, D, cores, timeout):
                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
              for i in range(cores)]
     try:
-        time.sleep(min(10.0, 1.0 + 0.05 * cores))          # let every process import and warm up
+        time.sleep(min(15.0, 2.0 + 0.1 * cores))          # let every process import and generate its utterances
         t0 = time.perf_counter()
         for p in procs:
             p.stdin.write("go\n")
@@ -94,50 +98,50 @@ def cpu_baseline(T, D, seconds):
     kind "reference": the reference's OWN numpy/bandmat/Cython code (oracle/_ref: its sources
     compiled unmodified by oracle/build_ref_so.sh), called the way the reference batches -- a
     Python loop of paramgen.mlpg over utterances (util/__init__.py:44-66) -- on ONE core (the
-    reference is single-threaded).  kind "port": the C restatement oracle/mlpg_oracle.c, if the
-    compiled reference is not present."""
+    reference is single-threaded).  The sample is a pool of DISTINCT utterances (5.8 MB each,
+    cycled if the time budget outlasts the pool), so the working set does not sit in the core's
+    cache.  kind "port": the C restatement oracle/mlpg_oracle.c, if the compiled reference is absent."""
     from oracle import mlpg as O
     from oracle import ref
     O.build()
     rng = np.random.RandomState(1234)
     if ref.available():
         G = ref.load()
-        m = rng.randn(T, D)
-        v = rng.rand(T, D) + 0.1
-        y = G.mlpg(m, v, WINDOWS)
-        assert np.array_equal(y, O.mlpg(m, v, WINDOWS)), "C oracle and compiled reference disagree"
+        pool = [(rng.randn(T, D), rng.rand(T, D) + 0.1) for _ in range(64)]
+        y = G.mlpg(*pool[0], WINDOWS)
+        assert np.array_equal(y, O.mlpg(*pool[0], WINDOWS)), "C oracle and compiled reference disagree"
         t0 = time.perf_counter()
-        G.mlpg(m, v, WINDOWS)
+        G.mlpg(*pool[1], WINDOWS)
         per = time.perf_counter() - t0
         n = int(max(8, min(4096, seconds / max(per, 1e-6))))
         t0 = time.perf_counter()
-        for _ in range(n):
-            G.mlpg(m, v, WINDOWS)
+        for k in range(n):
+            G.mlpg(*pool[k % len(pool)], WINDOWS)
         dt = time.perf_counter() - t0
         res = {
             "value": n * T / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
-            "sample": "%d utterances x T=%d x D=%d float64 through the reference's own paramgen.mlpg "
-                      "(numpy + bandmat Cython, compiled unmodified into oracle/_ref), Python loop over utterances, "
-                      "%.1f s on 1 core of %d" % (n, T, D, dt, os.cpu_count()),
+            "sample": "%d calls of the reference's own paramgen.mlpg (numpy + bandmat Cython, compiled unmodified into "
+                      "oracle/_ref) over a pool of %d distinct utterances of T=%d x D=%d float64, Python loop over "
+                      "utterances, %.1f s on 1 core of %d" % (n, len(pool), T, D, dt, os.cpu_count()),
         }
         # the same on many cores (independent processes; the reference itself has no threading)
         try:
             cores = max(1, min(os.cpu_count() or 1, 64))
-            per_proc = max(2, int(0.2 * n))
+            per_proc = max(2, min(24, int(0.2 * n)))
             rate, wall = _reference_pool(per_proc, T, D, cores, timeout=max(60.0, 6 * seconds))
             res["pool"] = {"value": rate, "unit": "frames/s", "cores": cores,
-                           "sample": "%d processes x %d utterances each, %.1f s wall" % (cores, per_proc, wall)}
+                           "sample": "%d processes x %d distinct utterances each, %.1f s wall" % (cores, per_proc, wall)}
         except Exception as e:  # the single-core figure is the reported baseline
             res["pool"] = {"error": str(e)[:200]}
         return res
-    m = rng.randn(4, T, D)
-    v = rng.rand(4, T, D) + 0.1
+    m = rng.randn(16, T, D)
+    v = rng.rand(16, T, D) + 0.1
     t0 = time.perf_counter()
-    O.mlpg_batch(m, v, WINDOWS)
+    O.mlpg_batch(m[:4], v[:4], WINDOWS)
     per4 = time.perf_counter() - t0
-    n = int(max(8, min(4096, seconds / max(per4 / 4, 1e-6))))
-    n -= n % 4
-    reps = n // 4
+    n = int(max(16, min(4096, seconds / max(per4 / 4, 1e-6))))
+    n -= n % 16
+    reps = n // 16
     t0 = time.perf_counter()
     for _ in range(reps):
         O.mlpg_batch(m, v, WINDOWS)
@@ -147,110 +151,210 @@ def cpu_baseline(T, D, seconds):
         "unit": "frames/s",
         "cores": 1,
         "kind": "port",
-        "sample": "%d utterances x T=%d x D=%d float64 through oracle/mlpg_oracle.c (C restatement of "
-                  "paramgen.mlpg, bit-exact vs the reference), %.1f s on 1 core of %d" % (n, T, D, dt, os.cpu_count()),
+        "sample": "%d calls over 16 distinct utterances of T=%d x D=%d float64 through oracle/mlpg_oracle.c (C restatement "
+                  "of paramgen.mlpg, bit-exact vs the reference), %.1f s on 1 core of %d" % (n, T, D, dt, os.cpu_count()),
     }
 
 
 def measured_traffic(B, T, sd, algo):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (profiles/traffic.json),
-    if it was taken on this exact workload; bench.py cannot run rocprofv3 on itself."""
+    if it was taken on this exact workload and kernel; bench.py cannot run rocprofv3 on itself."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
         w = t["workload"]
-        if (w["batch_per_gpu"], w["frames"], w["static_dim"]) == (B, T, sd) and algo in (0, 2):
+        if (w["batch_per_gpu"], w["frames"], w["static_dim"]) == (B, T, sd) and algo in t.get("algos", (0, 2)):
             return float(t["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
     return None
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks ourselves."""
+    import subprocess
+    if not args.dry_run_cpu:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d requested but this node has %d GPU(s); refusing to run a smaller job "
+                     "under that label" % (args.gpus, have))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-    from nnmnkwii_amd import _hip
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch exactly one rank per GPU" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    dry = args.dry_run_cpu
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     B, T, sd = args.batch, args.frames, args.static_dim
     D = 3 * sd
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    means = torch.randn(B, T, D, dtype=torch.float64, device=dev, generator=gen)
-    variances = torch.rand(B, T, D, dtype=torch.float64, device=dev, generator=gen) + 0.1
+    if dry:
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo")
+        out = status = None
 
-    def step():
-        return _hip.forward(means, variances, WINDOWS, None, algo=args.algo, want_status=True)
+        def step():
+            return None, None
 
-    for _ in range(args.warmup):
-        out, status = step()
-    torch.cuda.synchronize(dev)
+        def sync():
+            pass
+    else:
+        from nnmnkwii_amd import _hip
+        if torch.cuda.device_count() <= local_rank:
+            sys.exit("bench.py: rank %d has no GPU (device_count = %d)" % (rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        means = torch.randn(B, T, D, dtype=torch.float64, device=dev, generator=gen)
+        variances = torch.rand(B, T, D, dtype=torch.float64, device=dev, generator=gen) + 0.1
+
+        def step():
+            return _hip.forward(means, variances, WINDOWS, None, algo=args.algo, want_status=True)
+
+        def sync():
+            torch.cuda.synchronize(dev)
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if dry:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    ev0.record()
-    for k in range(args.steps):
+    def timed(nsteps):
+        """(wall seconds, ms per launch from one HIP-event pair on the launch stream) for nsteps back-to-back steps."""
+        o = st = None
+        if dry:
+            t0 = time.perf_counter()
+            for _ in range(nsteps):
+                o, st = step()
+            return time.perf_counter() - t0, 0.0, o, st
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(nsteps):
+            o, st = step()
+        ev1.record()
+        sync()
+        return time.perf_counter() - t0, float(ev0.elapsed_time(ev1)) / nsteps, o, st
+
+    for _ in range(args.warmup):
         out, status = step()
-    ev1.record()
-    torch.cuda.synchronize(dev)
+    sync()
+
+    # in-run single-GPU leg (N > 1 only): rank 0 alone, the others idle, same kernel and batch
+    solo = None
+    if world > 1:
+        barrier()
+        if rank == 0:
+            el, _, _, _ = timed(args.steps)
+            solo = B * T * args.steps / el
+        barrier()
+
     barrier()
-    elapsed = time.perf_counter() - t0
+    sync()
+    elapsed, kern_ms, out, status = timed(args.steps)
+    barrier()
 
-    # average launch duration from ONE pair of HIP events around the K back-to-back launches, recorded on the
-    # stream the kernel is launched on (per-launch event pairs add ~20 us of command-processor time each)
-    kern_ms = float(ev0.elapsed_time(ev1)) / args.steps
-    if not args.no_check:
-        assert int(status.abs().max().item()) == 0, "a system was not positive definite"
-    elif os.environ.get("MLPG_DUMP_STATUS"):
-        st = status.cpu().numpy()[:64 * 8].reshape(64, 8)
-        print("phase cycles (setup, wait-tiles, lds->regs, dma-issue, assembly, solve, status, output), mean over 64 WGs:",
-              [int(x) for x in st.mean(0)], "sum", int(st.mean(0).sum()), file=sys.stderr)
+    if not dry:
+        if not args.no_check:
+            assert int(status.abs().max().item()) == 0, "a system was not positive definite (or an internal wait timed out)"
+        elif os.environ.get("MLPG_DUMP_STATUS"):
+            if os.environ.get("MLPG_DUMP_STATUS") == "trace":
+                tr = status.cpu().numpy()[:3840 * 4].reshape(-1, 4).astype(np.int64)
+                t0 = tr[:, 0]
+                t0 = (t0 - t0.min()) & 0x3FFFFFFF
+                order = np.argsort(t0, kind="stable")
+                print("strip trace (100 MHz ticks = 10 ns): item start times, then durations [arrived, level3 done, end]", file=sys.stderr)
+                print("  start histogram (per 500 ticks = 5 us):", np.bincount((t0 // 500).astype(int)).tolist(), file=sys.stderr)
+                print("  end   histogram (per 500 ticks = 5 us):", np.bincount(((t0 + tr[:, 3]) // 500).astype(int)).tolist(), file=sys.stderr)
+                for nm, col in (("to-arrived", 1), ("to-level3", 2), ("to-end", 3)):
+                    v = tr[:, col]
+                    print("  %-10s median %d  p10 %d  p90 %d  max %d" % (nm, np.median(v), np.percentile(v, 10), np.percentile(v, 90), v.max()), file=sys.stderr)
+                # per utterance: spread of the start times of its 16 strips
+                st_ = t0[:3840 // 16 * 16].reshape(-1, 16)
+                print("  start spread within an utterance (ticks): median %d  p90 %d  max %d" % (
+                    np.median(st_.max(1) - st_.min(1)), np.percentile(st_.max(1) - st_.min(1), 90), (st_.max(1) - st_.min(1)).max()), file=sys.stderr)
+                print("  first 40 items in start order (start, arrived, l3, end):", tr[order[:40]].tolist(), file=sys.stderr)
+            elif os.environ.get("MLPG_DUMP_STATUS") == "strip":
+                st = status.cpu().numpy()[:8 * 16 * 16].reshape(8, 16, 16)
+                names = "claim assemble eliminate barrier level2 publish poll barrier l3-stage l3-sweep l2-back barrier backsub store l3-first-read l3-row-loop".split()
+                mean = st.reshape(-1, 16).mean(0)
+                print("strip phase cycles of wavefront 0, mean over 8 utterances x 16 strips:",
+                      {n: int(x) for n, x in zip(names, mean)}, "sum", int(mean[:14].sum()), file=sys.stderr)
+                print("  poll cycles by strip index:", [int(x) for x in st[:, :, 6].mean(0)], file=sys.stderr)
+                for k, n in enumerate(names):
+                    print("  %-10s by strip: %s" % (n, [int(x) for x in st[:, :, k].mean(0)]), file=sys.stderr)
 
+            else:
+                st = status.cpu().numpy()[:64 * 8].reshape(64, 8)
+                print("phase cycles (setup, wait-tiles, lds->regs, dma-issue, assembly, solve, status, output), mean over 64 WGs:",
+                      [int(x) for x in st.mean(0)], "sum", int(st.mean(0).sum()), file=sys.stderr)
+
+    per_rank = [elapsed]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
+    elapsed = max(per_rank)
 
     gather_ms = None
-    if args.gather and world > 1:
+    if args.gather and world > 1 and not dry:
         full = torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=dev)
         dist.all_gather_into_tensor(full, out)
-        torch.cuda.synchronize(dev)
+        sync()
         barrier()
         g0 = time.perf_counter()
         dist.all_gather_into_tensor(full, out)
-        torch.cuda.synchronize(dev)
+        sync()
         gather_ms = (time.perf_counter() - g0) * 1e3
 
+    # a longer steady-state leg (informational): the driver's --steps 20 is a ~4 ms region
+    steady_ms = None
+    if rank == 0 and not dry:
+        _, steady_ms, _, _ = timed(max(200, args.steps))
+
     if rank == 0:
-        # parity spot check outside the timed region (oracle = checker only)
-        from oracle import mlpg as O
-        O.build()
-        yo = O.mlpg(means[0].cpu().numpy(), variances[0].cpu().numpy(), WINDOWS)
-        err = float(np.abs(out[0].cpu().numpy() - yo).max() / np.abs(yo).max())
-        if not args.no_check:
-            assert err < 1e-9, err
+        err = None
+        if not dry:
+            # parity spot check outside the timed region (oracle = checker only)
+            from oracle import mlpg as O
+            O.build()
+            yo = O.mlpg(means[0].cpu().numpy(), variances[0].cpu().numpy(), WINDOWS)
+            err = float(np.abs(out[0].cpu().numpy() - yo).max() / np.abs(yo).max())
+            if not args.no_check:
+                assert err < 1e-9, err
 
         frames = world * B * T * args.steps
         alg_bytes = 56.0 * sd * B * T            # SURVEY 8(d): 56 B per (frame, static dim) per launch
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms else None
+        algo_names = {0: "auto", 1: "generic", 2: "wave-per-system", 3: "strip"}
         res = {
             "metric": "MLPG frames/sec (batch, 60-dim mgc x3 windows)",
             "value": frames / elapsed,
@@ -269,6 +373,7 @@ def main():
                             "(%d columns), float64, per-frame variances, std 3 windows; mlpg_hip_forward via C ABI"
                             % (B, T, sd, D),
                 "batch_per_gpu": B, "frames": T, "static_dim": sd, "algo": args.algo,
+                "kernel": algo_names.get(args.algo, "?") + (" (= strip at this shape)" if args.algo == 0 and sd >= 16 else ""),
                 "parallelism": "batch-sharded x%d, no data-path collective" % world,
             },
             "roofline": {
@@ -276,17 +381,24 @@ def main():
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "traffic": measured_traffic(B, T, sd, args.algo),
                 "traffic_unit": "bytes/launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/traffic.json)",
                 "kernel_ms": kern_ms,
+                "kernel_ms_steady": steady_ms,
                 "algorithmic_bytes": alg_bytes,
             },
             "parity_rel_err_vs_oracle": err,
+            "per_rank_ms_per_step": [x / args.steps * 1e3 for x in per_rank],
         }
+        if dry:
+            res["dry_run"] = True
+        if solo is not None:
+            res["in_run_single_gpu"] = {"value": solo, "unit": "frames/s",
+                                        "weak_scaling_efficiency": (frames / elapsed) / (world * solo)}
         if gather_ms is not None:
             res["allgather_ms"] = gather_ms
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dry:
             res["cpu_baseline"] = cpu_baseline(T, D, args.cpu_seconds)
         print(json.dumps(res), flush=True)
     if world > 1:

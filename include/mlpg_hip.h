@@ -54,9 +54,10 @@ extern "C" {
 #define MLPG_HIP_VAR_UNIT 2    /* var == NULL: unit variances (_mlpg.py:297-373) */
 
 /* kernel selection for the forward/backward solves */
-#define MLPG_HIP_ALGO_AUTO 0    /* wave-per-system when it applies, else generic */
+#define MLPG_HIP_ALGO_AUTO 0    /* strip kernel for wide streams, wave-per-system for narrow, else generic */
 #define MLPG_HIP_ALGO_GENERIC 1 /* thread-per-system, factor in HBM scratch       */
 #define MLPG_HIP_ALGO_WAVE 2    /* wave-per-system, factor in registers           */
+#define MLPG_HIP_ALGO_STRIP 3   /* lane-per-static-dim, wavefront per 16-frame chunk, any T */
 
 int mlpg_hip_abi_version(void);
 const char *mlpg_hip_last_error(void);

@@ -12,9 +12,9 @@ import threading
 import numpy as np
 
 F32, F64 = 0, 1
-ABI_VERSION = 3               # mlpg_hip_abi_version() of the library this binding was written for
+ABI_VERSION = 4               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
-ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE = 0, 1, 2
+ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE, ALGO_STRIP = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NNMNKWII_AMD_SO selects another build of the same library (kernel experiments); default: the in-tree build

@@ -6,8 +6,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["capi.hip", "mlpg_generic.hip", "mlpg_wave.hip", "mlpg_wave_fwd_f64.hip", "mlpg_wave_fwd_f32.hip",
-           "mlpg_wave_bwd_f64.hip", "mlpg_wave_bwd_f32.hip", "dtw.hip", "dtw_fast.hip", "modspec.hip"]
-HEADERS = ["common.h", "assemble.h", "mlpg_wave_impl.h", os.path.join("..", "..", "include", "mlpg_hip.h")]
+           "mlpg_wave_bwd_f64.hip", "mlpg_wave_bwd_f32.hip", "mlpg_strip.hip", "mlpg_strip_fwd_f64.hip",
+           "mlpg_strip_fwd_f32.hip", "mlpg_strip_bwd_f64.hip", "mlpg_strip_bwd_f32.hip", "dtw.hip", "dtw_fast.hip", "modspec.hip"]
+HEADERS = ["common.h", "assemble.h", "mlpg_wave_impl.h", "mlpg_strip_impl.h", os.path.join("..", "..", "include", "mlpg_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # The DTW kernels must round exactly like the CPU oracle (separate multiply and add); the MLPG
 # kernels are free to fuse multiply-adds.
@@ -30,15 +31,26 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def _headers_of(src):
+    """Headers a source depends on (the two big kernel headers only matter to their own instantiation files)."""
+    hs = [h for h in HEADERS if h not in ("mlpg_wave_impl.h", "mlpg_strip_impl.h")]
+    if src.startswith("mlpg_wave_"):
+        hs.append("mlpg_wave_impl.h")
+    if src.startswith("mlpg_strip_"):
+        hs.append("mlpg_strip_impl.h")
+    return [os.path.join(HERE, h) for h in hs] + [os.path.abspath(__file__)]
+
+
+def build(force=False, verbose=False, only=None):
+    """only: iterable of source-name prefixes to force-rebuild (kernel experiments with MLPG_HIP_EXTRA_FLAGS)."""
     hipcc = _hipcc()
-    hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(HERE, src)
         o = os.path.join(HERE, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
+        forced = force or (only is not None and any(src.startswith(pfx) for pfx in only))
+        if forced or _stale(o, [s] + _headers_of(src)):
             jobs.append([hipcc, "-x", "hip", *FLAGS, *FILE_FLAGS.get(src, ["-ffp-contract=fast"]), *EXTRA, "-c", s, "-o", o])
 
     def run(cmd):
@@ -60,4 +72,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+    print(build(force="--force" in sys.argv, verbose="--quiet" not in sys.argv, only=only or None))

@@ -2,7 +2,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "common.h"
 
@@ -17,28 +19,33 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-// ---- per-device grow-only scratch ------------------------------------------
+// ---- grow-only scratch, one set of buffers per (device, stream) ------------------------------
+// Launches on different streams of one device never share a buffer; a buffer is only ever
+// reused, grown or freed behind work of its own stream.
 namespace {
 constexpr int kMaxDevices = 16, kSlots = 4;
 struct Slot {
   void *ptr = nullptr;
   size_t bytes = 0;
 };
-Slot g_slots[kMaxDevices][kSlots];
+struct StreamScratch {
+  Slot slot[kSlots];
+};
+std::map<std::pair<int, hipStream_t>, StreamScratch> g_scratch;
 std::mutex g_mu;
 }  // namespace
 
-void *scratch(int device, int slot, size_t bytes) {
+void *scratch(int device, hipStream_t stream, int slot, size_t bytes) {
   if (device < 0 || device >= kMaxDevices || slot < 0 || slot >= kSlots) {
     set_error("scratch: bad device/slot %d/%d", device, slot);
     return nullptr;
   }
   std::lock_guard<std::mutex> lk(g_mu);
-  Slot &s = g_slots[device][slot];
+  Slot &s = g_scratch[std::make_pair(device, stream)].slot[slot];
   if (s.bytes >= bytes && s.ptr) return s.ptr;
   if (s.ptr) {
-    // the previous users of this buffer may still be running on some stream
-    (void)hipDeviceSynchronize();
+    // the previous users of this buffer were enqueued on this very stream
+    (void)hipStreamSynchronize(stream);
     (void)hipFree(s.ptr);
     s.ptr = nullptr;
     s.bytes = 0;
@@ -117,6 +124,31 @@ int check_common(int B, int Tmax, int D, int nw) {
   return 0;
 }
 
+// Kernel choice: AUTO = strip kernel for wide streams (static dims on lanes), wave-per-system kernel for narrow
+// ones, generic kernel for window extents > 1 or utterances longer than either supports.
+int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool backward, const Problem &p,
+                   const WinSet &ws, int device) {
+  if (algo < MLPG_HIP_ALGO_AUTO || algo > MLPG_HIP_ALGO_STRIP) {
+    set_error("unknown algo %d", algo);
+    return MLPG_HIP_EINVAL;
+  }
+  if (algo == MLPG_HIP_ALGO_WAVE && !wave_supported(p, ws)) {
+    set_error("MLPG_HIP_ALGO_WAVE does not support this problem (T=%d, half-bandwidth %d)", p.Tmax, ws.q);
+    return MLPG_HIP_EINVAL;
+  }
+  if (algo == MLPG_HIP_ALGO_STRIP && !strip_supported(p, ws)) {
+    set_error("MLPG_HIP_ALGO_STRIP does not support this problem (T=%d, half-bandwidth %d)", p.Tmax, ws.q);
+    return MLPG_HIP_EINVAL;
+  }
+  if (algo == MLPG_HIP_ALGO_AUTO) {
+    if (strip_preferred(p, ws) || (strip_supported(p, ws) && !wave_supported(p, ws))) algo = MLPG_HIP_ALGO_STRIP;
+    else algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
+  }
+  if (algo == MLPG_HIP_ALGO_STRIP) return launch_strip(st, in_dtype, out_dtype, backward, p, ws, device);
+  if (algo == MLPG_HIP_ALGO_WAVE) return launch_wave(st, in_dtype, out_dtype, backward, p, ws, device);
+  return launch_generic(st, in_dtype, out_dtype, backward, p, ws, device);
+}
+
 int solve_entry(int device, void *stream, int in_dtype, int out_dtype, int algo, bool backward, const void *mean,
                 const void *var, int var_mode, const void *grad_out, const int32_t *lengths, int B, int Tmax,
                 int D, int nw, const int32_t *wl, const int32_t *wu, const double *wc, void *out,
@@ -160,13 +192,7 @@ int solve_entry(int device, void *stream, int in_dtype, int out_dtype, int algo,
   p.ld_out = backward ? D : D / nw;
   p.ld_status = D / nw;
   hipStream_t st = (hipStream_t)stream;
-  if (algo == MLPG_HIP_ALGO_WAVE && !wave_supported(p, ws)) {
-    set_error("MLPG_HIP_ALGO_WAVE does not support this problem (T=%d, half-bandwidth %d)", Tmax, ws.q);
-    return MLPG_HIP_EINVAL;
-  }
-  const bool use_wave = algo == MLPG_HIP_ALGO_WAVE || (algo == MLPG_HIP_ALGO_AUTO && wave_supported(p, ws));
-  if (use_wave) return launch_wave(st, in_dtype, out_dtype, backward, p, ws, device);
-  return launch_generic(st, in_dtype, out_dtype, backward, p, ws, device);
+  return dispatch_solve(st, in_dtype, out_dtype, algo, backward, p, ws, device);
 }
 
 // One stream of a multi-stream batch: a column slice [in_col, in_col + nw*sd) of the (B, Tmax, ld_in)
@@ -200,13 +226,7 @@ int stream_entry(int device, hipStream_t st, int dtype, int algo, const void *me
   p.ld_gout = 0;
   p.ld_out = ld_out;
   p.ld_status = ld_status;
-  if (algo == MLPG_HIP_ALGO_WAVE && !wave_supported(p, ws)) {
-    set_error("MLPG_HIP_ALGO_WAVE does not support this stream (T=%d, half-bandwidth %d)", Tmax, ws.q);
-    return MLPG_HIP_EINVAL;
-  }
-  const bool use_wave = algo == MLPG_HIP_ALGO_WAVE || (algo == MLPG_HIP_ALGO_AUTO && wave_supported(p, ws));
-  if (use_wave) return launch_wave(st, dtype, dtype, false, p, ws, device);
-  return launch_generic(st, dtype, dtype, false, p, ws, device);
+  return dispatch_solve(st, dtype, dtype, algo, false, p, ws, device);
 }
 
 }  // namespace
@@ -216,7 +236,7 @@ using namespace mlpg;
 
 extern "C" {
 
-__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 3; }
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 4; }
 
 __attribute__((visibility("default"))) const char *mlpg_hip_last_error(void) { return g_err; }
 
@@ -233,14 +253,13 @@ __attribute__((visibility("default"))) void mlpg_hip_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   int prev = -1;
   (void)hipGetDevice(&prev);
-  for (int d = 0; d < kMaxDevices; ++d)
+  for (auto &kv : g_scratch) {
+    (void)hipSetDevice(kv.first.first);
+    (void)hipDeviceSynchronize();
     for (int s = 0; s < kSlots; ++s)
-      if (g_slots[d][s].ptr) {
-        (void)hipSetDevice(d);
-        (void)hipDeviceSynchronize();
-        (void)hipFree(g_slots[d][s].ptr);
-        g_slots[d][s] = Slot();
-      }
+      if (kv.second.slot[s].ptr) (void)hipFree(kv.second.slot[s].ptr);
+  }
+  g_scratch.clear();
   if (prev >= 0) (void)hipSetDevice(prev);
 }
 

@@ -45,8 +45,9 @@ struct Problem {
 };
 
 void set_error(const char *fmt, ...);
-// Grow-only per-device scratch. Returns nullptr (and sets the error) on failure.
-void *scratch(int device, int slot, size_t bytes);
+// Grow-only scratch, cached per (device, stream, slot): slot 0 generic factor, 1 fastdtw pyramids,
+// 2 generic status, 3 strip records.  Returns nullptr (and sets the error) on failure.
+void *scratch(int device, hipStream_t stream, int slot, size_t bytes);
 
 // launchers (one per translation unit)
 int launch_generic(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
@@ -54,6 +55,10 @@ int launch_generic(hipStream_t s, int dtype, int out_dtype, bool backward, const
 bool wave_supported(const Problem &p, const WinSet &w);
 int launch_wave(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
                 int device);
+bool strip_supported(const Problem &p, const WinSet &w);
+bool strip_preferred(const Problem &p, const WinSet &w);
+int launch_strip(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
+                 int device);
 int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,
                      int ncols, void *dst, long ld_dst);
 int launch_modspec(hipStream_t s, int mode, const double *x, const double *ms, const double *ph, double *out,

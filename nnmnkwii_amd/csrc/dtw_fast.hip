@@ -707,7 +707,7 @@ int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, 
     set_error("fastdtw: Tx=%d, Ty=%d, D=%d, radius=%d needs %zu bytes of LDS (> 160 KiB)", Tx, Ty, D, radius, lds);
     return MLPG_HIP_EINVAL;
   }
-  p.pyr = (double *)scratch(device, 1, sizeof(double) * p.pyr_stride * (size_t)N);
+  p.pyr = (double *)scratch(device, s, 1, sizeof(double) * p.pyr_stride * (size_t)N);
   if (!p.pyr) return MLPG_HIP_ENOMEM;
   MLPG_HIP_CHECK(hipFuncSetAttribute((const void *)fastdtw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));

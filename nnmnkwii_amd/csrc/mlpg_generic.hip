@@ -208,12 +208,12 @@ int launch_q(hipStream_t st, const Problem &p, const WinSet &w, int device) {
   const long S = (long)p.B * p.sd;
   if (S == 0 || p.Tmax == 0) return 0;
   const size_t bytes = sizeof(double) * (size_t)(Q + 2) * (size_t)p.Tmax * (size_t)S;
-  double *sc = (double *)scratch(device, 0, bytes);
+  double *sc = (double *)scratch(device, st, 0, bytes);
   if (!sc) return MLPG_HIP_ENOMEM;
   Problem q = p;
   if (BWD && !q.status) {
     // the epilogue needs to know which systems failed even when the caller does not ask for the status
-    q.status = (int32_t *)scratch(device, 2, sizeof(int32_t) * (size_t)S);
+    q.status = (int32_t *)scratch(device, st, 2, sizeof(int32_t) * (size_t)S);
     if (!q.status) return MLPG_HIP_ENOMEM;
     q.ld_status = p.sd;
   }

@@ -1,0 +1,924 @@
+// Strip MLPG kernels (algo = MLPG_HIP_ALGO_STRIP; the AUTO choice for wide streams).
+//
+// Mapping (the transpose of the wave-per-system kernel in mlpg_wave_impl.h):
+//   lane      = static dim d        (adjacent lanes = adjacent columns of the row-major input:
+//                                    every load/store instruction moves one contiguous run of
+//                                    sd elements of a frame, no LDS transposition)
+//   wavefront = chunk of M = 16 consecutive frames of one utterance
+//   workgroup = strip of W = 4 consecutive chunks (64 frames); two workgroups per CU
+//   an utterance of T frames is ceil(T / 64) strips that run on different CUs.
+// Windows must have extents l, u <= 1 (pentadiagonal P), any T.
+//
+// The solve is a three-level substructured LDL^T (tools/strip_model.py is the executable
+// specification, pinned against the oracle by tests/test_strip_model.py):
+//   level 1 (wavefront, registers): assemble the chunk's rows of P = sum_w W_w^T diag(tau_w) W_w
+//     and b from the frames f0-1 .. f0+16, eliminate the 14 interior frames carrying the two
+//     "left spike" columns that couple the chunk to the previous chunk's last two frames (its
+//     separator), run the elimination on into the chunk's own separator -> 14 numbers per lane;
+//   level 2 (workgroup, LDS): the block-tridiagonal system (2x2 blocks) of the strip's W
+//     separators is eliminated sequentially, lanes = dims in lockstep, carrying the spike block
+//     that couples the strip to the previous strip's last separator -> one 14-number record;
+//   level 3 (utterance, HBM): the strips publish their records (agent-scope write-through
+//     stores + arrival counter), every strip gathers all records of its utterance and runs the
+//     same forward sweep over them; the solution on its own two separators comes out of the sweep
+//     as an affine function of the last separator's, so no factor of the sweep is stored;
+//   back-substitution in the reverse order; trajectory rows stored straight from registers.
+// Edge rules (frames >= T, zeroed dynamic precisions on the first/last mw frames) are
+// wave-uniform in this mapping: interior chunks run a branch- and select-free path.
+//
+// Inter-workgroup protocol (cdna_hip_programming.md G16, placement independent): work items are
+// handed out by an atomic ticket in (utterance, strip) order, so the strips a workgroup waits for
+// are always held by running workgroups (dispatch order is not assumed); record words are stored
+// and loaded with agent scope (sc1), the arrival counter is one relaxed agent-scope atomic per
+// strip, polled by one lane; the control words are zeroed by a memset node ahead of every launch.
+//
+// Reference semantics as in mlpg_wave_impl.h (paramgen/_mlpg.py:92-199, :202-281).
+#pragma once
+#include "assemble.h"
+
+#ifndef MLPG_STRIP_ABLATE
+#define MLPG_STRIP_ABLATE 0  // profiling only: 1 no inter-workgroup level, 2 = 1 + no elimination, 3 = 2 + no assembly arithmetic
+#endif
+#ifdef MLPG_STRIP_TIMING
+#define STRIP_TICK(k)                                                  \
+  do {                                                                 \
+    const long long t_now_ = (long long)__builtin_readcyclecounter(); \
+    tq[k] += t_now_ - t_prev;                                          \
+    t_prev = t_now_;                                                   \
+  } while (0)
+#else
+#define STRIP_TICK(k) do {} while (0)
+#endif
+
+namespace mlpg {
+namespace strip {
+
+constexpr int kW = 4;        // chunks (wavefronts) per strip (workgroup)
+constexpr int kM = 16;       // frames per chunk
+constexpr int kN = kM - 2;   // interior frames of a chunk; frames kN, kN+1 are its separator
+constexpr int kRec = 14;     // doubles per lane in a level-1 / level-2 record
+constexpr int kStage = 6;    // records of level 3 staged in LDS per batch
+constexpr int kPark = 2 * kN;  // doubles per lane that wavefront 0 parks in LDS while it runs levels 2 and 3
+constexpr int kFac = 10;     // doubles per lane kept per eliminated separator of level 2
+constexpr int kSpinLimit = 1 << 20;
+
+// record slots
+enum { rT00, rT01, rT11, rH0, rH1, rD11, rD12, rD22, rF1, rF2, rL11, rL12, rL21, rL22 };
+
+// Control words, one per 128-byte line (32 ints) so that the pollers of one utterance, the ticket draws and the
+// arrivals of other utterances never queue on the same L2 line:
+//   line 0: spin time-outs;  lines 1 .. 8: ticket of work list x;  line 9 + g: arrivals of system group g.
+constexpr int kCtrlLine = 32;
+constexpr int kMaxLists = 8;
+__host__ __device__ inline size_t ctrl_ints(int nsg) { return (size_t)(1 + kMaxLists + nsg) * kCtrlLine; }
+
+struct Args {
+  int *ctrl;
+  double *rec;   // [g][R][kRec][64]
+  int R;         // strips per system group (from Tmax)
+  int ndg, dgw;  // dim groups per utterance, dims per group (<= 64)
+  int nsg;       // system groups: B * ndg
+  int nlists;    // work lists: 8 (system group g belongs to list g % 8, drawn first by the workgroups that run on
+                 // XCD g % 8, so that an utterance's strips share one L2) or 1 (small launches)
+};
+
+constexpr size_t kLdsStage = (size_t)kStage * kRec * 64 * 8;     // level-3 staging; its head doubles as the level-1 records
+constexpr size_t kLdsPark = (size_t)kPark * 64 * 8;
+constexpr size_t kLdsFac = (size_t)(kW - 1) * kFac * 64 * 8;
+constexpr size_t kLdsU = (size_t)(kW + 1) * 2 * 64 * 8;
+constexpr size_t kLdsMisc = 64;
+constexpr size_t kLdsBytes = kLdsStage + kLdsPark + kLdsFac + kLdsU + kLdsMisc;
+static_assert(kW * kRec <= kStage * kRec, "level-1 records must fit the staging area");
+static_assert(kLdsBytes <= 80 * 1024, "two workgroups per CU");
+
+__device__ __forceinline__ double fast_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+  x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+  return x;
+}
+template <typename T>
+__device__ __forceinline__ double tau_of(T v);
+template <>
+__device__ __forceinline__ double tau_of<float>(float v) {
+  return (double)__fdiv_rn(1.0f, v);  // float32 reciprocal, as _mlpg.py:188
+}
+template <>
+__device__ __forceinline__ double tau_of<double>(double v) {
+  return fast_rcp(v);
+}
+
+// ---- 2x2 blocks, one per lane ---------------------------------------------------------------
+struct S2 { double a, b, c; };     // symmetric [a b; b c]
+struct M2 { double a, b, c, d; };  // full      [a b; c d]
+struct V2 { double x, y; };
+
+__device__ __forceinline__ S2 sym_inv(const S2 &E, bool &bad) {
+  const double det = E.a * E.c - E.b * E.b;
+  bad |= (E.a <= 0.0) | (det <= 0.0) | !(det == det);
+  const double idet = fast_rcp(det);
+  return {E.c * idet, -E.b * idet, E.a * idet};
+}
+__device__ __forceinline__ M2 mul_ms(const M2 &L, const S2 &S) {  // L S
+  return {L.a * S.a + L.b * S.b, L.a * S.b + L.b * S.c, L.c * S.a + L.d * S.b, L.c * S.b + L.d * S.c};
+}
+__device__ __forceinline__ M2 mul_sm(const S2 &S, const M2 &V) {  // S V
+  return {S.a * V.a + S.b * V.c, S.a * V.b + S.b * V.d, S.b * V.a + S.c * V.c, S.b * V.b + S.c * V.d};
+}
+__device__ __forceinline__ M2 mul_mm(const M2 &A, const M2 &B) {
+  return {A.a * B.a + A.b * B.c, A.a * B.b + A.b * B.d, A.c * B.a + A.d * B.c, A.c * B.b + A.d * B.d};
+}
+__device__ __forceinline__ S2 mul_mmt_sym(const M2 &A, const M2 &B) {  // A B^T, symmetric by construction
+  return {A.a * B.a + A.b * B.b, A.a * B.c + A.b * B.d, A.c * B.c + A.d * B.d};
+}
+__device__ __forceinline__ S2 mul_mtm_sym(const M2 &A, const M2 &B) {  // A^T B, symmetric by construction
+  return {A.a * B.a + A.c * B.c, A.a * B.b + A.c * B.d, A.b * B.b + A.d * B.d};
+}
+__device__ __forceinline__ V2 mul_mv(const M2 &A, const V2 &v) { return {A.a * v.x + A.b * v.y, A.c * v.x + A.d * v.y}; }
+__device__ __forceinline__ V2 mul_mtv(const M2 &A, const V2 &v) { return {A.a * v.x + A.c * v.y, A.b * v.x + A.d * v.y}; }
+__device__ __forceinline__ V2 mul_sv(const S2 &S, const V2 &v) { return {S.a * v.x + S.b * v.y, S.b * v.x + S.c * v.y}; }
+__device__ __forceinline__ S2 sub(const S2 &A, const S2 &B) { return {A.a - B.a, A.b - B.b, A.c - B.c}; }
+__device__ __forceinline__ S2 add(const S2 &A, const S2 &B) { return {A.a + B.a, A.b + B.b, A.c + B.c}; }
+__device__ __forceinline__ V2 sub(const V2 &A, const V2 &B) { return {A.x - B.x, A.y - B.y}; }
+__device__ __forceinline__ V2 add(const V2 &A, const V2 &B) { return {A.x + B.x, A.y + B.y}; }
+__device__ __forceinline__ M2 neg(const M2 &A) { return {-A.a, -A.b, -A.c, -A.d}; }
+__device__ __forceinline__ M2 transpose(const M2 &A) { return {A.a, A.c, A.b, A.d}; }
+
+// agent-scope (sc1, write-through / L1-bypassing) 8-byte accesses for the records
+__device__ __forceinline__ void st_agent(double *p, double v) {
+  __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// ---- level 1: assembly of one chunk -----------------------------------------------------------
+// Frames f0-1 .. f0+M feed the rows f0 .. f0+M-1.  EDGE = false: every one of those frames is a
+// live frame of every window (mw <= f0-1, f0+M < T-mw): no masks.  mcol / vcol / gcol point at
+// (frame 0, window 0, this lane's dim) of the utterance.
+// The 18 frames of a window are taken in six batches of 3 through two register sets: the loads of
+// batch k+1 are in flight while batch k is accumulated, so that only the first batch's memory latency
+// is exposed (left to itself the compiler issues a window's loads, waits, computes, and only then
+// touches the next window).  Small batches because the accumulators already take 128 registers.
+constexpr int kNB = 6;                // batches per window (even: every window starts in the same register set)
+constexpr int kHB = (kM + 2) / kNB;   // frames per batch
+static_assert(kHB * kNB == kM + 2, "batches must tile the 18 frames");
+
+// Loads go through buffer descriptors: a wave-uniform descriptor (the utterance's rows from the dim group's first
+// column on), the row/window offset in an SGPR (soffset) and this lane's 32-bit byte offset in ONE VGPR -- no
+// per-load 64-bit address arithmetic and no address registers (global_load with 64-bit VGPR addresses costs two VALU
+// instructions and a register pair per load, which is what drove this kernel into scratch).
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+template <typename TIN>
+__device__ __forceinline__ TIN ld_row(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff);
+template <>
+__device__ __forceinline__ double ld_row<double>(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, loff, soff, 0);
+  return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+}
+template <>
+__device__ __forceinline__ float ld_row<float>(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, loff, soff, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
+  // the base must be wave-uniform PROVABLY (a lane-tainted descriptor is wrapped in a waterfall loop per load)
+  const unsigned long long u = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+
+// EDGE: a dead frame of the window (outside [lo, hi)) is loaded from the nearest live frame instead -- a finite
+// variance -- and enters with weight 0 (accumulate()), so that padding values never meet the reciprocal.
+template <typename TIN, bool BWD, int VM, bool EDGE, int H>
+__device__ __forceinline__ void load_batch(TIN (&rv)[kHB], TIN (&rm)[kHB], __amdgpu_buffer_rsrc_t mrs,
+                                           __amdgpu_buffer_rsrc_t vrs, unsigned woff, unsigned loff, unsigned ldi_bytes,
+                                           int f0, int lo, int hi) {
+#pragma unroll
+  for (int q = 0; q < kHB; ++q) {
+    int t = f0 + H * kHB + q - 1;
+    if (EDGE) t = t < lo ? lo : (t >= hi ? hi - 1 : t);
+    const unsigned soff = (unsigned)t * ldi_bytes + woff;
+    if (VM == MLPG_HIP_VAR_FRAME) rv[q] = ld_row<TIN>(vrs, soff, loff);
+    if (!BWD) rm[q] = ld_row<TIN>(mrs, soff, loff);
+  }
+}
+
+struct WinCoef {
+  double cm, c0, cp, c00, cpp, cmm, cp0, c0m, cpm, tau_glob;
+  int w;
+};
+
+template <typename TIN, bool BWD, int VM, bool EDGE, int H>
+__device__ __forceinline__ void accumulate(const TIN (&rv)[kHB], const TIN (&rm)[kHB], const WinCoef &k, int f0, int lo,
+                                           int hi, double (&Pd)[kM], double (&P1)[kM], double (&P2)[kM],
+                                           double (&rhs)[kM], double &ca, double &cb, double &cc) {
+#pragma unroll
+  for (int q = 0; q < kHB; ++q) {
+    const int i = H * kHB + q - 1;  // frame f0 + i, compile-time
+    const int t = f0 + i;
+    double tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(rv[q]) : k.tau_glob;
+    if (MLPG_STRIP_ABLATE >= 3) {
+      if (i >= 0 && i < kM) { Pd[i] += VM == MLPG_HIP_VAR_FRAME ? (double)rv[q] : 1.0; if (!BWD) rhs[i] += (double)rm[q]; }
+      continue;
+    }
+    if (EDGE) tau *= (t >= lo && t < hi) ? 1.0 : 0.0;  // wave-uniform weight (a scalar select, no branch, no mask)
+    double tm = 0.0;
+    if (!BWD) tm = tau * (double)rm[q];
+    if (i >= 0 && i < kM) {  // row f = t
+      Pd[i] += k.c00 * tau;
+      P1[i] += k.cp0 * tau;
+      if (!BWD) rhs[i] += k.c0 * tm;
+    }
+    if (i + 1 >= 0 && i + 1 < kM) {  // row f = t+1
+      Pd[i + 1] += k.cpp * tau;
+      if (!BWD) rhs[i + 1] += k.cp * tm;
+    }
+    if (i - 1 >= 0 && i - 1 < kM) {  // row f = t-1
+      Pd[i - 1] += k.cmm * tau;
+      P1[i - 1] += k.c0m * tau;
+      P2[i - 1] += k.cpm * tau;
+      if (!BWD) rhs[i - 1] += k.cm * tm;
+    }
+    // coupling of the chunk's first two rows to the previous chunk's separator:
+    // ca = P[f0, f0-2], cb = P[f0, f0-1], cc = P[f0+1, f0-1]
+    if (i == -1) {
+      ca += k.cpm * tau;
+      cb += k.cp0 * tau;
+    }
+    if (i == 0) {
+      cb += k.c0m * tau;
+      cc += k.cpm * tau;
+    }
+  }
+}
+
+template <typename TIN, int VM>
+__device__ __forceinline__ WinCoef win_coef(const WinSet &ws, int w, const TIN *vglob, int sd) {
+  const int l = ws.l[w], u = ws.u[w];
+  const double *cw = ws.c + ws.off[w];
+  WinCoef k;
+  k.cm = l ? cw[0] : 0.0;  // W[t,t-1], W[t,t], W[t,t+1]
+  k.c0 = cw[l];
+  k.cp = u ? cw[l + 1] : 0.0;
+  k.c00 = k.c0 * k.c0; k.cpp = k.cp * k.cp; k.cmm = k.cm * k.cm;
+  k.cp0 = k.cp * k.c0; k.c0m = k.c0 * k.cm; k.cpm = k.cp * k.cm;
+  k.tau_glob = 1.0;
+  if (VM == MLPG_HIP_VAR_GLOBAL) k.tau_glob = tau_of<TIN>(vglob[w * sd]);
+  k.w = w;
+  return k;
+}
+
+template <typename TIN, bool BWD, int VM, bool EDGE>
+__device__ __forceinline__ void assemble(__amdgpu_buffer_rsrc_t mrs, __amdgpu_buffer_rsrc_t vrs,
+                                         __amdgpu_buffer_rsrc_t grs, const TIN *__restrict__ vglob, unsigned loff,
+                                         long ldi, long ldg, int sd, int f0, int T, int Tmax, const WinSet &ws,
+                                         double (&Pd)[kM], double (&P1)[kM], double (&P2)[kM], double (&rhs)[kM],
+                                         double &ca, double &cb, double &cc) {
+#pragma unroll
+  for (int i = 0; i < kM; ++i) Pd[i] = P1[i] = P2[i] = rhs[i] = 0.0;
+  ca = cb = cc = 0.0;
+  const int mw = ws.mw, nw = ws.nw;
+  const unsigned ldi_bytes = (unsigned)ldi * (unsigned)sizeof(TIN), win_bytes = (unsigned)sd * (unsigned)sizeof(TIN);
+  // live frames of a window: [0, T) for the static window, [mw, T - mw) for the dynamic ones (none if mw == 0:
+  // Python's precisions[-0:] = 0 slice, _mlpg.py:191-193).  The caller guarantees f0 < T.
+  auto live_lo = [&](int w) { return w ? mw : 0; };
+  auto live_hi = [&](int w) { return w ? (mw != 0 && T - mw > mw ? T - mw : mw) : T; };  // hi == lo: nothing live
+  TIN rvA[kHB], rmA[kHB], rvB[kHB], rmB[kHB];
+  // a window without live frames (hi == lo) still loads (clamped to frame lo, which exists: lo < T) and weighs 0
+  auto clo = [&](int w) { const int l_ = live_lo(w); return l_ < T ? l_ : T - 1; };
+  auto chi = [&](int w) { const int h_ = live_hi(w), l_ = clo(w); return h_ > l_ ? h_ : l_ + 1; };
+  load_batch<TIN, BWD, VM, EDGE, 0>(rvA, rmA, mrs, vrs, 0u, loff, ldi_bytes, f0, clo(0), chi(0));
+  if (BWD) {
+#pragma unroll
+    for (int i = 0; i < kM; ++i) {
+      int t = f0 + i;
+      if (EDGE) t = t >= T ? T - 1 : t;
+      rhs[i] = (double)ld_row<TIN>(grs, (unsigned)t * (unsigned)ldg * (unsigned)sizeof(TIN), loff);  // rows >= T are reset below
+    }
+  }
+  for (int w = 0; w < nw; ++w) {
+    const WinCoef k = win_coef<TIN, VM>(ws, w, vglob, sd);
+    const unsigned woff = (unsigned)w * win_bytes;
+    const int lo = live_lo(w), hi = live_hi(w), cl = clo(w), ch = chi(w);
+    // the six batches alternate between the two register sets; the window ends with the next window's batch 0 in
+    // flight in set A.  sched_barrier pins the issue order: next batch's loads, then this batch's arithmetic.
+#define STRIP_STEP(H, RVX, RMX, RVY, RMY)                                                                      \
+    load_batch<TIN, BWD, VM, EDGE, (H) + 1>(RVY, RMY, mrs, vrs, woff, loff, ldi_bytes, f0, cl, ch);             \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    accumulate<TIN, BWD, VM, EDGE, (H)>(RVX, RMX, k, f0, lo, hi, Pd, P1, P2, rhs, ca, cb, cc);                  \
+    __builtin_amdgcn_sched_barrier(0);
+    STRIP_STEP(0, rvA, rmA, rvB, rmB)
+    STRIP_STEP(1, rvB, rmB, rvA, rmA)
+    STRIP_STEP(2, rvA, rmA, rvB, rmB)
+    STRIP_STEP(3, rvB, rmB, rvA, rmA)
+    STRIP_STEP(4, rvA, rmA, rvB, rmB)
+#undef STRIP_STEP
+    if (w + 1 < nw) load_batch<TIN, BWD, VM, EDGE, 0>(rvA, rmA, mrs, vrs, woff + win_bytes, loff, ldi_bytes, f0, clo(w + 1), chi(w + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    accumulate<TIN, BWD, VM, EDGE, 5>(rvB, rmB, k, f0, lo, hi, Pd, P1, P2, rhs, ca, cb, cc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (EDGE) {
+    // matrix edges: rows >= T are identity rows, entries that would leave the T x T matrix vanish
+#pragma unroll
+    for (int i = 0; i < kM; ++i) {
+      const int f = f0 + i;
+      if (f >= T) {
+        Pd[i] = 1.0;
+        P1[i] = P2[i] = rhs[i] = 0.0;
+      } else {
+        if (f + 1 >= T) P1[i] = 0.0;
+        if (f + 2 >= T) P2[i] = 0.0;
+      }
+    }
+    if (f0 == 0 || f0 >= T) ca = cb = cc = 0.0;
+    else if (f0 + 1 >= T) cc = 0.0;
+  }
+}
+
+// ---- level 1: interior elimination (as solve_chunk of mlpg_wave_impl.h, without the lane shuffles) ----
+// On return Pd/P1/P2/rhs[0..kN) hold 1/d, l1, l2, g; rec[] the chunk's Schur data.
+__device__ __forceinline__ bool eliminate(double (&Pd)[kM], double (&P1)[kM], double (&P2)[kM], double (&rhs)[kM],
+                                          double ca, double cb, double cc, double (&rec)[kRec]) {
+  bool bad = false;
+  double t00 = 0.0, t01 = 0.0, t11 = 0.0, h0 = 0.0, h1 = 0.0;
+  double g1 = 0.0, g2 = 0.0, va1 = 0.0, va2 = 0.0, vb1 = 0.0, vb2 = 0.0;
+  double l1p = 0.0, l2p = 0.0, l2pp = 0.0;
+#pragma unroll
+  for (int i = 0; i < kN; ++i) {
+    const double dd = Pd[i];
+    bad |= !(dd > 0.0);
+    const double dinv = fast_rcp(dd);
+    const double e1 = P1[i], e2 = P2[i];
+    const double l1 = e1 * dinv, l2 = e2 * dinv;
+    Pd[i + 1] -= l1 * e1;
+    P1[i + 1] -= l2 * e1;
+    Pd[i + 2] -= l2 * e2;
+    const double gi = rhs[i] - l1p * g1 - l2pp * g2;
+    const double ba = (i == 0) ? ca : 0.0;
+    const double bb = (i == 0) ? cb : ((i == 1) ? cc : 0.0);
+    const double va = ba - l1p * va1 - l2pp * va2;
+    const double vb = bb - l1p * vb1 - l2pp * vb2;
+    const double wa = va * dinv, wb = vb * dinv;
+    t00 += wa * va;
+    t01 += wa * vb;
+    t11 += wb * vb;
+    h0 += wa * gi;
+    h1 += wb * gi;
+    Pd[i] = dinv;
+    P1[i] = l1;
+    P2[i] = l2;
+    rhs[i] = gi;
+    g2 = g1; g1 = gi;
+    va2 = va1; va1 = va;
+    vb2 = vb1; vb1 = vb;
+    l2pp = l2p; l2p = l2; l1p = l1;
+    // the recurrence is sequential; letting the scheduler interleave the frames only inflates the live set
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  rec[rT00] = t00; rec[rT01] = t01; rec[rT11] = t11; rec[rH0] = h0; rec[rH1] = h1;
+  rec[rD11] = Pd[kN]; rec[rD12] = P1[kN]; rec[rD22] = Pd[kN + 1];
+  rec[rF1] = rhs[kN] - (l1p * g1 + l2pp * g2);
+  rec[rF2] = rhs[kN + 1] - l2p * g1;
+  rec[rL11] = -(l1p * va1 + l2pp * va2);
+  rec[rL12] = -(l1p * vb1 + l2pp * vb2);
+  rec[rL21] = -(l2p * va1);
+  rec[rL22] = -(l2p * vb1);
+  return bad;
+}
+
+// ---- level 1: back-substitution; on return x[0..kM) is the chunk's solution -------------------
+__device__ __forceinline__ void backsub(const double (&Pd)[kM], const double (&P1)[kM], const double (&P2)[kM],
+                                        double (&rhs)[kM], double ca, double cb, double cc, V2 ul, V2 u) {
+  {
+    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+#pragma unroll
+    for (int i = 0; i < kN; ++i) {
+      const double ba = (i == 0) ? ca : 0.0;
+      const double bb = (i == 0) ? cb : ((i == 1) ? cc : 0.0);
+      const double va = ba - q1 * a1 - q3 * a2;
+      const double vb = bb - q1 * b1 - q3 * b2;
+      rhs[i] -= va * ul.x + vb * ul.y;
+      a2 = a1; a1 = va;
+      b2 = b1; b1 = vb;
+      q3 = q2; q2 = P2[i]; q1 = P1[i];
+    }
+  }
+  double x1 = u.x, x2 = u.y;
+#pragma unroll
+  for (int i = kN - 1; i >= 0; --i) {
+    const double xi = rhs[i] * Pd[i] - P1[i] * x1 - P2[i] * x2;
+    rhs[i] = xi;
+    x2 = x1;
+    x1 = xi;
+  }
+  rhs[kN] = u.x;
+  rhs[kN + 1] = u.y;
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------
+template <typename TIN, typename TOUT, bool BWD, int VM>
+__global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws, Args a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double *lds_rec = (double *)smem;                                  // [kW][kRec][64]   (level 1 -> 2)
+  double *lds_stage = (double *)smem;                                // [kStage][kRec][64] (level 3), same bytes
+  double *lds_park = (double *)(smem + kLdsStage);                   // [kPark][64]: g and l2 of wavefront 0's chunk during levels 2-3
+  double *lds_fac = (double *)(smem + kLdsStage + kLdsPark);         // [kW-1][kFac][64]
+  double *lds_u = (double *)(smem + kLdsStage + kLdsPark + kLdsFac); // [kW+1][2][64]: slot j+1 = separator j, slot 0 = previous strip's
+  int *lds_misc = (int *)(smem + kLdsStage + kLdsPark + kLdsFac + kLdsU);  // [0] item, [1] poll result
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+#ifdef MLPG_STRIP_TIMING
+  // claim, assemble, eliminate, barrier, level 2, publish, poll, barrier, level-3 staging, level-3 sweep, level-2 backsub, barrier, backsub, store
+  long long tq[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_prev = (long long)__builtin_readcyclecounter();
+#endif
+  // ---- work items: (system group, strip), handed out by atomic tickets in that order, one list per XCD.
+  // A workgroup draws from the list of the XCD it runs on (HW_REG_XCC_ID) until that list is empty, then helps
+  // with the other lists: which workgroup runs which item never matters for the result (all inter-workgroup
+  // traffic is agent scope), only for speed.
+  const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (kMaxLists - 1);  // hwreg(HW_REG_XCC_ID, 0, 4)
+  const int R = a.R;
+  auto body = [&](const int g, const int r) __attribute__((always_inline)) {
+  const int b = g / a.ndg, dg = g - b * a.ndg;
+  const int sd = p.sd, Tmax = p.Tmax;
+  const long ldi = p.ld_in, ldg = p.ld_gout, ldo = p.ld_out;
+  int T = p.lengths ? p.lengths[b] : Tmax;
+  T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
+  const int Ract = (T + kW * kM - 1) / (kW * kM);  // strips of this utterance that hold live frames
+  const bool xwg = MLPG_STRIP_ABLATE ? false : Ract > 1;  // the utterance spans several strips: level 3 runs
+  const int d0 = dg * a.dgw;
+  const int nd = sd - d0 < a.dgw ? sd - d0 : a.dgw;
+  const bool lane_ok = lane < nd;
+  const int d = d0 + (lane_ok ? lane : nd - 1);  // idle lanes shadow the group's last dim (never stored)
+  const int f0 = (r * kW + wv) * kM;
+  const int nw = ws.nw, mw = ws.mw;
+
+  TOUT *out_b = (TOUT *)p.out + (size_t)b * Tmax * ldo;
+
+  if (r >= Ract) {
+    // nothing but padding frames here: zero-fill this chunk's rows
+    if (lane_ok) {
+      for (int i = 0; i < kM; ++i) {
+        const int t = f0 + i;
+        if (t >= Tmax) break;
+        if (!BWD) {
+          out_b[(size_t)t * ldo + d] = (TOUT)0;
+        } else {
+          for (int w = 0; w < nw; ++w) out_b[(size_t)t * ldo + w * sd + d] = (TOUT)0;
+        }
+      }
+    }
+#if !defined(MLPG_STRIP_TIMING) && !defined(MLPG_STRIP_TRACE)
+    if (r == 0 && wv == 0 && lane_ok && p.status) p.status[(size_t)b * p.ld_status + d] = 0;  // T == 0
+#endif
+    return;
+  }
+
+  // wave-uniform bases (utterance b, frame 0, first dim of the group) + this lane's byte offset
+  const unsigned loff = (unsigned)(d - d0) * (unsigned)sizeof(TIN);
+  const __amdgpu_buffer_rsrc_t mrs = make_rsrc(BWD ? (const TIN *)p.out : (const TIN *)p.mean + (size_t)b * Tmax * ldi + d0);
+  const __amdgpu_buffer_rsrc_t vrs =
+      make_rsrc(VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)b * Tmax * ldi + d0 : (const TIN *)p.out);
+  const TIN *vglob = VM == MLPG_HIP_VAR_GLOBAL ? (const TIN *)p.var + d : nullptr;
+  const __amdgpu_buffer_rsrc_t grs = make_rsrc(BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * ldg + d0 : (const TIN *)p.out);
+  const TIN *vcol = VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)b * Tmax * ldi + d : nullptr;  // backward epilogue
+#ifdef MLPG_STRIP_TIMING
+  const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();  // 100 MHz constant clock, comparable across CUs
+#endif
+  STRIP_TICK(0);
+#ifdef MLPG_STRIP_TRACE
+  const long long tr0 = (long long)__builtin_amdgcn_s_memrealtime();
+  long long tr1 = tr0, tr2 = tr0;
+#endif
+  // ---- level 1 ----
+  double Pd[kM], P1[kM], P2[kM], rhs[kM], ca, cb, cc;
+  double rec[kRec];
+  bool bad = false;
+  if (f0 < T) {
+    const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < T - mw;
+    if (interior) assemble<TIN, BWD, VM, false>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, Tmax, ws, Pd, P1, P2, rhs, ca, cb, cc);
+    else assemble<TIN, BWD, VM, true>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, Tmax, ws, Pd, P1, P2, rhs, ca, cb, cc);
+    STRIP_TICK(1);
+    if (MLPG_STRIP_ABLATE < 2) bad = eliminate(Pd, P1, P2, rhs, ca, cb, cc, rec);
+    else {
+#pragma unroll
+      for (int k = 0; k < kRec; ++k) rec[k] = Pd[k] + rhs[k];
+      rec[rD11] = rec[rD22] = 1.0; rec[rD12] = 0.0;
+    }
+  } else {
+    // a chunk of identity rows behind the utterance's end (keeps the strip's separator chain regular)
+#pragma unroll
+    for (int i = 0; i < kM; ++i) { Pd[i] = 1.0; P1[i] = P2[i] = rhs[i] = 0.0; }
+    ca = cb = cc = 0.0;
+#pragma unroll
+    for (int k = 0; k < kRec; ++k) rec[k] = 0.0;
+    rec[rD11] = rec[rD22] = 1.0;
+  }
+  if (bad) rec[rD11] = __builtin_nan("");  // poisons every later level: the system is reported, not solved
+#pragma unroll
+  for (int k = 0; k < kRec; ++k) lds_rec[(wv * kRec + k) * 64 + lane] = rec[k];
+  STRIP_TICK(2);
+  __syncthreads();
+  STRIP_TICK(3);
+
+  // ---- levels 2 and 3.  Wavefront 0 runs the sequential parts (the strip's separators, then the sweep over
+  // the utterance's records); wavefronts 1..3 stage the records for it.  The two roles are separate code paths
+  // that meet at the same barriers.  Wavefront 0 parks g and l2 of its own chunk in LDS for the duration: its
+  // chains then run out of registers, not out of scratch.
+  int timed_out = 0;
+  if (wv == 0) {
+#pragma unroll
+    for (int i = 0; i < kN; ++i) {
+      lds_park[i * 64 + lane] = rhs[i];
+      lds_park[(kN + i) * 64 + lane] = P2[i];
+    }
+    S2 E_s = {1.0, 0.0, 1.0};
+    V2 g_s = {0.0, 0.0};
+    auto R_ = [&](int j, int k) { return lds_rec[(j * kRec + k) * 64 + lane]; };
+    S2 E = {R_(0, rD11), R_(0, rD12), R_(0, rD22)};
+    V2 gg = {R_(0, rF1), R_(0, rF2)};
+    M2 V = {R_(0, rL11), R_(0, rL12), R_(0, rL21), R_(0, rL22)};
+    if (r == 0) V = {0.0, 0.0, 0.0, 0.0};
+    S2 Ts = {R_(0, rT00), R_(0, rT01), R_(0, rT11)};
+    V2 hs = {R_(0, rH0), R_(0, rH1)};
+    if (kW > 1) {
+      E = sub(E, S2{R_(1, rT00), R_(1, rT01), R_(1, rT11)});
+      gg = sub(gg, V2{R_(1, rH0), R_(1, rH1)});
+    }
+    bool bad2 = false;
+#pragma unroll
+    for (int j = 0; j + 1 < kW; ++j) {
+      const S2 Einv = sym_inv(E, bad2);
+      const M2 L = {R_(j + 1, rL11), R_(j + 1, rL12), R_(j + 1, rL21), R_(j + 1, rL22)};
+      const M2 Mn = mul_ms(L, Einv);
+      const M2 EV = mul_sm(Einv, V);
+      const V2 c = mul_sv(Einv, gg);
+      Ts = add(Ts, mul_mtm_sym(V, EV));
+      hs = add(hs, mul_mtv(V, c));
+      double *f = lds_fac + (size_t)j * kFac * 64 + lane;
+      f[0 * 64] = c.x; f[1 * 64] = c.y;
+      f[2 * 64] = EV.a; f[3 * 64] = EV.b; f[4 * 64] = EV.c; f[5 * 64] = EV.d;
+      f[6 * 64] = Mn.a; f[7 * 64] = Mn.b; f[8 * 64] = Mn.c; f[9 * 64] = Mn.d;
+      S2 Dn = {R_(j + 1, rD11), R_(j + 1, rD12), R_(j + 1, rD22)};
+      V2 Fn = {R_(j + 1, rF1), R_(j + 1, rF2)};
+      if (j + 2 < kW) {
+        Dn = sub(Dn, S2{R_(j + 2, rT00), R_(j + 2, rT01), R_(j + 2, rT11)});
+        Fn = sub(Fn, V2{R_(j + 2, rH0), R_(j + 2, rH1)});
+      }
+      E = sub(Dn, mul_mmt_sym(Mn, L));
+      gg = sub(Fn, mul_mv(Mn, gg));
+      V = neg(mul_mm(Mn, V));
+      // the chain is sequential: keep the scheduler from hoisting every later record read to the top (this
+      // wavefront holds its chunk's factor in 112 registers meanwhile)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (bad2) E.a = __builtin_nan("");
+    E_s = E;
+    g_s = gg;
+    STRIP_TICK(4);
+    if (xwg) {
+      // publish the strip's record, then announce it
+      double *rp = a.rec + ((size_t)g * R + r) * (kRec * 64) + lane;
+      st_agent(rp + 0 * 64, E.a); st_agent(rp + 1 * 64, E.b); st_agent(rp + 2 * 64, E.c);
+      st_agent(rp + 3 * 64, gg.x); st_agent(rp + 4 * 64, gg.y);
+      st_agent(rp + 5 * 64, V.a); st_agent(rp + 6 * 64, V.b); st_agent(rp + 7 * 64, V.c); st_agent(rp + 8 * 64, V.d);
+      st_agent(rp + 9 * 64, Ts.a); st_agent(rp + 10 * 64, Ts.b); st_agent(rp + 11 * 64, Ts.c);
+      st_agent(rp + 12 * 64, hs.x); st_agent(rp + 13 * 64, hs.y);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STRIP_TICK(5);
+      if (lane == 0) {
+        int *cnt = a.ctrl + (1 + kMaxLists + g) * kCtrlLine;
+        int spins = 0, ok = 1;
+        if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 < Ract) {
+          do {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > kSpinLimit) { ok = 0; break; }
+          } while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < Ract);
+        }
+        if (!ok) atomicAdd(a.ctrl, 1);
+        lds_misc[1] = ok;
+      }
+      STRIP_TICK(6);
+    }
+    __syncthreads();  // (S2) every wavefront: the utterance's strips have all arrived (or the wait timed out)
+    STRIP_TICK(7);
+#ifdef MLPG_STRIP_TRACE
+    tr1 = (long long)__builtin_amdgcn_s_memrealtime();   // all strips of the utterance have arrived
+#endif
+    // ---- level 3: every strip sweeps all records of its utterance ----
+    V2 sig = {0.0, 0.0}, sprev = {0.0, 0.0};  // solution on this strip's last separator / the previous strip's
+    if (xwg) {
+      timed_out = !__builtin_amdgcn_readfirstlane(lds_misc[1]);
+      {
+      // Two sweeps over the utterance's records, no factor stored: top-down over rows 0 .. r-1 (row j is finalised
+      // when row j+1 is at hand: A_j = E_j - T_{j+1} - Mn_j V_j^T with Mn_j = V_j A_{j-1}^-1, a_j likewise), then
+      // bottom-up over rows R-1 .. r+1 (the Schur complement (S, s) of the rows below row j:
+      // B_j = E_j - T_{j+1} - S, S' = V_j^T B_j^-1 V_j), and the 2-block system of rows r-1 and r in the middle.
+      // The records are staged in exactly that order: rows 0 .. r, then rows R-1 .. r (row r twice; nothing of the
+      // first part if r = 0).  Two register arrays hold the previous and the current record and swap roles every
+      // row: the next record is read from LDS into the previous one's array as soon as that one is used up.
+      const int ntop = r > 0 ? r + 1 : 0, npos = ntop + (Ract - r);
+      S2 Ainv = {0.0, 0.0, 0.0};
+      V2 av = {0.0, 0.0};
+      M2 Mn = {0.0, 0.0, 0.0, 0.0};
+      S2 Sb = {0.0, 0.0, 0.0}, Tn = {0.0, 0.0, 0.0};
+      V2 sb = {0.0, 0.0}, hn = {0.0, 0.0};
+      bool bad3 = false;
+      // the pending row of the top-down sweep (E, g, V of row j until row j+1 arrives)
+      S2 Ej = {0.0, 0.0, 0.0};
+      V2 gj = {0.0, 0.0};
+      M2 Vj = {0.0, 0.0, 0.0, 0.0};
+      for (int p0 = 0; p0 < npos; p0 += kStage) {
+        const int kn = npos - p0 < kStage ? npos - p0 : kStage;
+        __syncthreads();  // this batch is in LDS
+        STRIP_TICK(8);
+        if (!timed_out) {
+#ifndef MLPG_L3_NOPRIO
+          __builtin_amdgcn_s_setprio(2);  // the whole workgroup waits for this chain
+#endif
+          for (int q = 0; q < kn; ++q) {
+            const int pos = p0 + q;
+            double cur[kRec];
+#pragma unroll
+            for (int kk = 0; kk < kRec; ++kk) cur[kk] = lds_stage[(q * kRec + kk) * 64 + lane];
+            const S2 Ek = {cur[0], cur[1], cur[2]};
+            const V2 gk = {cur[3], cur[4]};
+            const M2 Vk = {cur[5], cur[6], cur[7], cur[8]};
+            const S2 Tk = {cur[9], cur[10], cur[11]};
+            const V2 hk = {cur[12], cur[13]};
+            if (pos < ntop) {
+              // top-down: row k = pos has arrived; row j = k-1 is finalised
+              if (pos > 0) {
+                const S2 A = sub(sub(Ej, Tk), mul_mmt_sym(Mn, Vj));  // Mn = 0 for j = 0
+                const V2 aa = sub(sub(gj, hk), mul_mv(Mn, av));
+                Ainv = sym_inv(A, bad3);
+                av = aa;
+                Mn = mul_ms(Vk, Ainv);  // V_{j+1} A_j^-1
+              }
+              Ej = Ek; gj = gk; Vj = Vk;
+            } else {
+              S2 B = sub(sub(Ek, Tn), Sb);
+              V2 bv = sub(sub(gk, hn), sb);
+              if (pos + 1 < npos) {
+                // bottom-up: row j > r
+                const S2 Binv = sym_inv(B, bad3);
+                Sb = mul_mtm_sym(Vk, mul_sm(Binv, Vk));
+                sb = mul_mtv(Vk, mul_sv(Binv, bv));
+                Tn = Tk;
+                hn = hk;
+              } else {
+                // middle: row r
+                if (r > 0) {  // Mn = V_r A_{r-1}^-1 from the top-down sweep
+                  B = sub(B, mul_mmt_sym(Mn, Vk));
+                  bv = sub(bv, mul_mv(Mn, av));
+                }
+                const S2 Binv = sym_inv(B, bad3);
+                sig = mul_sv(Binv, bv);
+                if (r > 0) sprev = sub(mul_sv(Ainv, av), mul_mtv(Mn, sig));  // A^-1 (a - V_r^T sigma_r)
+                if (bad3) sig.x = __builtin_nan("");
+              }
+            }
+          }
+          __builtin_amdgcn_s_setprio(0);
+        }
+        STRIP_TICK(9);
+        __syncthreads();  // done with this batch
+      }
+      }
+    } else {
+      bool bad3 = false;
+      const S2 Ai = sym_inv(E_s, bad3);
+      sig = mul_sv(Ai, g_s);
+      if (bad3) sig.x = __builtin_nan("");
+    }
+
+    // ---- back-substitution of level 2 ----
+    double *up = lds_u + lane;
+    up[0] = sprev.x; up[64] = sprev.y;
+    up[(kW * 2) * 64] = sig.x; up[(kW * 2 + 1) * 64] = sig.y;
+    V2 un = sig;
+#pragma unroll
+    for (int j = kW - 2; j >= 0; --j) {
+      const double *f = lds_fac + (size_t)j * kFac * 64 + lane;
+      const V2 c = {f[0 * 64], f[1 * 64]};
+      const M2 EV = {f[2 * 64], f[3 * 64], f[4 * 64], f[5 * 64]};
+      const M2 Mn = {f[6 * 64], f[7 * 64], f[8 * 64], f[9 * 64]};
+      const V2 uj = sub(sub(c, mul_mv(EV, sprev)), mul_mtv(Mn, un));
+      up[((j + 1) * 2) * 64] = uj.x; up[((j + 1) * 2 + 1) * 64] = uj.y;
+      un = uj;
+    }
+#pragma unroll
+    for (int i = 0; i < kN; ++i) {
+      rhs[i] = lds_park[i * 64 + lane];
+      P2[i] = lds_park[(kN + i) * 64 + lane];
+    }
+  } else {
+    __syncthreads();  // (S2)
+    // wavefronts 1..3: stage the records (kStage rows per batch) through LDS; the loads of batch k+1 are issued into
+    // registers before wavefront 0 starts on batch k, so only the first batch's memory latency is exposed
+    if (xwg) {
+      timed_out = !__builtin_amdgcn_readfirstlane(lds_misc[1]);
+      constexpr int kSlots = (kStage + kW - 2) / (kW - 1);  // rows per stager per batch
+      double sv[kSlots][kRec];
+      // staged record number p: rows 0 .. r, then rows Ract-1 .. r (see the sweep)
+      auto stage_load = [&](int p0, int kn) __attribute__((always_inline)) {
+        const int ntop_ = r > 0 ? r + 1 : 0;
+#pragma unroll
+        for (int sl = 0; sl < kSlots; ++sl) {
+          const int q = (wv - 1) + sl * (kW - 1);
+          if (q < kn && !timed_out) {
+            const int pos = p0 + q;
+            const int row = pos < ntop_ ? pos : Ract - 1 - (pos - ntop_);
+            const double *rp = a.rec + ((size_t)g * R + row) * (kRec * 64) + lane;
+#pragma unroll
+            for (int k = 0; k < kRec; ++k) sv[sl][k] = ld_agent(rp + k * 64);
+          }
+        }
+      };
+      const int ntop = r > 0 ? r + 1 : 0, npos = ntop + (Ract - r);
+      stage_load(0, npos < kStage ? npos : kStage);
+      for (int p0 = 0; p0 < npos; p0 += kStage) {
+        const int kn = npos - p0 < kStage ? npos - p0 : kStage;
+#pragma unroll
+        for (int sl = 0; sl < kSlots; ++sl) {
+          const int q = (wv - 1) + sl * (kW - 1);
+          if (q < kn && !timed_out) {
+#pragma unroll
+            for (int k = 0; k < kRec; ++k) lds_stage[(q * kRec + k) * 64 + lane] = sv[sl][k];
+          }
+        }
+        __syncthreads();  // this batch is in LDS
+        if (p0 + kStage < npos) stage_load(p0 + kStage, npos - p0 - kStage < kStage ? npos - p0 - kStage : kStage);
+        __syncthreads();  // wavefront 0 has read this batch
+      }
+    }
+  }
+  STRIP_TICK(10);
+  __syncthreads();
+  STRIP_TICK(11);
+#ifdef MLPG_STRIP_TRACE
+  tr2 = (long long)__builtin_amdgcn_s_memrealtime();   // level 3 done
+#endif
+
+  // ---- level-1 back-substitution and output ----
+  const V2 ul = {lds_u[(wv * 2) * 64 + lane], lds_u[(wv * 2 + 1) * 64 + lane]};
+  const V2 uo = {lds_u[((wv + 1) * 2) * 64 + lane], lds_u[((wv + 1) * 2 + 1) * 64 + lane]};
+  const double sx = lds_u[(kW * 2) * 64 + lane];
+  const bool sys_bad = !(sx == sx) || !(uo.x == uo.x) || !(ul.x == ul.x);  // NaN: some pivot of this system failed
+  if (MLPG_STRIP_ABLATE < 2) backsub(Pd, P1, P2, rhs, ca, cb, cc, ul, uo);
+  STRIP_TICK(12);
+
+  // status (strip 0 only): the reference's natural-order first failing pivot; -1 = inter-workgroup wait timed
+  // out (never expected), -2 = the blocked elimination broke down although the natural-order scan found no
+  // failing pivot (numerically singular)
+  if (r == 0 && wv == 0) {
+    int status = 0;
+    const int to = __builtin_amdgcn_readfirstlane(timed_out);
+    if (to) status = -1;
+    else if (sys_bad && lane_ok) {
+      const SysView<TIN, BWD> view = make_view<TIN, BWD>(p, ws, b, d, T);
+      status = first_bad_pivot<2, TIN, BWD>(view, ws);
+      if (status == 0) status = -2;
+    }
+#if !defined(MLPG_STRIP_TIMING) && !defined(MLPG_STRIP_TRACE)
+    if (lane_ok && p.status) p.status[(size_t)b * p.ld_status + d] = status;
+#endif
+  }
+  const bool zero_out = sys_bad || timed_out;
+
+#ifndef MLPG_STRIP_TIMING
+  if (!lane_ok) return;
+#endif
+  if (!BWD) {
+#pragma unroll
+    for (int i = 0; i < kM; ++i) {
+      const int t = f0 + i;
+      if (t < Tmax) out_b[(size_t)t * ldo + d] = (t < T && !zero_out) ? (TOUT)rhs[i] : (TOUT)0;
+    }
+  } else {
+    // grad[t, w*sd+d] = tau_w[t] * (cm x[t-1] + c0 x[t] + cp x[t+1])  (paramgen/_mlpg.py:202-281).  The row whose
+    // right neighbour lives in the next chunk is written by that chunk: this wavefront writes rows f0-1 .. f0+14,
+    // and row f0+15 only if it is the utterance's last frame or padding.
+    for (int w = 0; w < nw; ++w) {
+      const int l = ws.l[w], u = ws.u[w];
+      const double *cw = ws.c + ws.off[w];
+      const double cm = l ? cw[0] : 0.0, c0 = cw[l], cp = u ? cw[l + 1] : 0.0;
+      double tau_glob = 1.0;
+      if (VM == MLPG_HIP_VAR_GLOBAL) tau_glob = tau_of<TIN>(vglob[w * sd]);
+      const TIN *vw_col = VM == MLPG_HIP_VAR_FRAME ? vcol + (size_t)w * sd : nullptr;
+      TOUT *ow = out_b + (size_t)w * sd + d;
+#pragma unroll
+      for (int i = -1; i < kM; ++i) {
+        const int t = f0 + i;
+        if (t < 0 || t >= Tmax) continue;
+        if (t >= T) {
+          if (i >= 0) ow[(size_t)t * ldo] = (TOUT)0;
+          continue;
+        }
+        if (i == -1 && f0 >= T) continue;          // (cannot happen in an active chunk; keeps the rule explicit)
+        if (i == kM - 1 && t != T - 1) continue;    // the next chunk writes it
+        const bool lv = w ? (mw != 0 && t >= mw && t < T - mw) : true;
+        double tau = 0.0;
+        if (lv) tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(vw_col[(size_t)t * ldi]) : tau_glob;
+        const double xm = (i == -1) ? ul.x : ((i == 0) ? ul.y : rhs[i > 0 ? i - 1 : 0]);
+        const double x0 = (i == -1) ? ul.y : rhs[i >= 0 ? i : 0];
+        const double xp = (i == kM - 1) ? 0.0 : rhs[i + 1];
+        const double gval = tau * (cm * xm + c0 * x0 + cp * xp);
+        ow[(size_t)t * ldo] = zero_out ? (TOUT)0 : (TOUT)gval;
+      }
+    }
+  }
+#ifdef MLPG_STRIP_TIMING
+  // profiling build only: phase cycle counts of wavefront 0 of strips 0..15 of utterances 0..7 overwrite the head of
+  // the status array (run bench.py --no-check with MLPG_DUMP_STATUS=1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STRIP_TICK(13);
+  if (wv == 0 && lane == 0 && p.status && b < 8 && r < 16 && dg == 0)
+  {
+    for (int k = 0; k < 16; ++k) p.status[(b * 16 + r) * 16 + k] = (int)tq[k];
+  }
+#endif
+#ifdef MLPG_STRIP_TRACE
+  if (wv == 0 && lane == 0 && p.status && (g * R + r) * 4 + 3 < p.B * p.ld_status) {
+    int *tp = p.status + (g * R + r) * 4;
+    tp[0] = (int)(tr0 & 0x3FFFFFFF); tp[1] = (int)(tr1 - tr0); tp[2] = (int)(tr2 - tr0);
+    tp[3] = (int)((long long)__builtin_amdgcn_s_memrealtime() - tr0) | (xcd << 24) | ((blockIdx.x & 0x3FF) << 14 >> 14 << 0) * 0;
+  }
+#endif
+  };  // body
+
+#ifndef MLPG_STRIP_STAGGER
+#define MLPG_STRIP_STAGGER 0  // x 8128 cycles (measured: no gain; kept for experiments)
+#endif
+  // The two workgroups of a CU start together and would load, wait and solve in lockstep (the memory pipe idle
+  // half of the time).  Blocks b and b + 256 of a launch usually share a CU: the second one starts half a period
+  // late, and the offset persists because the periods are equal.  (A wrong guess about placement costs nothing.)
+  if (MLPG_STRIP_STAGGER && (blockIdx.x & 256))
+    for (int q = 0; q < MLPG_STRIP_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
+
+  for (int k = 0; k < a.nlists; ++k) {
+    const int lst = (xcd + k) % a.nlists;
+    const int lim = ((a.nsg - lst + a.nlists - 1) / a.nlists) * R;  // items of this list
+    int *ticket = a.ctrl + (1 + lst) * kCtrlLine;
+    for (;;) {
+      if (tid == 0) {
+        int tk = lim;  // a plain look first: an exhausted list costs no read-modify-write
+        if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lim) tk = atomicAdd(ticket, 1);
+        lds_misc[0] = tk;
+      }
+      __syncthreads();
+      const int tk = __builtin_amdgcn_readfirstlane(lds_misc[0]);
+      if (tk >= lim) break;
+#ifdef MLPG_STRIP_TIMING
+      t_prev = (long long)__builtin_readcyclecounter();
+      for (int q = 0; q < 16; ++q) tq[q] = 0;
+#endif
+      body((tk / R) * a.nlists + lst, tk % R);
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+}
+
+// ---- launcher ------------------------------------------------------------------------------------
+// Scratch layout for one launch: control words, then the records.
+inline size_t ctrl_bytes(int nsg) { return (ctrl_ints(nsg) * sizeof(int) + 255) / 256 * 256; }
+
+template <typename TIN, typename TOUT, bool BWD>
+int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, int ndg, int dgw) {
+  Args a;
+  const int nsg = p.B * ndg;
+  a.ctrl = (int *)scratch_base;
+  a.rec = (double *)((char *)scratch_base + ctrl_bytes(nsg));
+  a.R = R;
+  a.ndg = ndg;
+  a.dgw = dgw;
+  a.nsg = nsg;
+  const long nitems = (long)nsg * R;
+  a.nlists = nitems >= 512 ? kMaxLists : 1;  // a small launch may not put a workgroup on every XCD early: one list
+  MLPG_HIP_CHECK(hipMemsetAsync(a.ctrl, 0, ctrl_ints(nsg) * sizeof(int), st));
+  // persistent workgroups: as many as can be resident (two per CU), each draws items until the lists are empty
+  int dev = 0, ncu = 256;
+  MLPG_HIP_CHECK(hipGetDevice(&dev));
+  MLPG_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  const long grid = nitems < 2L * ncu ? nitems : 2L * ncu;
+  auto go = [&](auto kern) -> int {
+    MLPG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kW * 64), kLdsBytes, st, p, ws, a);
+    MLPG_HIP_CHECK(hipGetLastError());
+    return 0;
+  };
+  switch (p.var_mode) {
+    case MLPG_HIP_VAR_FRAME: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_FRAME>);
+    case MLPG_HIP_VAR_GLOBAL: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_GLOBAL>);
+    default: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_UNIT>);
+  }
+}
+
+}  // namespace strip
+}  // namespace mlpg

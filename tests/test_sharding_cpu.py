@@ -96,3 +96,25 @@ def test_sharded_mlpg_and_dtw_gloo_world2(B):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` without a launcher starts 2 ranks itself (gloo dry run here: no GPU) and reports
+    n_gpus = 2; without --dry-run-cpu it refuses to run on a node with fewer GPUs than asked for."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run-cpu"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["dry_run"] is True and len(res["per_rank_ms_per_step"]) == 2
+    assert res["scaling"] == "weak" and "in_run_single_gpu" in res
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                           capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

@@ -1,0 +1,196 @@
+"""GPU parity tests (-m gpu) of the strip MLPG kernel (algo = MLPG_HIP_ALGO_STRIP: lane per static dim,
+wavefront per 16-frame chunk, strips of one utterance solved across workgroups), through the C ABI,
+against the CPU oracle.  Same tolerances as tests/test_mlpg_gpu.py."""
+import numpy as np
+import pytest
+
+from cases import WINDOW_SETS, c2_utterance
+from oracle import mlpg as O
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-9
+TOL32 = 5e-6
+STRIP_WINDOWS = ("std3", "std2", "asym2", "static", "zero2")   # extents <= 1
+
+
+def rel_err(y, ref):
+    scale = np.abs(ref).max(axis=0, keepdims=True)
+    scale = np.where(scale == 0, 1.0, scale)
+    return float((np.abs(y.astype(np.float64) - ref.astype(np.float64)) / scale).max())
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 15, 16, 17, 33, 63, 64, 65, 66, 127, 128, 129, 200, 257, 513, 1000, 1025, 2048, 4100])
+def test_strip_all_lengths(T):
+    """Every strip count from 1 to 65 (several level-3 batches), ragged lengths, 70 static dims in two dim groups."""
+    import torch
+    from nnmnkwii_amd import _hip
+    for wname in ("std3", "asym2") if T > 600 else STRIP_WINDOWS:
+        windows = WINDOW_SETS[wname]
+        nw = len(windows)
+        B, sd = 3, 70 if T <= 300 else 20
+        rng = np.random.RandomState(T + nw)
+        M_ = rng.randn(B, T, nw * sd)
+        V_ = rng.rand(B, T, nw * sd) + 0.1
+        lengths = np.array([T, max(1, T - 1), max(1, T // 2)], dtype=np.int32)
+        m, v, L = torch.from_numpy(M_).cuda(), torch.from_numpy(V_).cuda(), torch.from_numpy(lengths).cuda()
+        ys, sts = _hip.forward(m, v, windows, L, algo=_hip.ALGO_STRIP)
+        assert int(sts.abs().max()) == 0
+        yo, _, rc = O.mlpg_batch(M_, V_, windows, lengths)
+        assert rc == 0
+        ys = ys.cpu().numpy()
+        assert rel_err(ys.reshape(-1, sd), yo.reshape(-1, sd)) <= TOL64, (wname, T)
+        for b in range(B):
+            assert not ys[b, lengths[b]:].any()
+        # backward: strip == generic (and == oracle in test_strip_backward_vs_reference_goldens)
+        go = torch.from_numpy(rng.randn(B, T, sd)).cuda()
+        gs, _ = _hip.backward(v, go, windows, nw * sd, L, out_dtype=torch.float64, algo=_hip.ALGO_STRIP)
+        gg, _ = _hip.backward(v, go, windows, nw * sd, L, out_dtype=torch.float64, algo=_hip.ALGO_GENERIC)
+        scale = float(gg.abs().max()) + 1e-300
+        assert float((gs - gg).abs().max()) <= 1e-10 * scale, (wname, T)
+        # float32 inputs; global and unit variances vs the oracle
+        M32 = M_.astype(np.float32)
+        m32 = torch.from_numpy(M32).cuda()
+        vg = V_[0, 0].astype(np.float32)
+        a, _ = _hip.forward(m32, torch.from_numpy(vg).cuda(), windows, L, algo=_hip.ALGO_STRIP)
+        ao, _, _ = O.mlpg_batch(M32, vg, windows, lengths)
+        assert rel_err(a.cpu().numpy().reshape(-1, sd), ao.reshape(-1, sd)) <= TOL32, (wname, T)
+        a, _ = _hip.forward(m32, None, windows, L, algo=_hip.ALGO_STRIP)
+        ao, _, _ = O.mlpg_batch(M32, np.ones(nw * sd, dtype=np.float32), windows, lengths)
+        assert rel_err(a.cpu().numpy().reshape(-1, sd), ao.reshape(-1, sd)) <= TOL32, (wname, T)
+
+
+@pytest.mark.parametrize("sd", [1, 5, 16, 25, 60, 63, 64, 65, 128, 130])
+def test_strip_static_dims(sd):
+    import torch
+    from nnmnkwii_amd import _hip
+    windows = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(sd)
+    B, T = 2, 150
+    M_ = rng.randn(B, T, 3 * sd)
+    V_ = rng.rand(B, T, 3 * sd) + 0.1
+    y, st = _hip.forward(torch.from_numpy(M_).cuda(), torch.from_numpy(V_).cuda(), windows, algo=_hip.ALGO_STRIP)
+    yo, _, rc = O.mlpg_batch(M_, V_, windows)
+    assert rc == 0 and int(st.abs().max()) == 0
+    assert rel_err(y.cpu().numpy().reshape(-1, sd), yo.reshape(-1, sd)) <= TOL64
+
+
+def test_strip_config2_utterances(golden):
+    """BASELINE config-2 utterances against the reference's own outputs (goldens), whole batch via AUTO."""
+    import torch
+    from nnmnkwii_amd import _hip
+    ms, vs = zip(*(c2_utterance(b) for b in range(2)))
+    m, v = torch.from_numpy(np.stack(ms)).cuda(), torch.from_numpy(np.stack(vs)).cuda()
+    for algo in (_hip.ALGO_STRIP, _hip.ALGO_AUTO):
+        y, st = _hip.forward(m, v, WINDOW_SETS["std3"], algo=algo)
+        assert int(st.abs().max()) == 0
+        for b in range(2):
+            assert rel_err(y[b].cpu().numpy(), golden["mlpg/c2-utt%d/y" % b]) <= TOL64
+    y32, _ = _hip.forward(m[:1].float().contiguous(), v[:1].float().contiguous(), WINDOW_SETS["std3"], algo=_hip.ALGO_STRIP)
+    assert rel_err(y32[0].cpu().numpy(), golden["mlpg/c2-utt0-f32/y"]) <= 2e-6
+
+
+def test_strip_not_pd_status():
+    """The strip kernel reports the reference's first failing natural-order pivot and zero-fills the system."""
+    import torch
+    from nnmnkwii_amd import _hip
+    windows = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(0)
+    B, T, sd = 2, 300, 20
+    M_ = rng.randn(B, T, 3 * sd)
+    V_ = rng.rand(B, T, 3 * sd) + 0.1
+    V_[1, 137, 4] = -1e-3       # static variance of dim 4 -> pivot 138 fails (third strip)
+    V_[0, 10, sd + 2] = -1e-4   # delta variance of dim 2 (first strip)
+    V_[0, 290, 7] = -1e-4       # last strip
+    exp = np.zeros((B, sd), dtype=np.int32)
+    for b, d in ((1, 4), (0, 2), (0, 7)):
+        cols = [d, sd + d, 2 * sd + d]
+        _, s1, _ = O.mlpg_batch(M_[b:b + 1][:, :, cols], V_[b:b + 1][:, :, cols], windows)
+        exp[b, d] = s1[0, 0]
+    assert exp[1, 4] == 138 and exp[0, 2] > 0 and exp[0, 7] > 0
+    y, st = _hip.forward(torch.from_numpy(M_).cuda(), torch.from_numpy(V_).cuda(), windows, algo=_hip.ALGO_STRIP)
+    assert np.array_equal(st.cpu().numpy().reshape(B, sd), exp)
+    y = y.cpu().numpy()
+    assert not y[1, :, 4].any() and not y[0, :, 2].any() and not y[0, :, 7].any()
+    ok = np.ones((B, sd), dtype=bool)
+    ok[1, 4] = ok[0, 2] = ok[0, 7] = False
+    V_ok = np.abs(V_)
+    yo, _, _ = O.mlpg_batch(M_, V_ok, windows)
+    for b in range(B):
+        for d in range(sd):
+            if ok[b, d]:
+                assert np.abs(y[b, :, d] - yo[b, :, d]).max() <= TOL64 * np.abs(yo[b, :, d]).max()
+
+
+@pytest.mark.parametrize("sigma,tol", [(2.0, 1e-9), (4.0, 1e-7), (6.0, 1e-5)])
+def test_strip_ill_conditioned(sigma, tol):
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(int(sigma * 10))
+    B, T, sd = 3, 1000, 16
+    m = rng.randn(B, T, 3 * sd)
+    v = np.exp(sigma * rng.randn(B, T, 3 * sd))
+    ref, st, rc = O.mlpg_batch(m, v, STD3)
+    assert rc == 0
+    out, status = _hip.forward(torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), STD3, algo=_hip.ALGO_STRIP)
+    assert int(status.abs().max().item()) == 0
+    err = np.abs(out.cpu().numpy() - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    print("sigma", sigma, "strip max rel err", err.max())
+    assert err.max() <= tol
+
+
+def test_strip_full_size_and_repeatability():
+    """Config-2 size: linearity, batch-permutation equivariance (bitwise), repeated launches bitwise equal
+    (the inter-workgroup protocol leaves no timing dependence in the numbers), spot parity vs the oracle."""
+    import torch
+    from nnmnkwii_amd import _hip
+    windows = WINDOW_SETS["std3"]
+    g = torch.Generator(device="cuda").manual_seed(7)
+    B, T, D = 256, 1000, 180
+    m1 = torch.randn(B, T, D, dtype=torch.float64, device="cuda", generator=g)
+    m2 = torch.randn(B, T, D, dtype=torch.float64, device="cuda", generator=g)
+    v = torch.rand(B, T, D, dtype=torch.float64, device="cuda", generator=g) + 0.1
+    f = lambda m: _hip.forward(m, v, windows, algo=_hip.ALGO_STRIP)
+    y1, s1 = f(m1)
+    assert int(s1.abs().max()) == 0
+    for _ in range(5):
+        ya, _ = f(m1)
+        assert torch.equal(ya, y1)
+    y2, _ = f(m2)
+    y3, _ = f(2.5 * m1 + m2)
+    scale = float(y3.abs().max())
+    assert float((y3 - (2.5 * y1 + y2)).abs().max()) <= 1e-11 * scale
+    perm = torch.randperm(B, device="cuda", generator=g)
+    yp, _ = _hip.forward(m1[perm].contiguous(), v[perm].contiguous(), windows, algo=_hip.ALGO_STRIP)
+    assert torch.equal(yp, y1[perm])
+    for b in (0, 100, 255):
+        yo = O.mlpg(m1[b].cpu().numpy(), v[b].cpu().numpy(), windows)
+        assert rel_err(y1[b].cpu().numpy(), yo) <= TOL64
+    # forward/backward adjointness at full size
+    go = torch.randn(B, T, D // 3, dtype=torch.float64, device="cuda", generator=g)
+    gm, _ = _hip.backward(v, go, windows, D, out_dtype=torch.float64, algo=_hip.ALGO_STRIP)
+    lhs, rhs = float((go * y1).sum()), float((gm * m1).sum())
+    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), 1.0)
+
+
+def test_strip_two_streams_concurrently():
+    """Launches on two HIP streams of one device use separate scratch (records, arrival counters)."""
+    import torch
+    from nnmnkwii_amd import _hip
+    windows = WINDOW_SETS["std3"]
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, T, D = 64, 700, 90
+    ms = [torch.randn(B, T, D, dtype=torch.float64, device="cuda", generator=g) for _ in range(2)]
+    vs = [torch.rand(B, T, D, dtype=torch.float64, device="cuda", generator=g) + 0.1 for _ in range(2)]
+    ref = [_hip.forward(ms[k], vs[k], windows, algo=_hip.ALGO_STRIP)[0] for k in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = [None, None]
+    for rep in range(8):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                outs[k] = _hip.forward(ms[k], vs[k], windows, algo=_hip.ALGO_STRIP)[0]
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(outs[k], ref[k])

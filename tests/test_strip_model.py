@@ -1,0 +1,58 @@
+"""CPU: the numpy model of the strip kernel's three-level elimination (tools/strip_model.py, the
+executable specification the HIP code in csrc/mlpg_strip.hip transliterates) against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from cases import WINDOW_SETS, rand_case
+from oracle import mlpg as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import strip_model as S  # noqa: E402
+
+
+def rel_err(y, ref):
+    scale = np.abs(ref).max(axis=0, keepdims=True)
+    scale = np.where(scale == 0, 1.0, scale)
+    return float((np.abs(y - ref) / scale).max())
+
+
+@pytest.mark.parametrize("wname", ["std3", "std2", "static", "asym2", "zero2"])
+@pytest.mark.parametrize("T", [1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 66, 127, 130, 200, 257, 1000])
+def test_model_vs_oracle(wname, T):
+    m, v, vg = rand_case(wname, "f64", T, 3, salt=7)
+    for W in (1, 2, 4):
+        if T > 300 and W != 4:
+            continue
+        y, bad = S.mlpg_strip(m, v, WINDOW_SETS[wname], W=W)
+        assert not bad.any()
+        assert rel_err(y, O.mlpg(m, v, WINDOW_SETS[wname])) < 1e-11, (wname, T, W)
+    y, _ = S.mlpg_strip(m, vg, WINDOW_SETS[wname], W=4)
+    assert rel_err(y, O.mlpg(m, vg, WINDOW_SETS[wname])) < 1e-11
+
+
+def test_model_one_sided_and_two_sided_level3_agree():
+    m, v, _ = rand_case("std3", "f64", 1000, 2, salt=9)
+    y1, _ = S.mlpg_strip(m, v, WINDOW_SETS["std3"], two_sided=False)
+    y2, _ = S.mlpg_strip(m, v, WINDOW_SETS["std3"], two_sided=True)
+    assert rel_err(y1, y2) < 1e-12
+    assert rel_err(y2, O.mlpg(m, v, WINDOW_SETS["std3"])) < 1e-11
+
+
+def test_model_ragged_length():
+    m, v, _ = rand_case("std3", "f64", 150, 2, salt=1)
+    for T in (149, 128, 113, 112, 97, 64, 50, 3):
+        y, _ = S.mlpg_strip(m, v, WINDOW_SETS["std3"], W=4, T=T)
+        yo = O.mlpg(m[:T], v[:T], WINDOW_SETS["std3"])
+        assert rel_err(y[:T], yo) < 1e-11
+        assert not y[T:].any()
+
+
+def test_model_flags_indefinite():
+    m, v, _ = rand_case("std3", "f64", 100, 2, salt=2)
+    v = v.copy()
+    v[40, 0] = -0.05
+    _, bad = S.mlpg_strip(m, v, WINDOW_SETS["std3"])
+    assert bad[0] and not bad[1]
