@@ -212,6 +212,19 @@ int mlpg_hip_trim_lengths(int device, void *stream, int dtype, const void *X,
  *   path_len : int32[N] (0 if the pair failed), cost : float64[N] = accumulated
  *   distance D[len_x, len_y] (alignment.py:50, before the :51 normalisation).
  */
+/* local distances of mlpg_hip_fastdtw */
+#define MLPG_HIP_DIST_L2 0           /* sqrt(sum_k (x_k-y_k)^2), k ascending: DTWAligner's default dist
+                                        (alignment.py:35: lambda x, y: norm(x - y)) in the oracle's summation order */
+#define MLPG_HIP_DIST_SCALED_L2_NP 1 /* dist_scale * sqrt(((x-y)*(x-y)).sum()) with the sum in numpy's pairwise
+                                        order (D <= 128): metrics.melcd(x, y) for two frames
+                                        (metrics/__init__.py:27-59) with dist_scale = 10/ln(10)*sqrt(2) */
+int mlpg_hip_fastdtw(int device, void *stream, const double *X,
+                     const double *Y, const int32_t *lenx,
+                     const int32_t *leny, int N, int Tx, int Ty, int D,
+                     int radius, int dist_kind, double dist_scale,
+                     int32_t *path_i, int32_t *path_j,
+                     int32_t *path_len, double *cost);
+/* = mlpg_hip_fastdtw(..., MLPG_HIP_DIST_L2, 1.0, ...) */
 int mlpg_hip_fastdtw_l2(int device, void *stream, const double *X,
                         const double *Y, const int32_t *lenx,
                         const int32_t *leny, int N, int Tx, int Ty, int D,

@@ -12,7 +12,7 @@ import threading
 import numpy as np
 
 F32, F64 = 0, 1
-ABI_VERSION = 4               # mlpg_hip_abi_version() of the library this binding was written for
+ABI_VERSION = 5               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE, ALGO_STRIP = 0, 1, 2, 3
 
@@ -34,6 +34,7 @@ EXPORTS = (
     "mlpg_hip_modspec_smoothing",
     "mlpg_hip_modspec_backward",
     "mlpg_hip_trim_lengths",
+    "mlpg_hip_fastdtw",
     "mlpg_hip_fastdtw_l2",
     "mlpg_hip_gather_path",
 )
@@ -93,6 +94,8 @@ def lib():
         L.mlpg_hip_trim_lengths.argtypes = [ci, vp, ci, vp, ci, ci, ci, cd, vp]
         L.mlpg_hip_fastdtw_l2.restype = ci
         L.mlpg_hip_fastdtw_l2.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
+        L.mlpg_hip_fastdtw.restype = ci
+        L.mlpg_hip_fastdtw.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cd, vp, vp, vp, vp]
         L.mlpg_hip_gather_path.restype = ci
         L.mlpg_hip_gather_path.argtypes = [ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
         if L.mlpg_hip_abi_version() != ABI_VERSION:
@@ -367,8 +370,12 @@ def trim_lengths(X, eps=1e-7):
     return lengths
 
 
-def fastdtw_l2(X, Y, lenx, leny, radius=1):
-    """fastdtw paths for N pairs. Returns (path_i, path_j (N, Tx+Ty) int32, path_len (N,), cost (N,))."""
+DIST_L2, DIST_SCALED_L2_NP = 0, 1
+
+
+def fastdtw_l2(X, Y, lenx, leny, radius=1, dist_kind=DIST_L2, dist_scale=1.0):
+    """fastdtw paths for N pairs. Returns (path_i, path_j (N, Tx+Ty) int32, path_len (N,), cost (N,)).
+    dist_kind / dist_scale: the local distance (include/mlpg_hip.h MLPG_HIP_DIST_*)."""
     torch = torch_mod()
     assert X.is_cuda and Y.is_cuda and X.dtype == torch.float64 and Y.dtype == torch.float64
     assert X.is_contiguous() and Y.is_contiguous() and X.dim() == 3 and Y.dim() == 3
@@ -380,9 +387,10 @@ def fastdtw_l2(X, Y, lenx, leny, radius=1):
     path_j = torch.empty((N, Tx + Ty), dtype=torch.int32, device=dev)
     path_len = torch.empty((N,), dtype=torch.int32, device=dev)
     cost = torch.empty((N,), dtype=torch.float64, device=dev)
-    rc = lib().mlpg_hip_fastdtw_l2(dev.index, _stream(dev), _p(X), _p(Y), _p(lenx), _p(leny), N, Tx, Ty, D,
-                                   int(radius), _p(path_i), _p(path_j), _p(path_len), _p(cost))
-    _check(rc, "mlpg_hip_fastdtw_l2")
+    rc = lib().mlpg_hip_fastdtw(dev.index, _stream(dev), _p(X), _p(Y), _p(lenx), _p(leny), N, Tx, Ty, D,
+                                int(radius), int(dist_kind), float(dist_scale), _p(path_i), _p(path_j), _p(path_len),
+                                _p(cost))
+    _check(rc, "mlpg_hip_fastdtw")
     return path_i, path_j, path_len, cost
 
 

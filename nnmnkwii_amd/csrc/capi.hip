@@ -236,7 +236,7 @@ using namespace mlpg;
 
 extern "C" {
 
-__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 4; }
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 5; }
 
 __attribute__((visibility("default"))) const char *mlpg_hip_last_error(void) { return g_err; }
 
@@ -448,11 +448,12 @@ __attribute__((visibility("default"))) int mlpg_hip_trim_lengths(int device, voi
   return launch_trim((hipStream_t)stream, dtype, X, N, T, D, eps, lengths);
 }
 
-__attribute__((visibility("default"))) int mlpg_hip_fastdtw_l2(int device, void *stream, const double *X,
-                                                               const double *Y, const int32_t *lenx,
-                                                               const int32_t *leny, int N, int Tx, int Ty, int D,
-                                                               int radius, int32_t *path_i, int32_t *path_j,
-                                                               int32_t *path_len, double *cost) {
+__attribute__((visibility("default"))) int mlpg_hip_fastdtw(int device, void *stream, const double *X,
+                                                            const double *Y, const int32_t *lenx,
+                                                            const int32_t *leny, int N, int Tx, int Ty, int D,
+                                                            int radius, int dist_kind, double dist_scale,
+                                                            int32_t *path_i, int32_t *path_j, int32_t *path_len,
+                                                            double *cost) {
   if (N < 0 || Tx < 1 || Ty < 1 || D < 1 || radius < 1) {
     set_error("fastdtw: need N >= 0, Tx, Ty, D >= 1 and radius >= 1");
     return MLPG_HIP_EINVAL;
@@ -467,8 +468,17 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw_l2(int device, void 
     set_error("cannot select device %d", device);
     return MLPG_HIP_ERUNTIME;
   }
-  return launch_fastdtw((hipStream_t)stream, device, X, Y, lenx, leny, N, Tx, Ty, D, radius, path_i, path_j,
-                        path_len, cost);
+  return launch_fastdtw((hipStream_t)stream, device, X, Y, lenx, leny, N, Tx, Ty, D, radius, dist_kind, dist_scale,
+                        path_i, path_j, path_len, cost);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_fastdtw_l2(int device, void *stream, const double *X,
+                                                               const double *Y, const int32_t *lenx,
+                                                               const int32_t *leny, int N, int Tx, int Ty, int D,
+                                                               int radius, int32_t *path_i, int32_t *path_j,
+                                                               int32_t *path_len, double *cost) {
+  return mlpg_hip_fastdtw(device, stream, X, Y, lenx, leny, N, Tx, Ty, D, radius, MLPG_HIP_DIST_L2, 1.0, path_i, path_j,
+                          path_len, cost);
 }
 
 __attribute__((visibility("default"))) int mlpg_hip_gather_path(int device, void *stream, int dtype, const void *src,

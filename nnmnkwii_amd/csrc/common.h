@@ -67,8 +67,8 @@ int launch_delta(hipStream_t s, int dtype, const void *x, const int32_t *lengths
                  const WinSet &w, void *out);
 int launch_trim(hipStream_t s, int dtype, const void *X, int N, int T, int D, double eps, int32_t *lengths);
 int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, const int32_t *lenx,
-                   const int32_t *leny, int N, int Tx, int Ty, int D, int radius, int32_t *path_i,
-                   int32_t *path_j, int32_t *path_len, double *cost);
+                   const int32_t *leny, int N, int Tx, int Ty, int D, int radius, int dist_kind, double dist_scale,
+                   int32_t *path_i, int32_t *path_j, int32_t *path_len, double *cost);
 int launch_gather(hipStream_t s, int dtype, const void *src, const int32_t *path, const int32_t *path_len, int N,
                   int Tsrc, int path_stride, int D, int Tout, void *out);
 

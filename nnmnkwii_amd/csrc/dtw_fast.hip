@@ -66,6 +66,8 @@ struct DtwParams {
   size_t pyr_stride;  // (Tx + Ty) * D
   int cellcap;        // window cells per level (bound)
   int chunkcap;       // cost cells per DP chunk
+  int dist_kind;      // MLPG_HIP_DIST_*
+  double dist_scale;  // factor of MLPG_HIP_DIST_SCALED_L2_NP
 };
 
 constexpr int kMaxLevels = 20;
@@ -97,6 +99,43 @@ __device__ __forceinline__ double l2_cost(const double *__restrict__ a, const do
     acc = __dadd_rn(acc, __dmul_rn(diff, diff));
   }
   return __dsqrt_rn(acc);
+}
+
+// scale * sqrt(sum_k (a_k - b_k)^2) with the sum in numpy's order for a contiguous float64 vector of D <= 128
+// elements (numpy/core/src/umath/loops_utils.h.src, pairwise sum: sequential below 8 elements, else eight
+// partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail): what
+// `scale * math.sqrt(((x - y) * (x - y)).sum(-1))` evaluates to, i.e. the reference's metrics.melcd(x, y) for two
+// frames (metrics/__init__.py:27-59) with scale = 10 / ln 10 * sqrt 2.
+__device__ __forceinline__ double np_l2_cost(const double *__restrict__ a, const double *__restrict__ b, int D, double scale) {
+  double res;
+  if (D < 8) {
+    res = 0.0;
+    for (int k = 0; k < D; ++k) {
+      const double diff = __dsub_rn(a[k], b[k]);
+      res = __dadd_rn(res, __dmul_rn(diff, diff));
+    }
+  } else {
+    double r[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double diff = __dsub_rn(a[q], b[q]);
+      r[q] = __dmul_rn(diff, diff);
+    }
+    int k = 8;
+    for (; k < D - (D % 8); k += 8) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const double diff = __dsub_rn(a[k + q], b[k + q]);
+        r[q] = __dadd_rn(r[q], __dmul_rn(diff, diff));
+      }
+    }
+    res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])), __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+    for (; k < D; ++k) {
+      const double diff = __dsub_rn(a[k], b[k]);
+      res = __dadd_rn(res, __dmul_rn(diff, diff));
+    }
+  }
+  return __dmul_rn(scale, __dsqrt_rn(res));
 }
 
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total) {
@@ -351,7 +390,8 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         }
         const int row = i0 + a;
         const int j = (int)lo[row] + cc - (off[row] - base);
-        dst[cc + 2 * a + 1] = l2_cost(xk + (size_t)row * D, yk + (size_t)j * D, D);
+        dst[cc + 2 * a + 1] = p.dist_kind == MLPG_HIP_DIST_L2 ? l2_cost(xk + (size_t)row * D, yk + (size_t)j * D, D)
+                                                              : np_l2_cost(xk + (size_t)row * D, yk + (size_t)j * D, D, p.dist_scale);
       }
       for (int a = tid - t0; a < R; a += nthr) {  // the +INF frame of every row
         dst[off[i0 + a] - base + 2 * a] = INFINITY;
@@ -684,8 +724,16 @@ size_t lds_bytes(int Tx, int Ty, int D, const DtwParams &p) {
 }  // namespace
 
 int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, const int32_t *lenx,
-                   const int32_t *leny, int N, int Tx, int Ty, int D, int radius, int32_t *path_i,
-                   int32_t *path_j, int32_t *path_len, double *cost) {
+                   const int32_t *leny, int N, int Tx, int Ty, int D, int radius, int dist_kind, double dist_scale,
+                   int32_t *path_i, int32_t *path_j, int32_t *path_len, double *cost) {
+  if (dist_kind != MLPG_HIP_DIST_L2 && dist_kind != MLPG_HIP_DIST_SCALED_L2_NP) {
+    set_error("fastdtw: unknown local distance %d", dist_kind);
+    return MLPG_HIP_EINVAL;
+  }
+  if (dist_kind == MLPG_HIP_DIST_SCALED_L2_NP && D > 128) {
+    set_error("fastdtw: MLPG_HIP_DIST_SCALED_L2_NP reproduces numpy's summation order up to 128 feature dims (got %d)", D);
+    return MLPG_HIP_EINVAL;
+  }
   if (Tx > 65000 || Ty > 65000) {
     set_error("fastdtw: sequences longer than 65000 frames are not supported");
     return MLPG_HIP_EINVAL;
@@ -694,6 +742,8 @@ int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, 
   p.X = X; p.Y = Y; p.lenx = lenx; p.leny = leny;
   p.N = N; p.Tx = Tx; p.Ty = Ty; p.D = D; p.radius = radius;
   p.path_i = path_i; p.path_j = path_j; p.path_len = path_len; p.cost = cost;
+  p.dist_kind = dist_kind;
+  p.dist_scale = dist_scale;
   p.pyr_stride = (size_t)(Tx + Ty) * D;
   // window cells per level <= (4r+2)(tx+ty); the coarsest level runs a
   // full DTW with one side <= r+1

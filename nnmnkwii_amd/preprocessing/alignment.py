@@ -17,15 +17,54 @@ def _default_dist(x, y):
     return norm(x - y)
 
 
+def _resolve_dist(dist):
+    """Map a ``dist`` callable onto a local cost the HIP kernel evaluates: (dist_kind, dist_scale).
+
+    * the default (``norm(x - y)``) and any callable that IS the Euclidean distance -> MLPG_HIP_DIST_L2;
+    * ``metrics.melcd`` (this package's or the reference's) and any callable that is a positive multiple of the
+      Euclidean distance -> MLPG_HIP_DIST_SCALED_L2_NP (numpy summation order, the multiple as measured);
+    * anything else cannot run on the GPU (there is no CPU fallback): NotImplementedError.
+    The callable is only probed on a few random frame pairs, never called per DP cell.
+    """
+    from .. import metrics
+    if dist is _default_dist:
+        return _hip.DIST_L2, 1.0
+    if dist is metrics.melcd:
+        return _hip.DIST_SCALED_L2_NP, float(metrics._logdb_const)
+    if not callable(dist):
+        raise TypeError("dist must be callable")
+    rng = np.random.RandomState(12345)
+    ratios = []
+    try:
+        for D in (1, 5, 25):
+            for _ in range(3):
+                x, y = rng.randn(D), rng.randn(D)
+                ratios.append(float(dist(x, y)) / float(norm(x - y)))
+    except Exception as e:   # a callable that does not take two frames
+        raise NotImplementedError("DTWAligner: cannot evaluate `dist` on two frames (%s)" % e)
+    ratios = np.asarray(ratios)
+    c = float(np.median(ratios))
+    if not (c > 0 and np.all(np.abs(ratios - c) <= 1e-9 * c)):
+        raise NotImplementedError(
+            "nnmnkwii_amd.DTWAligner evaluates the local cost on the GPU: the default Euclidean distance, "
+            "metrics.melcd, or a callable that is a positive multiple of the Euclidean distance; an arbitrary "
+            "Python `dist` cannot run there (and there is no CPU fallback)")
+    if abs(c - 1.0) <= 1e-12:
+        return _hip.DIST_L2, 1.0
+    return _hip.DIST_SCALED_L2_NP, c
+
+
 class DTWAligner(object):
     """Align feature matrices with fastdtw (radius-limited multi-resolution DTW).
 
     Same constructor and ``transform`` contract as the reference class: inputs
     are zero-padded ``(N, Tx, D)`` / ``(N, Ty, D)`` arrays; outputs are two
     ``(N, max(T_longer, longest path), D)`` arrays with the dtype of the longer
-    input.  ``dist`` must be left at its default (Euclidean ``norm(x - y)``):
-    the HIP kernel evaluates that local cost itself, and an arbitrary Python
-    callable cannot run on the GPU -- any other ``dist`` raises
+    input.  ``dist``: the HIP kernel evaluates the local cost itself, so the
+    callable is mapped onto a device-side cost (:func:`_resolve_dist`): the
+    default Euclidean ``norm(x - y)``, ``metrics.melcd`` (the reference's own
+    test passes it), or any positive multiple of the Euclidean distance.  An
+    arbitrary Python callable cannot run on the GPU and raises
     ``NotImplementedError`` (there is no CPU fallback).
 
     Attributes:
@@ -42,10 +81,7 @@ class DTWAligner(object):
     def _paths(self, X, Y):
         """Device-side trim + fastdtw. Returns torch tensors (Xd, Yd, path_i, path_j, path_len, cost, lenx, leny)."""
         torch = _hip.torch_mod()
-        if self.dist is not _default_dist:
-            raise NotImplementedError(
-                "nnmnkwii_amd.DTWAligner evaluates the default Euclidean local cost on the GPU; "
-                "custom `dist` callables are not supported")
+        dist_kind, dist_scale = _resolve_dist(self.dist)
         dev = _hip.require_gpu()
         Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
         Yd = torch.from_numpy(np.ascontiguousarray(Y)).to(dev)
@@ -57,7 +93,7 @@ class DTWAligner(object):
         leny = _hip.trim_lengths(Yd)
         X64 = Xd if Xd.dtype == torch.float64 else Xd.to(torch.float64)   # fastdtw casts to float
         Y64 = Yd if Yd.dtype == torch.float64 else Yd.to(torch.float64)
-        path_i, path_j, path_len, cost = _hip.fastdtw_l2(X64, Y64, lenx, leny, self.radius)   # :50
+        path_i, path_j, path_len, cost = _hip.fastdtw_l2(X64, Y64, lenx, leny, self.radius, dist_kind, dist_scale)   # :50
         return Xd, Yd, path_i, path_j, path_len, cost, lenx, leny
 
     def transform(self, XY):

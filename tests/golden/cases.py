@@ -100,3 +100,15 @@ def gmm_joint_data(wname, sd, n=400, T=30):
     y = x @ A + 0.5 + 0.3 * rng.randn(n, D)
     src = centers[rng.randint(0, 3, size=T)] + rng.randn(T, D)
     return np.concatenate([x, y], axis=1), src
+
+
+def c4_pairs(n, seed=4242):
+    """n BASELINE config-4 sized pairs: smooth 25-dim tracks, T in [700, 900], zero-padded to 900 (float64)."""
+    rng = np.random.RandomState(seed)
+    X = np.zeros((n, 900, 25))
+    Y = np.zeros((n, 900, 25))
+    for k in range(n):
+        a, b = rng.randint(700, 901, size=2)
+        X[k, :a] = np.cumsum(rng.randn(a, 25), 0) * 0.1
+        Y[k, :b] = np.cumsum(rng.randn(b, 25), 0) * 0.1
+    return X, Y

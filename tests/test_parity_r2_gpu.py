@@ -1,0 +1,170 @@
+"""Round-2 parity tests (-m gpu): the holes the round-1 review listed.
+
+* backward (mlpg_grad) of every kernel -- generic, wave-per-system (M = 8 / 16 / 32), strip -- against the
+  REFERENCE's own O(T^2) mlpg_grad at T = 300, 1000, 2000 (tests/golden/mlpg_golden2.npz, made by
+  tests/golden/make_golden2.py from the reference itself), float32 and float64;
+* float32 / global-variance / unit-variance forward of the wave and generic kernels against the ORACLE (not against
+  each other) at the same T;
+* BASELINE config 3 at its size (64 x 500 x 180 float32): unit_variance_mlpg forward and backward against the dense
+  R @ means of the reference's definition evaluated in float64 on the host (R = the oracle's restatement of
+  unit_variance_mlpg_matrix, itself checked against rows produced by the reference);
+* BASELINE config 4 sized DTW pairs through DTWAligner against the reference's unmodified alignment.py run with its
+  own dist = norm(x - y) (align_golden2.npz).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from cases import WINDOW_SETS, c4_pairs, rand_case  # noqa: E402
+from oracle import mlpg as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def golden2():
+    return np.load(os.path.join(HERE, "golden", "mlpg_golden2.npz"))
+
+
+def _algos(T):
+    from nnmnkwii_amd import _hip
+    a = [_hip.ALGO_GENERIC, _hip.ALGO_STRIP, _hip.ALGO_AUTO]
+    if T <= 2048:
+        a.append(_hip.ALGO_WAVE)
+    return a
+
+
+@pytest.mark.parametrize("key", ["std3-f32-T300", "std3-f64-T300", "std3-f32-T1000", "std3-f64-T1000",
+                                 "std3-f32-T2000", "std3-f64-T2000", "std2-f64-T700", "asym2-f64-T700"])
+def test_backward_vs_reference_mlpg_grad(golden2, key):
+    import torch
+    from nnmnkwii_amd import _hip
+    wname, dt, T = key.split("-")
+    T = int(T[1:])
+    windows = WINDOW_SETS[wname]
+    sd = 2 if wname == "std3" else 3
+    m, v, _ = rand_case(wname, dt, T, sd, salt=11)
+    go = np.random.RandomState(500 + T).randn(T, sd).astype(m.dtype)
+    ref = golden2["grad2/%s/g" % key]                      # float32, as the reference returns it (_mlpg.py:248)
+    scale = np.abs(ref).max()
+    vt, gt = torch.from_numpy(v[None]).cuda(), torch.from_numpy(go[None]).cuda()
+    for algo in _algos(T):
+        g, st = _hip.backward(vt, gt, windows, v.shape[1], out_dtype=torch.float32, algo=algo)
+        assert int(st.abs().max()) == 0
+        g = g[0].cpu().numpy()
+        assert g.dtype == np.float32 and g.shape == ref.shape
+        assert np.abs(g - ref).max() <= 3e-6 * scale, (key, algo, np.abs(g - ref).max() / scale)
+    # float64 output of the float64 case against the float64 oracle restatement as well
+    if dt == "f64":
+        g64, _ = _hip.backward(vt, gt, windows, v.shape[1], out_dtype=torch.float64, algo=_hip.ALGO_AUTO)
+        assert np.abs(g64[0].cpu().numpy() - ref).max() <= 3e-6 * scale
+
+
+@pytest.mark.parametrize("T", [200, 500, 1000, 2000])
+def test_forward_f32_global_unit_vs_oracle(T):
+    """Every kernel, float32 inputs with per-frame / global / unit variances and float64 with global / unit ones,
+    ragged lengths: against the oracle (which is bit-exact against the reference)."""
+    import torch
+    from nnmnkwii_amd import _hip
+    windows = WINDOW_SETS["std3"]
+    B, sd = 3, 20
+    rng = np.random.RandomState(T)
+    M_ = rng.randn(B, T, 3 * sd)
+    V_ = rng.rand(B, T, 3 * sd) + 0.1
+    lengths = np.array([T, T - 1, T // 2], dtype=np.int32)
+    L = torch.from_numpy(lengths).cuda()
+    for dt, tol in ((np.float32, 5e-6), (np.float64, 1e-9)):
+        Md = M_.astype(dt)
+        for mode in ("frame", "global", "unit"):
+            if mode == "frame":
+                Vd = V_.astype(dt)
+            elif mode == "global":
+                Vd = V_[0, 0].astype(dt)
+            else:
+                Vd = None
+            yo, _, rc = O.mlpg_batch(Md, Vd if Vd is not None else np.ones(3 * sd, dtype=dt), windows, lengths)
+            assert rc == 0
+            for algo in _algos(T):
+                y, st = _hip.forward(torch.from_numpy(Md).cuda(), None if Vd is None else torch.from_numpy(Vd).cuda(),
+                                     windows, L, algo=algo)
+                assert int(st.abs().max()) == 0
+                y = y.cpu().numpy()
+                sc = np.abs(yo).max(axis=1, keepdims=True) + 1e-300
+                assert (np.abs(y - yo) / sc).max() <= tol, (T, dt.__name__, mode, algo)
+
+
+def test_config3_size_unit_variance_autograd(golden2):
+    """BASELINE config 3: B = 64, T = 500, D = 180 float32 tensors on the GPU, forward + backward through
+    autograd.unit_variance_mlpg, against the reference's definition (dense R @ means, R^T @ grad) in float64."""
+    import torch
+    from nnmnkwii_amd import autograd as AF
+    from nnmnkwii_amd import paramgen as G
+    windows = WINDOW_SETS["std3"]
+    B, T, D = 64, 500, 180
+    sd = D // 3
+    Ro = O.unit_variance_mlpg_matrix(windows, T).astype(np.float64)          # (T, 3T) restatement of _mlpg.py:297-373
+    assert np.abs(Ro[[0, 1, 2, 250, 497, 498, 499]] - golden2["uv3/rows"]).max() <= 1e-6   # the reference's rows (float32)
+    assert np.abs(Ro.sum(axis=1) - golden2["uv3/rowsum"]).max() <= 1e-5
+    R = torch.from_numpy(G.unit_variance_mlpg_matrix(windows, T)).cuda()
+    assert np.abs(R.cpu().numpy() - Ro).max() <= 2e-7
+    torch.manual_seed(1234)
+    means = torch.rand(B, T, D, device="cuda", requires_grad=True)
+    target = torch.rand(B, T, sd, device="cuda")
+    y = AF.unit_variance_mlpg(R, means)
+    loss = torch.nn.MSELoss()(y, target)
+    loss.backward()
+    m64 = means.detach().cpu().numpy().astype(np.float64)
+    rm = m64.reshape(B, T, 3, sd).transpose(0, 2, 1, 3).reshape(B, 3 * T, sd)   # reshape_means per utterance
+    y_ref = np.einsum("tk,bkd->btd", Ro, rm)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (B, T, sd)
+    assert np.abs(y.detach().cpu().numpy() - y_ref).max() <= 5e-6
+    gy = 2.0 * (y_ref - target.cpu().numpy().astype(np.float64)) / (B * T * sd)
+    gr = np.einsum("tk,btd->bkd", Ro, gy).reshape(B, 3, T, sd).transpose(0, 2, 1, 3).reshape(B, T, D)
+    assert np.abs(means.grad.cpu().numpy() - gr).max() <= 1e-6 * np.abs(gr).max() + 1e-12
+
+
+def test_config4_size_dtw_aligner_vs_reference_alignment():
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    g = np.load(os.path.join(HERE, "golden", "align_golden2.npz"))
+    X, Y = c4_pairs(6)
+    Xa, Ya = DTWAligner().transform((X, Y))
+    assert Xa.shape == g["dtw4/Xa"].shape and Ya.shape == g["dtw4/Ya"].shape
+    np.testing.assert_array_equal(Xa, g["dtw4/Xa"])
+    np.testing.assert_array_equal(Ya, g["dtw4/Ya"])
+
+
+@pytest.mark.parametrize("name", ["small", "grow", "c4"])
+def test_dtw_aligner_custom_dist_melcd_vs_reference(name):
+    """DTWAligner(dist=melcd): the reference's own custom-dist case (tests/test_preprocessing.py:496-501), goldens from
+    the reference's unmodified alignment.py + metrics.melcd."""
+    from cases import align_batch
+    from nnmnkwii_amd.metrics import melcd
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    g = np.load(os.path.join(HERE, "golden", "align_golden2.npz"))
+    X, Y = c4_pairs(2, seed=99) if name == "c4" else align_batch(name)
+    Xa, Ya = DTWAligner(dist=melcd).transform((X, Y))
+    np.testing.assert_array_equal(Xa, g["dtw-melcd/%s/Xa" % name])
+    np.testing.assert_array_equal(Ya, g["dtw-melcd/%s/Ya" % name])
+
+
+def test_dtw_aligner_dist_resolution():
+    from numpy.linalg import norm
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd.metrics import melcd
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner, _resolve_dist
+    assert _resolve_dist(lambda x, y: norm(x - y)) == (_hip.DIST_L2, 1.0)          # the reference's default, passed explicitly
+    assert _resolve_dist(lambda x, y: np.sqrt(((x - y) ** 2).sum())) == (_hip.DIST_L2, 1.0)
+    k, c = _resolve_dist(melcd)
+    assert k == _hip.DIST_SCALED_L2_NP and abs(c - 10.0 / np.log(10.0) * np.sqrt(2.0)) < 1e-15
+    k, c = _resolve_dist(lambda x, y: 3.0 * norm(x - y))
+    assert k == _hip.DIST_SCALED_L2_NP and abs(c - 3.0) < 1e-12
+    with pytest.raises(NotImplementedError):
+        _resolve_dist(lambda x, y: np.abs(x - y).sum())
+    X, Y = c4_pairs(1, seed=5)
+    a = DTWAligner(dist=lambda x, y: norm(x - y)).transform((X, Y))
+    b = DTWAligner().transform((X, Y))
+    np.testing.assert_array_equal(a[0], b[0])
