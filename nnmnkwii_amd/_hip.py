@@ -132,8 +132,15 @@ def require_gpu(device=None):
     return device
 
 
+class PackedWindows(tuple):
+    """(int32 l[], int32 u[], float64 coeff[], num_windows): what pack_windows returns; pass it instead of the window
+    list to skip the packing in a hot loop."""
+
+
 def pack_windows(windows):
     """Reference `(l, u, coeff)` triples -> (int32 l[], int32 u[], float64 coeff[]) host arrays."""
+    if isinstance(windows, PackedWindows):
+        return windows[0], windows[1], windows[2]
     wl, wu, wc = [], [], []
     for l, u, coeff in windows:
         l, u = int(l), int(u)
@@ -145,6 +152,18 @@ def pack_windows(windows):
         wc.append(coeff)
     return (np.ascontiguousarray(wl, dtype=np.int32), np.ascontiguousarray(wu, dtype=np.int32),
             np.ascontiguousarray(np.concatenate(wc)))
+
+
+def prepack_windows(windows):
+    """Pack once, reuse: the result is accepted wherever a window list is."""
+    if isinstance(windows, PackedWindows):
+        return windows
+    wl, wu, wc = pack_windows(windows)
+    return PackedWindows((wl, wu, wc, len(wl)))
+
+
+def _nw(windows):
+    return windows[3] if isinstance(windows, PackedWindows) else len(windows)
 
 
 def _dt(t):
@@ -179,7 +198,7 @@ def forward(mean, var, windows, lengths=None, algo=ALGO_AUTO, want_status=True):
     torch = torch_mod()
     assert mean.is_cuda and mean.dim() == 3 and mean.is_contiguous()
     B, T, D = mean.shape
-    nw = len(windows)
+    nw = _nw(windows)
     wl, wu, wc = pack_windows(windows)
     if var is None:
         mode = VAR_UNIT
@@ -266,7 +285,7 @@ def backward(var, grad_out, windows, D, lengths=None, out_dtype=None, algo=ALGO_
     torch = torch_mod()
     assert grad_out.is_cuda and grad_out.dim() == 3 and grad_out.is_contiguous()
     B, T, sd = grad_out.shape
-    nw = len(windows)
+    nw = _nw(windows)
     assert sd * nw == D
     wl, wu, wc = pack_windows(windows)
     if var is None:

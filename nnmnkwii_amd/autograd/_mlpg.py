@@ -20,7 +20,18 @@ CHECK_STATUS = True
 
 
 def _to_gpu(t, dev):
-    return t.detach().to(dev).contiguous()
+    t = t.detach()
+    if t.device != dev:
+        t = t.to(dev)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _back(t, like):
+    """Result tensor on the device and in the dtype of `like` (no-ops skipped: every torch call costs microseconds
+    of host time, which is all this path costs at BASELINE config 3)."""
+    if t.device != like.device or t.dtype != like.dtype:
+        t = t.to(device=like.device, dtype=like.dtype)
+    return t
 
 
 class MLPG(Function):
@@ -87,7 +98,8 @@ def _identify_R(R):
             windows, T_reg, R_reg = reg
             same = torch.equal(R.detach().to(torch.float32).cpu(), torch.from_numpy(R_reg))
             if same and T_reg == T:
-                found = ([(l, u, np.asarray(c)) for l, u, c in windows], T)
+                # packed once: the hot loop hands the packed tables straight to the C ABI
+                found = (_hip.prepack_windows([(l, u, np.asarray(c)) for l, u, c in windows]), T)
     try:
         R._nnmnkwii_amd_ident = (R._version, found)
     except AttributeError:  # pragma: no cover
@@ -143,7 +155,7 @@ class UnitVarianceMLPG(Function):
             # (B, nw*T, sd) -> frame-major (B, T, nw*sd), the layout the kernels read
             m3 = m3.view(B, nw, T, static_dim).transpose(1, 2).contiguous().view(B, T, nw * static_dim)
         out, _ = _hip.forward(m3, None, windows, want_status=False)
-        out = out.to(device=means.device, dtype=means.dtype)
+        out = _back(out, means)
         if dim == 2:
             return out.view(-1, static_dim)
         return out
@@ -178,7 +190,7 @@ class UnitVarianceMLPG(Function):
         grad, _ = _hip.backward(None, go, ctx.windows, nw * sd, out_dtype=go.dtype, want_status=False)
         if reshaped:
             grad = grad.view(B, T, nw, sd).transpose(1, 2).contiguous().view(B, nw * T, sd)
-        grad = grad.to(device=means.device, dtype=means.dtype)
+        grad = _back(grad, means)
         if dim == 2:
             return grad.view(-1, D), None
         return grad, None

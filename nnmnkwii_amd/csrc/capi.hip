@@ -68,6 +68,32 @@ void *scratch(int device, hipStream_t stream, int slot, size_t bytes) {
 
 namespace {
 
+// Side streams for the independent streams of one multi-stream call (per device, created once).
+struct SideStreams {
+  static constexpr int kN = 3;
+  hipStream_t st[kN];
+  hipEvent_t fork, join[kN];
+};
+SideStreams *g_side[kMaxDevices] = {};
+
+SideStreams *side_streams(int device) {
+  if (device < 0 || device >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_side[device]) return g_side[device];
+  SideStreams *s = new SideStreams();
+  bool ok = hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) == hipSuccess;
+  for (int q = 0; ok && q < SideStreams::kN; ++q)
+    ok = hipStreamCreateWithFlags(&s->st[q], hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&s->join[q], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {  // no side streams: the caller falls back to its own stream
+    (void)hipGetLastError();
+    delete s;
+    return nullptr;
+  }
+  g_side[device] = s;
+  return s;
+}
+
 int pack_windows(int nw, const int32_t *wl, const int32_t *wu, const double *wc, WinSet *ws) {
   if (nw < 1 || nw > kMaxWindows || !wl || !wu || !wc) {
     set_error("num_windows must be in [1, %d] and the window tables non-NULL", kMaxWindows);
@@ -322,21 +348,46 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
     set_error("cannot select device %d", device);
     return MLPG_HIP_ERUNTIME;
   }
+  // The streams are independent: the widest one runs on the caller's stream, every other one on a side stream of
+  // this device that is forked from and joined back into the caller's stream with events (no host synchronisation,
+  // capturable), so that a narrow stream's launch fills the tail of the wide one instead of queueing behind it.
+  int widest = -1;
+  for (int k = 0; k < num_streams; ++k)
+    if (streams_h[k].static_dim > 0 && (widest < 0 || streams_h[k].static_dim * (streams_h[k].num_windows + 1) >
+                                                          streams_h[widest].static_dim * (streams_h[widest].num_windows + 1)))
+      widest = k;
+  hipStream_t main_st = (hipStream_t)stream;
+  SideStreams *side = side_streams(device);
+  int nside = 0;
+  bool forked = false;
   int status_col = 0;
   for (int k = 0; k < num_streams; ++k) {
     const mlpg_hip_stream_t &sm = streams_h[k];
     if (sm.static_dim > 0) {
-      if (int rc = stream_entry(device, (hipStream_t)stream, dtype, algo, mean, var, var_mode, (long)ld_in, lengths, B,
-                                Tmax, sm, win_l_h, win_u_h, win_coef_h, out, (long)ld_out, status, (int)sd_total,
-                                status_col))
+      hipStream_t st = main_st;
+      if (side && k != widest && nside < SideStreams::kN) {
+        if (!forked) {
+          MLPG_HIP_CHECK(hipEventRecord(side->fork, main_st));
+          forked = true;
+        }
+        st = side->st[nside];
+        MLPG_HIP_CHECK(hipStreamWaitEvent(st, side->fork, 0));
+        ++nside;
+      }
+      if (int rc = stream_entry(device, st, dtype, algo, mean, var, var_mode, (long)ld_in, lengths, B, Tmax, sm, win_l_h,
+                                win_u_h, win_coef_h, out, (long)ld_out, status, (int)sd_total, status_col))
         return rc;
       if (sm.num_windows == 0 && status) {
         // pass-through streams cannot fail: their status columns are cleared
         MLPG_HIP_CHECK(hipMemset2DAsync(status + status_col, sizeof(int32_t) * (size_t)sd_total, 0,
-                                        sizeof(int32_t) * (size_t)sm.static_dim, (size_t)B, (hipStream_t)stream));
+                                        sizeof(int32_t) * (size_t)sm.static_dim, (size_t)B, st));
       }
     }
     status_col += sm.static_dim;
+  }
+  for (int q = 0; q < nside; ++q) {
+    MLPG_HIP_CHECK(hipEventRecord(side->join[q], side->st[q]));
+    MLPG_HIP_CHECK(hipStreamWaitEvent(main_st, side->join[q], 0));
   }
   return 0;
 }

@@ -85,6 +85,20 @@ def _as_float(a):
     return a
 
 
+def _match_dtypes(m, v):
+    """Means and variances of different float dtypes, as the reference treats them (_mlpg.py:180-188): the reciprocal
+    is taken in the VARIANCES' dtype, everything after it in float64, the result is cast to the means' dtype.
+    float64 means + float32 variances: the float32 reciprocal is taken here (one elementwise pass) and handed to the
+    float64 kernel as an exactly invertible float64 variance; float32 means + float64 variances: float64 kernel."""
+    torch = _hip.torch_mod()
+    if v.dtype == m.dtype:
+        return m, v
+    if m.dtype == torch.float64 and v.dtype == torch.float32:
+        tau32 = torch.reciprocal(v)                        # float32 reciprocal, correctly rounded
+        return m, torch.reciprocal(tau32.to(torch.float64))
+    return m.to(torch.float64), v.to(torch.float64)
+
+
 def mlpg_batch(means, variances, windows, lengths=None, algo=_hip.ALGO_AUTO, check=True, device=None):
     """Batched MLPG over a zero-padded ``(B, Tmax, D)`` batch -- the GPU-native
     form of the reference's per-utterance loop (util/__init__.py:44-66).
@@ -104,12 +118,13 @@ def mlpg_batch(means, variances, windows, lengths=None, algo=_hip.ALGO_AUTO, che
     else:
         m = means.to(dev).contiguous()
     assert m.dim() == 3
+    out_dtype = m.dtype
     if variances is None:
         v = None
-    elif torch.is_tensor(variances):
-        v = variances.to(device=dev, dtype=m.dtype).contiguous()
     else:
-        v = torch.from_numpy(np.ascontiguousarray(np.asarray(variances))).to(device=dev, dtype=m.dtype)
+        v = (variances if torch.is_tensor(variances) else
+             torch.from_numpy(np.ascontiguousarray(_as_float(variances)))).to(dev).contiguous()
+        m, v = _match_dtypes(m, v)
     if v is not None and v.dim() != 1:
         assert v.shape == m.shape                         # paramgen/_mlpg.py:171
     L = None
@@ -119,6 +134,8 @@ def mlpg_batch(means, variances, windows, lengths=None, algo=_hip.ALGO_AUTO, che
     out, status = _hip.forward(m, v, windows, L, algo=algo, want_status=check)
     if check:
         _hip.raise_on_status(status, out.shape[-1])
+    if out.dtype != out_dtype:
+        out = out.to(out_dtype)                            # output dtype = dtype of the means (_mlpg.py:166,183)
     if is_np:
         return out.cpu().numpy()
     return out
@@ -152,12 +169,13 @@ def multi_stream_mlpg(inputs, variances, windows, stream_sizes, has_dynamic_feat
     assert m.dim() == 3
     D = m.shape[-1]
     assert len(stream_sizes) == len(has_dynamic_features) and sum(stream_sizes) == D
+    out_dtype = m.dtype
     if variances is None:
         v = None
-    elif torch.is_tensor(variances):
-        v = variances.to(device=dev, dtype=m.dtype).contiguous()
     else:
-        v = torch.from_numpy(np.ascontiguousarray(np.asarray(variances))).to(device=dev, dtype=m.dtype)
+        v = (variances if torch.is_tensor(variances) else
+             torch.from_numpy(np.ascontiguousarray(_as_float(variances)))).to(dev).contiguous()
+        m, v = _match_dtypes(m, v)
     if v is not None and v.dim() != 1:
         if two_d and v.dim() == 2:
             v = v[None]
@@ -180,6 +198,8 @@ def multi_stream_mlpg(inputs, variances, windows, stream_sizes, has_dynamic_feat
     out, status = _hip.forward_streams(m, v, streams, L, algo=algo, want_status=check)
     if check:
         _hip.raise_on_status(status, out.shape[-1])
+    if out.dtype != out_dtype:
+        out = out.to(out_dtype)
     if two_d:
         out = out[0]
     return out.cpu().numpy() if is_np else out
@@ -232,7 +252,10 @@ def mlpg_grad(mean_frames, variance_frames, windows, grad_output):
 # registry of MLPG matrices handed out by unit_variance_mlpg_matrix, so that
 # autograd.unit_variance_mlpg(R, means) can recover (windows, T) from R and run
 # the banded O(T) kernels instead of a dense (T x nw*T) product.
-_UV_REGISTRY = {}
+import collections
+
+_UV_REGISTRY = collections.OrderedDict()
+_UV_REGISTRY_MAX = 8          # matrices remembered (each is a (T, nw*T) float32 array: 3 MB at T = 500)
 
 
 def _fingerprint(R):
@@ -267,13 +290,18 @@ def unit_variance_mlpg_matrix(windows, T):
     R = out[0].to(torch.float32).cpu().numpy()
     _UV_REGISTRY[_fingerprint(R)] = (tuple((int(l), int(u), tuple(np.asarray(c, dtype=np.float64).tolist()))
                                            for l, u, c in windows), int(T), R)
+    while len(_UV_REGISTRY) > _UV_REGISTRY_MAX:      # least recently registered / looked up goes first
+        _UV_REGISTRY.popitem(last=False)
     return R
 
 
 def lookup_unit_variance_matrix(R_np_or_fp):
     """(windows, T, R) registered for this matrix, or None."""
     key = R_np_or_fp if isinstance(R_np_or_fp, tuple) else _fingerprint(R_np_or_fp)
-    return _UV_REGISTRY.get(key)
+    hit = _UV_REGISTRY.get(key)
+    if hit is not None:
+        _UV_REGISTRY.move_to_end(key)
+    return hit
 
 
 def reshape_means(means, static_dim):

@@ -45,7 +45,12 @@ def gpu_time(fn, steps=10, warmup=2):
     return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
 
+HBM_PEAK_GBS = 8000.0
+
+
 def emit(**kw):
+    if "GBps" in kw and kw["GBps"] is not None:
+        kw["roofline_frac"] = kw["GBps"] / HBM_PEAK_GBS      # algorithmic bytes / time against the 8 TB/s HBM3E peak
     print(json.dumps(kw), flush=True)
 
 
@@ -65,6 +70,35 @@ def main():
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev).manual_seed(1234)
     want = lambda k: not args.only or k in args.only.split(",")  # noqa: E731
+
+    # ---- c2k: config 2 through every forward kernel (generic / wave-per-system / strip) ----
+    if want("c2k"):
+        B, T, sd = 256, 1000, 60
+        m = torch.randn(B, T, 3 * sd, dtype=torch.float64, device=dev, generator=gen)
+        v = torch.rand(B, T, 3 * sd, dtype=torch.float64, device=dev, generator=gen) + 0.1
+        by = 56.0 * sd * B * T
+        for name, algo in (("generic", 1), ("wave", 2), ("strip", 3)):
+            ms = gpu_time(lambda: _hip.forward(m, v, WINDOWS, algo=algo, want_status=False), steps=20)
+            emit(path="c2k-forward-" + name, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
+        for name, algo in (("wave", 2), ("strip", 3)):
+            go = torch.randn(B, T, sd, dtype=torch.float64, device=dev, generator=gen)
+            ms = gpu_time(lambda: _hip.backward(v, go, WINDOWS, 3 * sd, out_dtype=torch.float64, algo=algo, want_status=False))
+            byb = 8.0 * 7 * sd * B * T
+            emit(path="c2k-backward-f64-" + name, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=byb, GBps=byb / ms / 1e6)
+        # delta_features (the step before MLPG): read sd, write 3 sd per frame
+        x = torch.randn(B, T, sd, dtype=torch.float64, device=dev, generator=gen)
+        ms = gpu_time(lambda: _hip.delta_features(x, WINDOWS))
+        byd = 8.0 * 4 * sd * B * T
+        emit(path="c2k-delta_features", ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=byd, GBps=byd / ms / 1e6)
+        # long utterances (T = 4000: beyond the wave kernel): strip vs generic
+        B2, T2 = 64, 4000
+        m2 = torch.randn(B2, T2, 3 * sd, dtype=torch.float64, device=dev, generator=gen)
+        v2 = torch.rand(B2, T2, 3 * sd, dtype=torch.float64, device=dev, generator=gen) + 0.1
+        by2 = 56.0 * sd * B2 * T2
+        for name, algo in (("generic", 1), ("strip", 3)):
+            ms = gpu_time(lambda: _hip.forward(m2, v2, WINDOWS, algo=algo, want_status=False), steps=5)
+            emit(path="long-T4000-forward-" + name, ms=ms, frames_per_s=B2 * T2 / ms * 1e3, alg_bytes=by2, GBps=by2 / ms / 1e6)
+        del m, v, x, m2, v2
 
     # ---- c2g: global / unit variances ----
     if want("c2g"):
@@ -126,6 +160,26 @@ def main():
 
         ms = gpu_time(step)
         by = 1920.0 * B * T    # 960 B/frame forward + 960 B/frame backward
+        # the same training step captured once into a HIP graph and replayed (eager mode is host-bound: a dozen
+        # framework launches of a few microseconds each around two short kernels)
+        ms_graph = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            means.grad = None
+            with torch.cuda.graph(graph):
+                y_ = AF.unit_variance_mlpg(R, means)
+                loss_ = loss_fn(y_, target)
+                loss_.backward()
+            ms_graph = gpu_time(graph.replay, steps=20)
+        except Exception as e:  # noqa: BLE001
+            ms_graph = "capture failed: %s" % str(e)[:120]
         # reference CPU form: dense R @ means on torch CPU (autograd/_impl/mlpg.py:138,158), 1 thread
         torch.set_num_threads(1)
         Rc, mc = R.cpu(), means.detach().cpu().requires_grad_()
@@ -138,7 +192,9 @@ def main():
             loss_fn(torch.matmul(Rc, rm), tc).backward()
         cpu_s = (time.perf_counter() - t0) / nrep
         emit(path="c3-unit-variance-autograd-fwd+bwd", ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by,
-             GBps=by / ms / 1e6, cpu_dense_matmul_1thread_frames_per_s=B * T / cpu_s)
+             GBps=by / ms / 1e6, ms_hip_graph_replay=ms_graph,
+             GBps_hip_graph_replay=(by / ms_graph / 1e6 if isinstance(ms_graph, float) else None),
+             cpu_dense_matmul_1thread_frames_per_s=B * T / cpu_s)
 
     # ---- c3m: generic autograd.mlpg fwd+bwd (one utterance, like the reference's MLPG) ----
     if want("c3m"):
@@ -184,6 +240,14 @@ def main():
             OD.fastdtw(X[n, :int(lenx[n])], Y[n, :int(leny[n])], 1)
         cpu_s = (time.perf_counter() - t0) / ncpu
         ms_full = gpu_time(lambda: DTWAligner().transform((X, Y)), steps=3, warmup=1)
+        if not args.quick:
+            # all 1024 pairs of config 4 on one GPU (the pairs repeated 8 times)
+            X8, Y8 = Xd.repeat(8, 1, 1).contiguous(), Yd.repeat(8, 1, 1).contiguous()
+            lx8, ly8 = lenx.repeat(8).contiguous(), leny.repeat(8).contiguous()
+            ms8 = gpu_time(lambda: _hip.fastdtw_l2(X8, Y8, lx8, ly8, 1), steps=5)
+            emit(path="c4-fastdtw-kernel-1024pairs", pairs=8 * N, ms=ms8, pairs_per_s=8 * N / ms8 * 1e3, alg_bytes=8 * by,
+                 GBps=8 * by / ms8 / 1e6)
+            del X8, Y8
         emit(path="c4-fastdtw-kernel", pairs=N, ms=ms, pairs_per_s=N / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6,
              cpu_oracle_c_pairs_per_s=1.0 / cpu_s, transform_numpy_to_numpy_ms=ms_full)
 
