@@ -88,6 +88,25 @@ int mlpg_hip_forward(int device, void *stream, int dtype, int algo,
                      void *out, int32_t *status);
 
 /*
+ * The same call on HOST memory (numpy in, numpy out; no framework tensor in between): what a user of the
+ * reference writes as a Python loop of paramgen.mlpg over a padded batch (util/__init__.py:44-66).  Synchronous.
+ * The batch is cut into utterance chunks that alternate between two internal HIP streams, so that the host ->
+ * device copy of one chunk, the kernels of another and the device -> host copy of a third overlap; pageable
+ * memory is staged through pinned buffers by a few copy threads, memory from mlpg_hip_host_alloc (or any pinned /
+ * registered host memory) is transferred in place.  All pointers are HOST pointers; shapes, dtypes, windows,
+ * var_mode and status as for mlpg_hip_forward (lengths_h may be NULL).
+ */
+int mlpg_hip_forward_host(int device, int dtype, int algo, const void *mean_h,
+                          const void *var_h, int var_mode,
+                          const int32_t *lengths_h, int B, int Tmax, int D,
+                          int num_windows, const int32_t *win_l_h,
+                          const int32_t *win_u_h, const double *win_coef_h,
+                          void *out_h, int32_t *status_h);
+/* Pinned host memory for arrays that are handed to mlpg_hip_forward_host repeatedly (transferred in place). */
+void *mlpg_hip_host_alloc(size_t bytes);
+void mlpg_hip_host_free(void *p);
+
+/*
  * Multi-stream MLPG forward over one padded acoustic feature batch (SURVEY 8(f)
  * rank 3).  Replaces the per-utterance, per-stream Python loop that users of
  * the reference write around paramgen.mlpg: util.apply_each2d_padded /
@@ -230,6 +249,21 @@ int mlpg_hip_fastdtw_l2(int device, void *stream, const double *X,
                         const int32_t *leny, int N, int Tx, int Ty, int D,
                         int radius, int32_t *path_i, int32_t *path_j,
                         int32_t *path_len, double *cost);
+
+/*
+ * Frame-wise conversion under a joint source/target GMM.  Replaces the per-frame,
+ * per-mixture Python loop of baseline/gmm.py:97-120 (MLPGBase.transform: np.linalg.solve(covarXX[m], x - mu_x[m])
+ * for every frame and mixture) and :225-244 (MLPG.transform: the same for the most likely mixture of each frame):
+ *   out[n, :] = sum_m posterior[n, m] * (mu_y[m] + A[m] (x[n] - mu_x[m])),     A[m] = covarYX[m] covarXX[m]^-1
+ * x (N, D), posterior (N, M) or NULL, mixture int32 (N) (used when posterior is NULL: one mixture per frame),
+ * mu_x (M, D), mu_y (M, Dy), A (M, Dy, D), out (N, Dy); all float64, row-major.  A is factored once per model by
+ * the caller (host LAPACK); the mixture posteriors come from scikit-learn as in the reference.
+ */
+int mlpg_hip_gmm_convert(int device, void *stream, const double *x,
+                         const double *posterior, const int32_t *mixture,
+                         const double *mu_x, const double *mu_y,
+                         const double *A, int64_t N, int D, int Dy, int M,
+                         double *out);
 
 /*
  * Gather rows along the warping path into zero-padded outputs.  Replaces

@@ -12,7 +12,7 @@ import threading
 import numpy as np
 
 F32, F64 = 0, 1
-ABI_VERSION = 5               # mlpg_hip_abi_version() of the library this binding was written for
+ABI_VERSION = 7               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE, ALGO_STRIP = 0, 1, 2, 3
 
@@ -26,6 +26,9 @@ EXPORTS = (
     "mlpg_hip_device_count",
     "mlpg_hip_shutdown",
     "mlpg_hip_forward",
+    "mlpg_hip_forward_host",
+    "mlpg_hip_host_alloc",
+    "mlpg_hip_host_free",
     "mlpg_hip_forward_streams",
     "mlpg_hip_backward",
     "mlpg_hip_delta_features",
@@ -37,6 +40,7 @@ EXPORTS = (
     "mlpg_hip_fastdtw",
     "mlpg_hip_fastdtw_l2",
     "mlpg_hip_gather_path",
+    "mlpg_hip_gmm_convert",
 )
 
 
@@ -75,6 +79,12 @@ def lib():
         L.mlpg_hip_shutdown.argtypes = []
         L.mlpg_hip_forward.restype = ci
         L.mlpg_hip_forward.argtypes = [ci, vp, ci, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
+        L.mlpg_hip_forward_host.restype = ci
+        L.mlpg_hip_forward_host.argtypes = [ci, ci, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
+        L.mlpg_hip_host_alloc.restype = vp
+        L.mlpg_hip_host_alloc.argtypes = [ctypes.c_size_t]
+        L.mlpg_hip_host_free.restype = None
+        L.mlpg_hip_host_free.argtypes = [vp]
         L.mlpg_hip_forward_streams.restype = ci
         L.mlpg_hip_forward_streams.argtypes = [ci, vp, ci, ci, vp, vp, ci, ctypes.c_int64, vp, ci, ci, ci, vp, ci, vp, vp, vp,
                                                vp, ctypes.c_int64, vp]
@@ -96,6 +106,8 @@ def lib():
         L.mlpg_hip_fastdtw_l2.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
         L.mlpg_hip_fastdtw.restype = ci
         L.mlpg_hip_fastdtw.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cd, vp, vp, vp, vp]
+        L.mlpg_hip_gmm_convert.restype = ci
+        L.mlpg_hip_gmm_convert.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
         L.mlpg_hip_gather_path.restype = ci
         L.mlpg_hip_gather_path.argtypes = [ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
         if L.mlpg_hip_abi_version() != ABI_VERSION:
@@ -217,6 +229,61 @@ def forward(mean, var, windows, lengths=None, algo=ALGO_AUTO, want_status=True):
                                 _p(lengths), B, T, D, nw, _np(wl), _np(wu), _np(wc), _p(out), _p(status))
     _check(rc, "mlpg_hip_forward")
     return out, status
+
+
+def forward_host(mean, var, windows, lengths=None, algo=ALGO_AUTO, device=0):
+    """Batched MLPG, numpy in -> numpy out through mlpg_hip_forward_host (no torch involved): mean (B, T, D)
+    float32/float64 C-contiguous, var same shape / (D,) / None, lengths int32 (B,) or None.
+    Returns (out (B, T, sd) ndarray, status int32 (B, sd))."""
+    L = lib()
+    if L.mlpg_hip_device_count() <= 0:
+        raise HipExtensionError("nnmnkwii_amd needs an AMD GPU (none visible to the HIP runtime); there is no CPU fallback")
+    assert mean.ndim == 3 and mean.flags.c_contiguous and mean.dtype in (np.float32, np.float64)
+    B, T, D = mean.shape
+    nw = _nw(windows)
+    wl, wu, wc = pack_windows(windows)
+    dt = F32 if mean.dtype == np.float32 else F64
+    if var is None:
+        mode = VAR_UNIT
+    else:
+        assert var.dtype == mean.dtype and var.flags.c_contiguous
+        mode = VAR_GLOBAL if var.ndim == 1 else VAR_FRAME
+        assert var.shape == ((D,) if var.ndim == 1 else mean.shape)
+    if lengths is not None:
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        assert lengths.shape == (B,)
+    out = np.empty((B, T, D // nw), dtype=mean.dtype)
+    status = np.zeros((B, D // nw), dtype=np.int32)
+    rc = L.mlpg_hip_forward_host(int(device), dt, algo, _np(mean), None if var is None else _np(var), mode,
+                                 None if lengths is None else _np(lengths), B, T, D, nw, _np(wl), _np(wu), _np(wc),
+                                 _np(out), _np(status))
+    _check(rc, "mlpg_hip_forward_host")
+    return out, status
+
+
+class _PinnedOwner(object):
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().mlpg_hip_host_free(ctypes.c_void_p(self.ptr))
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """An uninitialised numpy array in pinned (page-locked) host memory: forward_host transfers such arrays in place
+    (no staging copy), at the PCIe rate."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    ptr = lib().mlpg_hip_host_alloc(max(n, 1))
+    if not ptr:
+        raise HipExtensionError("mlpg_hip_host_alloc failed: %s" % lib().mlpg_hip_last_error().decode())
+    buf = (ctypes.c_char * max(n, 1)).from_address(ptr)
+    buf._owner = _PinnedOwner(ptr)     # freed when the last array viewing this buffer goes away
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 class StreamDesc(ctypes.Structure):
@@ -422,6 +489,21 @@ def gather_path(src, path, path_len, Tout):
     rc = lib().mlpg_hip_gather_path(src.device.index, _stream(src.device), _dt(src), _p(src), _p(path),
                                     _p(path_len), N, Tsrc, path.shape[1], D, Tout, _p(out))
     _check(rc, "mlpg_hip_gather_path")
+    return out
+
+
+def gmm_convert(x, posterior, mixture, mu_x, mu_y, A):
+    """out[n] = sum_m posterior[n, m] (mu_y[m] + A[m] (x[n] - mu_x[m])) on the GPU; float64 CUDA tensors:
+    x (N, D), posterior (N, M) or None, mixture int32 (N) or None, mu_x (M, D), mu_y (M, Dy), A (M, Dy, D)."""
+    torch = torch_mod()
+    assert x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.is_contiguous()
+    N, D = x.shape
+    M, Dy = mu_y.shape
+    assert mu_x.shape == (M, D) and A.shape == (M, Dy, D) and A.is_contiguous()
+    out = torch.empty((N, Dy), dtype=torch.float64, device=x.device)
+    rc = lib().mlpg_hip_gmm_convert(x.device.index, _stream(x.device), _p(x), _p(posterior), _p(mixture), _p(mu_x),
+                                    _p(mu_y), _p(A), N, D, Dy, M, _p(out))
+    _check(rc, "mlpg_hip_gmm_convert")
     return out
 
 

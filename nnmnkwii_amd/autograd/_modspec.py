@@ -22,7 +22,8 @@ class ModSpec(Function):
         ctx.norm = norm
         ctx.save_for_backward(y)
         dev = _hip.require_gpu(y.device if y.is_cuda else None)
-        ms, _ = _hip.modspec(y.detach().to(dev)[None], ctx.n, _norm_flag(norm))
+        # np.fft.rfft(y, n) crops a longer signal to its first n frames (autograd/_impl/modspec.py:30-35)
+        ms, _ = _hip.modspec(y.detach()[:ctx.n].to(dev)[None], ctx.n, _norm_flag(norm))
         return ms[0].to(device=y.device, dtype=y.dtype)
 
     @staticmethod
@@ -31,8 +32,12 @@ class ModSpec(Function):
         T, D = y.size()
         assert grad_output.size() == torch.Size((ctx.n // 2 + 1, D))
         dev = _hip.require_gpu(y.device if y.is_cuda else None)
-        g = _hip.modspec_backward(y.detach().to(dev)[None], grad_output.detach().to(dev)[None], ctx.n, _norm_flag(ctx.norm))
-        return g[0].to(device=y.device, dtype=y.dtype), None, None
+        Tc = min(T, ctx.n)
+        g = _hip.modspec_backward(y.detach()[:Tc].to(dev)[None], grad_output.detach().to(dev)[None], ctx.n, _norm_flag(ctx.norm))
+        g = g[0].to(device=y.device, dtype=y.dtype)
+        if Tc < T:  # frames beyond the DFT length do not reach the spectrum: zero gradient
+            g = torch.cat([g, g.new_zeros((T - Tc, D))], dim=0)
+        return g, None, None
 
 
 def modspec(y, n=2048, norm=None):

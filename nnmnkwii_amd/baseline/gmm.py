@@ -3,14 +3,17 @@
 Host-side mirror of /root/reference/nnmnkwii/baseline/gmm.py:46-247 (``MLPGBase``,
 ``MLPG``).  The mixture model itself stays with scikit-learn, as in the reference; what
 the reference does frame by frame in Python (one ``np.linalg.solve`` per frame and
-mixture, gmm.py:111-113,225-229) is evaluated here for the whole utterance at once with
-stacked LAPACK solves, and the trajectory generation -- the expensive part -- goes to the
-HIP MLPG kernels through :func:`nnmnkwii_amd.paramgen.mlpg`.
+mixture, gmm.py:111-113,225-229) is ONE launch of ``mlpg_hip_gmm_convert`` over all frames
+(the M regression matrices ``S_yx S_xx^-1`` are formed once per model on the host), and the
+trajectory generation -- the expensive part -- goes to the HIP MLPG kernels through
+:func:`nnmnkwii_amd.paramgen.mlpg`.  ``transform_batch`` converts a whole list of utterances
+with one launch (what ``IterativeDTWAligner`` calls every iteration).
 """
 import numpy as np
 from scipy import linalg as _sla
 from sklearn.mixture import GaussianMixture
 
+from .. import _hip
 from ..paramgen import mlpg as _mlpg
 
 
@@ -65,36 +68,55 @@ class MLPGBase(object):
         px.precisions_cholesky_ = _precisions_cholesky_full(px.covariances_)
         self.px = px
 
-    def _conditional_means(self, src, mix=None):
-        """E_m[y | x_t] = mu_y[m] + S_yx[m] S_xx[m]^-1 (x_t - mu_x[m]).
+    def _regression(self):
+        """A[m] = S_yx[m] S_xx[m]^-1, (M, Dy, D), formed once per model (host LAPACK, M small systems)."""
+        A = getattr(self, "_A", None)
+        if A is None:
+            # A^T = S_xx^-1 S_xy  (S_xx symmetric)
+            A = np.ascontiguousarray(np.linalg.solve(self.covarXX, self.covarYX.transpose(0, 2, 1)).transpose(0, 2, 1))
+            self._A = A
+        return A
 
-        ``mix`` None: all mixtures -> (T, M, D); else per-frame mixture indices -> (T, D).
-        One stacked LAPACK solve replaces the reference's Python double loop.
-        """
-        src = np.asarray(src, dtype=np.float64)
-        if mix is None:
-            dev = src[:, None, :] - self.src_means[None]                   # (T, M, D)
-            z = np.linalg.solve(self.covarXX[None], dev[..., None])        # (T, M, D, 1)
-            return self.tgt_means[None] + np.matmul(self.covarYX[None], z)[..., 0]
-        dev = src - self.src_means[mix]
-        z = np.linalg.solve(self.covarXX[mix], dev[..., None])
-        return self.tgt_means[mix] + np.matmul(self.covarYX[mix], z)[..., 0]
+    def _convert(self, src, posterior=None, mix=None):
+        """sum_m posterior[n, m] (mu_y[m] + A[m] (x_n - mu_x[m])) for all rows of ``src`` in one GPU launch
+        (``mix``: one mixture per row instead of posterior weights).  Returns a float64 ndarray."""
+        torch = _hip.torch_mod()
+        dev = _hip.require_gpu()
+        f64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
+        x = f64(src)
+        post = f64(posterior) if posterior is not None else None
+        mx = torch.from_numpy(np.ascontiguousarray(mix, dtype=np.int32)).to(dev) if mix is not None else None
+        out = _hip.gmm_convert(x, post, mx, f64(self.src_means), f64(self.tgt_means), f64(self._regression()))
+        return out.cpu().numpy()
 
     def _transform_frame(self, src):
         """One frame (D,) -> E[p(y|x)] (gmm.py:97-120)."""
         src = np.asarray(src)
-        E = self._conditional_means(src[None])[0]                         # (M, D)
         posterior = self.px.predict_proba(np.atleast_2d(src))             # (1, M)
-        return posterior.dot(E).flatten()
+        return self._convert(np.atleast_2d(src), posterior)[0]
 
     def transform(self, src):
         if src.ndim != 2:
             return self._transform_frame(src)
-        E = self._conditional_means(src)                                  # (T, M, D)
-        posterior = self.px.predict_proba(src)                            # (T, M)
+        posterior = self.px.predict_proba(src)                            # (T, M): scikit-learn, as the reference
         tgt = np.zeros_like(src)                                          # dtype of src (gmm.py:89)
-        tgt[...] = np.einsum("tm,tmd->td", posterior, E)
+        tgt[...] = self._convert(src, posterior)
         return tgt
+
+    def transform_batch(self, utterances):
+        """``[transform(x) for x in utterances]`` with one posterior evaluation and one GPU launch over all frames."""
+        utterances = [np.asarray(u) for u in utterances]
+        if not utterances:
+            return []
+        allx = np.concatenate(utterances, axis=0)
+        y = self._convert(allx, self.px.predict_proba(allx))
+        out, o = [], 0
+        for u in utterances:
+            t = np.zeros_like(u)
+            t[...] = y[o:o + len(u)]
+            out.append(t)
+            o += len(u)
+        return out
 
 
 class MLPG(MLPGBase):
@@ -116,7 +138,7 @@ class MLPG(MLPGBase):
         if src.shape[1] == self.static_dim:
             return super(MLPG, self).transform(src)
         mix = self.px.predict(src)                                        # sub-optimum mixture sequence, eq. 37
-        E = self._conditional_means(src, mix)                             # eq. 22 / 40
+        E = self._convert(src, mix=mix)                                   # eq. 22 / 40
         dg = lambda a: np.diagonal(a, axis1=1, axis2=2)                   # noqa: E731
         Dm = dg(self.covarYY) - dg(self.covarYX) / dg(self.covarXX) * dg(self.covarXY)   # eq. 23, diagonal approx.
         return _mlpg(E, np.ascontiguousarray(Dm[mix]), self.windows)

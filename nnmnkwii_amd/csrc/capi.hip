@@ -124,6 +124,12 @@ int pack_windows(int nw, const int32_t *wl, const int32_t *wu, const double *wc,
   return 0;
 }
 
+}  // namespace
+int pack_windows_public(int nw, const int32_t *wl, const int32_t *wu, const double *wc, WinSet *ws) {
+  return pack_windows(nw, wl, wu, wc, ws);
+}
+namespace {
+
 struct DeviceGuard {
   int prev = -1;
   bool ok = true;
@@ -150,6 +156,8 @@ int check_common(int B, int Tmax, int D, int nw) {
   return 0;
 }
 
+}  // namespace
+
 // Kernel choice: AUTO = strip kernel for wide streams (static dims on lanes), wave-per-system kernel for narrow
 // ones, generic kernel for window extents > 1 or utterances longer than either supports.
 int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool backward, const Problem &p,
@@ -174,6 +182,8 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
   if (algo == MLPG_HIP_ALGO_WAVE) return launch_wave(st, in_dtype, out_dtype, backward, p, ws, device);
   return launch_generic(st, in_dtype, out_dtype, backward, p, ws, device);
 }
+
+namespace {
 
 int solve_entry(int device, void *stream, int in_dtype, int out_dtype, int algo, bool backward, const void *mean,
                 const void *var, int var_mode, const void *grad_out, const int32_t *lengths, int B, int Tmax,
@@ -262,7 +272,7 @@ using namespace mlpg;
 
 extern "C" {
 
-__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 5; }
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 7; }
 
 __attribute__((visibility("default"))) const char *mlpg_hip_last_error(void) { return g_err; }
 
@@ -530,6 +540,28 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw_l2(int device, void 
                                                                int32_t *path_len, double *cost) {
   return mlpg_hip_fastdtw(device, stream, X, Y, lenx, leny, N, Tx, Ty, D, radius, MLPG_HIP_DIST_L2, 1.0, path_i, path_j,
                           path_len, cost);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_gmm_convert(int device, void *stream, const double *x,
+                                                                const double *posterior, const int32_t *mixture,
+                                                                const double *mu_x, const double *mu_y,
+                                                                const double *A, int64_t N, int D, int Dy, int M,
+                                                                double *out) {
+  if (N < 0 || D < 1 || Dy < 1 || M < 1) {
+    set_error("gmm_convert: bad sizes");
+    return MLPG_HIP_EINVAL;
+  }
+  if (N == 0) return 0;
+  if (!x || !mu_x || !mu_y || !A || !out || (!posterior && !mixture)) {
+    set_error("gmm_convert: NULL pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  return launch_gmm_convert((hipStream_t)stream, x, posterior, mixture, mu_x, mu_y, A, (long)N, D, Dy, M, out);
 }
 
 __attribute__((visibility("default"))) int mlpg_hip_gather_path(int device, void *stream, int dtype, const void *src,

@@ -69,6 +69,8 @@ int launch_trim(hipStream_t s, int dtype, const void *X, int N, int T, int D, do
 int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, const int32_t *lenx,
                    const int32_t *leny, int N, int Tx, int Ty, int D, int radius, int dist_kind, double dist_scale,
                    int32_t *path_i, int32_t *path_j, int32_t *path_len, double *cost);
+int launch_gmm_convert(hipStream_t s, const double *x, const double *post, const int32_t *mix, const double *mu_x,
+                       const double *mu_y, const double *A, long N, int D, int Dy, int M, double *out);
 int launch_gather(hipStream_t s, int dtype, const void *src, const int32_t *path, const int32_t *path_len, int N,
                   int Tsrc, int path_stride, int D, int Tout, void *out);
 

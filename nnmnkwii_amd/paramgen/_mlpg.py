@@ -109,14 +109,11 @@ def mlpg_batch(means, variances, windows, lengths=None, algo=_hip.ALGO_AUTO, che
     frames beyond it are zero.  Returns the same kind of object as ``means``,
     shape ``(B, Tmax, D // len(windows))``.
     """
+    if isinstance(means, np.ndarray) or not hasattr(means, "is_cuda"):
+        return _mlpg_batch_host(means, variances, windows, lengths, algo, check, device)
     torch = _hip.torch_mod()
-    is_np = not torch.is_tensor(means)
-    dev = _hip.require_gpu(device if is_np or not means.is_cuda else means.device)
-    if is_np:
-        means_h = np.ascontiguousarray(_as_float(means))
-        m = torch.from_numpy(means_h).to(dev)
-    else:
-        m = means.to(dev).contiguous()
+    dev = _hip.require_gpu(means.device if means.is_cuda else device)
+    m = means.to(dev).contiguous()
     assert m.dim() == 3
     out_dtype = m.dtype
     if variances is None:
@@ -136,9 +133,42 @@ def mlpg_batch(means, variances, windows, lengths=None, algo=_hip.ALGO_AUTO, che
         _hip.raise_on_status(status, out.shape[-1])
     if out.dtype != out_dtype:
         out = out.to(out_dtype)                            # output dtype = dtype of the means (_mlpg.py:166,183)
-    if is_np:
-        return out.cpu().numpy()
     return out
+
+
+def _mlpg_batch_host(means, variances, windows, lengths, algo, check, device):
+    """numpy in -> numpy out through the host-pointer entry point of the C ABI (no torch): chunked, with the PCIe
+    transfers overlapped with the kernels (include/mlpg_hip.h mlpg_hip_forward_host)."""
+    m = np.ascontiguousarray(_as_float(means))
+    assert m.ndim == 3
+    out_dtype = m.dtype
+    v = None
+    if variances is not None:
+        v = np.ascontiguousarray(_as_float(variances))
+        if v.ndim != 1:
+            assert v.shape == m.shape                      # paramgen/_mlpg.py:171
+        if v.dtype != m.dtype:                             # see _match_dtypes: reciprocal in the variances' dtype
+            if m.dtype == np.float64:
+                v = 1.0 / (np.float32(1.0) / v).astype(np.float64)
+            else:
+                m = m.astype(np.float64)
+    dev_index = 0
+    if device is not None:                                 # int, "cuda:1" or an object with .index
+        idx = getattr(device, "index", device)
+        if isinstance(idx, str):
+            idx = idx.split(":")[-1] if ":" in idx else 0
+        dev_index = 0 if idx is None else int(idx)
+    out, status = _hip.forward_host(m, v, windows, lengths, algo=algo, device=dev_index)
+    if check:
+        st = status.ravel()
+        bad = np.flatnonzero(st)
+        if bad.size:
+            k = int(st[bad[0]])
+            if k > 0:
+                raise np.linalg.LinAlgError("%d-th leading minor not positive definite" % k)
+            raise np.linalg.LinAlgError("the blocked elimination broke down (numerically singular system)" if k == -2
+                                        else "internal error: inter-workgroup wait timed out")
+    return out if out.dtype == out_dtype else out.astype(out_dtype)
 
 
 def multi_stream_mlpg(inputs, variances, windows, stream_sizes, has_dynamic_features, lengths=None,

@@ -189,9 +189,9 @@ class IterativeDTWAligner(object):
             gmm.fit(joint)                                     # :170-178
             conv = MLPG(gmm, windows=[(0, 0, np.array([1.0]))])   # no delta: frame-wise conversion (:179-180)
             nx = lenx.cpu().numpy()                            # trim_zeros_frames(Xc[idx]) of this iteration
+            converted = conv.transform_batch([Xc[idx][: int(nx[idx])] for idx in range(N)])   # one launch (:181-183)
             for idx in range(N):
-                x = Xc[idx][: int(nx[idx])]
-                Xc[idx][: len(x)] = conv.transform(x)          # :181-183
+                Xc[idx][: len(converted[idx])] = converted[idx]
 
         for idx in range(N):                                   # aligned ORIGINAL X (:186-188)
             n = int(plen[idx])

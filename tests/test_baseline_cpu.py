@@ -1,5 +1,6 @@
-"""Host logic of baseline.gmm (no GPU): the frame-wise conversion (MLPGBase) is plain numpy + sklearn
-and must match the reference's baseline/gmm.py on the goldens it produced (make_golden_align.py)."""
+"""baseline.gmm: host logic (attributes, swap/diff algebra: no GPU) and the frame-wise conversion (MLPGBase: one
+mlpg_hip_gmm_convert launch; -m gpu) against the reference's baseline/gmm.py on the goldens it produced
+(make_golden_align.py)."""
 import os
 import sys
 
@@ -19,6 +20,7 @@ def _gmm(golden, key, prefix=""):
     return g
 
 
+@pytest.mark.gpu
 def test_framewise_conversion_matches_reference():
     from nnmnkwii_amd.baseline.gmm import MLPG, MLPGBase
     golden = np.load(os.path.join(HERE, "golden", "align_golden.npz"))
@@ -36,6 +38,9 @@ def test_framewise_conversion_matches_reference():
         np.testing.assert_allclose(MLPGBase(gs).transform(s[0, :3]), ref[0], rtol=1e-10, atol=1e-12)
         # output dtype follows the input (gmm.py:89 zeros_like)
         assert MLPGBase(gs).transform(s[:, :3].astype(np.float32)).dtype == np.float32
+        # the batched form used by IterativeDTWAligner
+        parts = MLPGBase(gs).transform_batch([s[:7, :3], s[7:, :3]])
+        np.testing.assert_allclose(np.concatenate(parts), ref, rtol=1e-10, atol=1e-12)
 
 
 def test_attributes_and_swap_diff_algebra():

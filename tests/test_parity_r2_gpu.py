@@ -168,3 +168,46 @@ def test_dtw_aligner_dist_resolution():
     a = DTWAligner(dist=lambda x, y: norm(x - y)).transform((X, Y))
     b = DTWAligner().transform((X, Y))
     np.testing.assert_array_equal(a[0], b[0])
+
+
+def test_host_entry_point_numpy_in_numpy_out():
+    """mlpg_hip_forward_host (chunked, overlapped staging; no torch on the path): several chunks, ragged lengths,
+    every variance mode, float32 and float64, pageable and pinned host arrays -- against the oracle."""
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd import paramgen as G
+    windows = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(3)
+    B, T, sd = 37, 300, 60           # 37 utterances: chunks of 10 (the last one short)
+    M_ = rng.randn(B, T, 3 * sd)
+    V_ = rng.rand(B, T, 3 * sd) + 0.1
+    lengths = rng.randint(1, T + 1, size=B).astype(np.int32)
+    lengths[5] = T
+    yo, _, rc = O.mlpg_batch(M_, V_, windows, lengths)
+    assert rc == 0
+    y, st = _hip.forward_host(M_, V_, windows, lengths)
+    assert not st.any() and y.dtype == np.float64
+    sc = np.abs(yo).max(axis=1, keepdims=True) + 1e-300
+    assert (np.abs(y - yo) / sc).max() <= 1e-9
+    # pinned arrays are transferred in place
+    Mp, Vp = _hip.pinned_empty(M_.shape), _hip.pinned_empty(V_.shape)
+    Mp[...] = M_
+    Vp[...] = V_
+    y2, _ = _hip.forward_host(Mp, Vp, windows, lengths)
+    assert np.array_equal(y2, y)
+    # the drop-in batch call takes this path for numpy inputs; global / unit variances; float32
+    y3 = G.mlpg_batch(M_, V_, windows, lengths)
+    assert np.array_equal(y3, y)
+    vg = V_[0, 0].copy()
+    yg = G.mlpg_batch(M_, vg, windows, lengths)
+    ygo, _, _ = O.mlpg_batch(M_, vg, windows, lengths)
+    assert (np.abs(yg - ygo) / (np.abs(ygo).max(axis=1, keepdims=True) + 1e-300)).max() <= 1e-9
+    M32 = M_.astype(np.float32)
+    yu = G.mlpg_batch(M32, None, windows, lengths)
+    yuo, _, _ = O.mlpg_batch(M32, np.ones(3 * sd, dtype=np.float32), windows, lengths)
+    assert yu.dtype == np.float32
+    assert (np.abs(yu - yuo) / (np.abs(yuo).max(axis=1, keepdims=True) + 1e-300)).max() <= 5e-6
+    # a non-positive-definite system is reported like the reference does
+    Vb = V_.copy()
+    Vb[20, 100, 7] = -1e-3
+    with pytest.raises(np.linalg.LinAlgError):
+        G.mlpg_batch(M_, Vb, windows, lengths=None)

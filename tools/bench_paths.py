@@ -125,8 +125,19 @@ def main():
         wall = (time.perf_counter() - t0) / nrep
         by = 56.0 * sd * B * T
         emit(path="c2h-numpy-to-numpy-mlpg_batch", ms=wall * 1e3, frames_per_s=B * T / wall, alg_bytes=by,
-             GBps=by / wall / 1e9, note="pageable host arrays: H2D of 737 MB + kernel + D2H of 123 MB + status check")
-        del mh, vh, yh
+             GBps=by / wall / 1e9, note="pageable host arrays through mlpg_hip_forward_host: chunked, staged by copy threads, transfers overlapped with the kernels")
+        # the same from pinned host arrays (nnmnkwii_amd._hip.pinned_empty): transferred in place, no staging copies
+        mp, vp = _hip.pinned_empty(mh.shape), _hip.pinned_empty(vh.shape)
+        mp[...] = mh
+        vp[...] = vh
+        G.mlpg_batch(mp[:8], vp[:8], WINDOWS)
+        t0 = time.perf_counter()
+        for _ in range(nrep):
+            yh = G.mlpg_batch(mp, vp, WINDOWS)
+        wall = (time.perf_counter() - t0) / nrep
+        emit(path="c2h-numpy-to-numpy-mlpg_batch-pinned-inputs", ms=wall * 1e3, frames_per_s=B * T / wall, alg_bytes=by,
+             GBps=by / wall / 1e9, note="pinned inputs, pageable output: PCIe floor ~14 ms for 860 MB at Gen5 x16")
+        del mh, vh, yh, mp, vp
 
     # ---- c2b: backward (mlpg_hip_backward) at config-2 scale, float64 and float32 ----
     if want("c2b"):

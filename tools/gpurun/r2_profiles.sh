@@ -5,10 +5,10 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 sum() { f=$(find gpurun_out/$1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py "$f" $2 > gpurun_out/$1.txt 2>&1; rm -rf gpurun_out/$1; }
 # 1. the driver's command form (default kernel choice), with the CPU baseline leg
 rocprofv3 --kernel-trace --stats -d gpurun_out/r02_bench_default -o run -- python bench.py --steps 20 --warmup 3 > gpurun_out/r02_bench_default.log 2>&1
-tail -1 gpurun_out/r02_bench_default.log > gpurun_out/r02_bench_default.json; sum r02_bench_default
+grep "^{" gpurun_out/r02_bench_default.log | tail -1 > gpurun_out/r02_bench_default.json; sum r02_bench_default
 # 2. the strip kernel on the same workload
 rocprofv3 --kernel-trace --stats -d gpurun_out/r02_bench_strip -o run -- python bench.py --steps 20 --warmup 3 --algo 3 --no-cpu-baseline > gpurun_out/r02_bench_strip.log 2>&1
-tail -1 gpurun_out/r02_bench_strip.log > gpurun_out/r02_bench_strip.json; sum r02_bench_strip
+grep "^{" gpurun_out/r02_bench_strip.log | tail -1 > gpurun_out/r02_bench_strip.json; sum r02_bench_strip
 # 3. PMC passes (own runs, kernel-trace only), default kernel and strip kernel
 for a in 0 3; do
   for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
