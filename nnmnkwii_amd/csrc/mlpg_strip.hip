@@ -36,7 +36,7 @@ int launch_strip(hipStream_t st, int dtype, int out_dtype, bool backward, const 
   const int ndg = (p.sd + 63) / 64;
   const int dgw = (p.sd + ndg - 1) / ndg;
   const size_t nsg = (size_t)p.B * ndg;
-  const size_t ctrl = ((1 + 8 + nsg) * 32 * sizeof(int) + 255) / 256 * 256;  // strip::ctrl_bytes
+  const size_t ctrl = (((1 + 8 + nsg) * 32 + nsg * (size_t)((R + 31) / 32 * 32)) * sizeof(int) + 255) / 256 * 256;  // strip::ctrl_bytes
   void *sc = scratch(device, st, 3, ctrl + nsg * R * kRecBytes);
   if (!sc) return MLPG_HIP_ENOMEM;
   if (!backward)

@@ -67,10 +67,25 @@ enum { rT00, rT01, rT11, rH0, rH1, rD11, rD12, rD22, rF1, rF2, rL11, rL12, rL21,
 
 // Control words, one per 128-byte line (32 ints) so that the pollers of one utterance, the ticket draws and the
 // arrivals of other utterances never queue on the same L2 line:
-//   line 0: spin time-outs;  lines 1 .. 8: ticket of work list x;  line 9 + g: arrivals of system group g.
+//   line 0: spin time-outs;  lines 1 .. 8: ticket of work list x;  line 9 + g: arrivals of system group g;
+//   then one flag per strip, Rpad = R rounded up to a line per system group: flag[g * Rpad + r].
 constexpr int kCtrlLine = 32;
 constexpr int kMaxLists = 8;
-__host__ __device__ inline size_t ctrl_ints(int nsg) { return (size_t)(1 + kMaxLists + nsg) * kCtrlLine; }
+constexpr int kLocal = 2;          // level 3 first looks at the records of strips r-2 .. r+2 only
+constexpr double kDampTol = 1e-22; // ... and accepts that if the window's edges are damped below this at rows r-1, r
+// the records strip r of Ract reads first: rows lo .. hiE; the last one only as the clamped edge (T, h, V) if `edge`
+struct Window { int lo, hiE, edge; };
+__device__ __forceinline__ Window local_window(int r, int Ract) {
+  Window w;
+  w.lo = r - kLocal < 0 ? 0 : r - kLocal;
+  w.edge = r + kLocal < Ract - 1;
+  w.hiE = w.edge ? r + kLocal : Ract - 1;
+  return w;
+}
+__host__ __device__ inline int flag_pitch(int R) { return (R + kCtrlLine - 1) / kCtrlLine * kCtrlLine; }
+__host__ __device__ inline size_t ctrl_ints(int nsg, int R) {
+  return (size_t)(1 + kMaxLists + nsg) * kCtrlLine + (size_t)nsg * flag_pitch(R);
+}
 
 struct Args {
   int *ctrl;
@@ -124,6 +139,13 @@ __device__ __forceinline__ M2 mul_ms(const M2 &L, const S2 &S) {  // L S
 }
 __device__ __forceinline__ M2 mul_sm(const S2 &S, const M2 &V) {  // S V
   return {S.a * V.a + S.b * V.c, S.a * V.b + S.b * V.d, S.b * V.a + S.c * V.c, S.b * V.b + S.c * V.d};
+}
+__device__ __forceinline__ M2 mul_smt(const S2 &S, const M2 &V) {  // S V^T
+  return {S.a * V.a + S.b * V.b, S.a * V.c + S.b * V.d, S.b * V.a + S.c * V.b, S.b * V.c + S.c * V.d};
+}
+__device__ __forceinline__ double amax4(const M2 &m) {  // twice this bounds the block's 2-norm
+  return __builtin_fmax(__builtin_fmax(__builtin_fabs(m.a), __builtin_fabs(m.b)),
+                        __builtin_fmax(__builtin_fabs(m.c), __builtin_fabs(m.d)));
 }
 __device__ __forceinline__ M2 mul_mm(const M2 &A, const M2 &B) {
   return {A.a * B.a + A.b * B.c, A.a * B.b + A.b * B.d, A.c * B.a + A.d * B.c, A.c * B.b + A.d * B.d};
@@ -591,17 +613,28 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       st_agent(rp + 12 * 64, hs.x); st_agent(rp + 13 * 64, hs.y);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       STRIP_TICK(5);
+      // announce: the utterance's arrival counter (for the full sweep) and this strip's own flag (for the neighbours)
+      int *cnt = a.ctrl + (1 + kMaxLists + g) * kCtrlLine;
+      int *flags = a.ctrl + (1 + kMaxLists + a.nsg) * kCtrlLine + (size_t)g * flag_pitch(R);
       if (lane == 0) {
-        int *cnt = a.ctrl + (1 + kMaxLists + g) * kCtrlLine;
+        __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flags + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // wait for the strips of the local window only: lane l polls the flag of strip wlo + l
+      {
+        const Window w = local_window(r, Ract);
         int spins = 0, ok = 1;
-        if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 < Ract) {
-          do {
-            __builtin_amdgcn_s_sleep(32);
-            if (++spins > kSpinLimit) { ok = 0; break; }
-          } while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < Ract);
+        for (;;) {
+          int f = 1;
+          if (lane <= w.hiE - w.lo) f = __hip_atomic_load(flags + w.lo + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__ballot(f == 0) == 0ull) break;
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > kSpinLimit) { ok = 0; break; }
         }
-        if (!ok) atomicAdd(a.ctrl, 1);
-        lds_misc[1] = ok;
+        if (lane == 0) {
+          if (!ok) atomicAdd(a.ctrl, 1);
+          lds_misc[1] = ok;
+        }
       }
       STRIP_TICK(6);
     }
@@ -614,81 +647,131 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
     V2 sig = {0.0, 0.0}, sprev = {0.0, 0.0};  // solution on this strip's last separator / the previous strip's
     if (xwg) {
       timed_out = !__builtin_amdgcn_readfirstlane(lds_misc[1]);
-      {
-      // Two sweeps over the utterance's records, no factor stored: top-down over rows 0 .. r-1 (row j is finalised
-      // when row j+1 is at hand: A_j = E_j - T_{j+1} - Mn_j V_j^T with Mn_j = V_j A_{j-1}^-1, a_j likewise), then
-      // bottom-up over rows R-1 .. r+1 (the Schur complement (S, s) of the rows below row j:
-      // B_j = E_j - T_{j+1} - S, S' = V_j^T B_j^-1 V_j), and the 2-block system of rows r-1 and r in the middle.
-      // The records are staged in exactly that order: rows 0 .. r, then rows R-1 .. r (row r twice; nothing of the
-      // first part if r = 0).  Two register arrays hold the previous and the current record and swap roles every
-      // row: the next record is read from LDS into the previous one's array as soon as that one is used up.
-      const int ntop = r > 0 ? r + 1 : 0, npos = ntop + (Ract - r);
-      S2 Ainv = {0.0, 0.0, 0.0};
-      V2 av = {0.0, 0.0};
-      M2 Mn = {0.0, 0.0, 0.0, 0.0};
-      S2 Sb = {0.0, 0.0, 0.0}, Tn = {0.0, 0.0, 0.0};
-      V2 sb = {0.0, 0.0}, hn = {0.0, 0.0};
-      bool bad3 = false;
-      // the pending row of the top-down sweep (E, g, V of row j until row j+1 arrives)
-      S2 Ej = {0.0, 0.0, 0.0};
-      V2 gj = {0.0, 0.0};
-      M2 Vj = {0.0, 0.0, 0.0, 0.0};
-      for (int p0 = 0; p0 < npos; p0 += kStage) {
-        const int kn = npos - p0 < kStage ? npos - p0 : kStage;
-        __syncthreads();  // this batch is in LDS
-        STRIP_TICK(8);
-        if (!timed_out) {
+      // Two sweeps over the records of rows lo .. hiE, no factor stored: top-down over rows lo .. r-1 (row j is
+      // finalised when row j+1 is at hand: A_j = E_j - T_{j+1} - Mn_j V_j^T with Mn_j = V_j A_{j-1}^-1, a_j likewise),
+      // bottom-up over rows hiE .. r+1 (the Schur complement (S, s) of the rows below row j: B_j = E_j - T_{j+1} - S,
+      // S' = V_j^T B_j^-1 V_j), and the 2-block system of rows r-1 and r in the middle.  The records are staged in
+      // exactly that order: rows lo .. r, then rows hiE .. r (row r twice; nothing of the first part if r = lo).
+      // With lo = 0, hiE = Ract-1 this is the exact solve.  A narrower window clamps the separators just outside it
+      // to zero: separator lo-1 (record lo holds strip lo's interior and its coupling V_lo to that separator) and,
+      // with `edge`, separator hiE (record hiE is read for T, h -- that strip's interior -- and its coupling V only).
+      // What this ignores is exactly V_lo u_{lo-1} on the window's first row and V_hiE^T u_hiE on its last, and
+      // they reach rows r-1, r through the transfer matrices of the two eliminations:
+      //     top:     |du_{r-1}| <= prod_{j=lo}^{r-1} |A_j^-1 V_j| |u_{lo-1}|,    du_r: one more factor |S_r^-1 V_r|
+      //     bottom:  |du_r| <= |S_r^-1 V_{r+1}^T| prod_{j=r+1}^{hiE-1} |B_j^-1 V_{j+1}^T| |u_hiE|,
+      //              du_{r-1}: one more factor |A_{r-1}^-1 V_r^T|
+      // (|.| of a 2x2 block <= twice its largest entry).  `damp` is the larger product.  Separators 64 frames apart
+      // are coupled by ~1e-20 for ordinary variances, so the window reproduces the exact solve to the last bit;
+      // where the bound says otherwise (long spans of vanishing static precision) the sweep is repeated over the
+      // whole utterance.  tools/strip_model.py: utterance_solve_two_sided.
+      double damp = 0.0;
+      auto sweep = [&](const int lo, const int hiE, const int edge) __attribute__((always_inline)) {
+        const int ntop = r > lo ? r - lo + 1 : 0, npos = ntop + (hiE - r + 1);
+        S2 Ainv = {0.0, 0.0, 0.0};
+        V2 av = {0.0, 0.0};
+        M2 Mn = {0.0, 0.0, 0.0, 0.0};
+        S2 Sb = {0.0, 0.0, 0.0}, Tn = {0.0, 0.0, 0.0};
+        V2 sb = {0.0, 0.0}, hn = {0.0, 0.0};
+        M2 Vn = {0.0, 0.0, 0.0, 0.0};  // coupling of the row below to the current one
+        double dt = lo > 0 ? 1.0 : 0.0, db = edge ? 1.0 : 0.0;
+        bool bad3 = false;
+        // the pending row of the top-down sweep (E, g, V of row j until row j+1 arrives)
+        S2 Ej = {0.0, 0.0, 0.0};
+        V2 gj = {0.0, 0.0};
+        M2 Vj = {0.0, 0.0, 0.0, 0.0};
+        for (int p0 = 0; p0 < npos; p0 += kStage) {
+          const int kn = npos - p0 < kStage ? npos - p0 : kStage;
+          __syncthreads();  // this batch is in LDS
+          STRIP_TICK(8);
+          if (!timed_out) {
 #ifndef MLPG_L3_NOPRIO
-          __builtin_amdgcn_s_setprio(2);  // the whole workgroup waits for this chain
+            __builtin_amdgcn_s_setprio(2);  // the whole workgroup waits for this chain
 #endif
-          for (int q = 0; q < kn; ++q) {
-            const int pos = p0 + q;
-            double cur[kRec];
+            for (int q = 0; q < kn; ++q) {
+              const int pos = p0 + q;
+              double cur[kRec];
 #pragma unroll
-            for (int kk = 0; kk < kRec; ++kk) cur[kk] = lds_stage[(q * kRec + kk) * 64 + lane];
-            const S2 Ek = {cur[0], cur[1], cur[2]};
-            const V2 gk = {cur[3], cur[4]};
-            const M2 Vk = {cur[5], cur[6], cur[7], cur[8]};
-            const S2 Tk = {cur[9], cur[10], cur[11]};
-            const V2 hk = {cur[12], cur[13]};
-            if (pos < ntop) {
-              // top-down: row k = pos has arrived; row j = k-1 is finalised
-              if (pos > 0) {
-                const S2 A = sub(sub(Ej, Tk), mul_mmt_sym(Mn, Vj));  // Mn = 0 for j = 0
-                const V2 aa = sub(sub(gj, hk), mul_mv(Mn, av));
-                Ainv = sym_inv(A, bad3);
-                av = aa;
-                Mn = mul_ms(Vk, Ainv);  // V_{j+1} A_j^-1
-              }
-              Ej = Ek; gj = gk; Vj = Vk;
-            } else {
-              S2 B = sub(sub(Ek, Tn), Sb);
-              V2 bv = sub(sub(gk, hn), sb);
-              if (pos + 1 < npos) {
-                // bottom-up: row j > r
-                const S2 Binv = sym_inv(B, bad3);
-                Sb = mul_mtm_sym(Vk, mul_sm(Binv, Vk));
-                sb = mul_mtv(Vk, mul_sv(Binv, bv));
-                Tn = Tk;
-                hn = hk;
-              } else {
-                // middle: row r
-                if (r > 0) {  // Mn = V_r A_{r-1}^-1 from the top-down sweep
-                  B = sub(B, mul_mmt_sym(Mn, Vk));
-                  bv = sub(bv, mul_mv(Mn, av));
+              for (int kk = 0; kk < kRec; ++kk) cur[kk] = lds_stage[(q * kRec + kk) * 64 + lane];
+              const S2 Ek = {cur[0], cur[1], cur[2]};
+              const V2 gk = {cur[3], cur[4]};
+              const M2 Vk = {cur[5], cur[6], cur[7], cur[8]};
+              const S2 Tk = {cur[9], cur[10], cur[11]};
+              const V2 hk = {cur[12], cur[13]};
+              if (pos < ntop) {
+                // top-down: row lo + pos has arrived; the row before it is finalised
+                if (pos > 0) {
+                  const S2 A = sub(sub(Ej, Tk), mul_mmt_sym(Mn, Vj));  // Mn = 0 for the window's first row
+                  const V2 aa = sub(sub(gj, hk), mul_mv(Mn, av));
+                  Ainv = sym_inv(A, bad3);
+                  av = aa;
+                  Mn = mul_ms(Vk, Ainv);  // V_{j+1} A_j^-1
+                  dt *= 2.0 * amax4(mul_sm(Ainv, Vj));
                 }
-                const S2 Binv = sym_inv(B, bad3);
-                sig = mul_sv(Binv, bv);
-                if (r > 0) sprev = sub(mul_sv(Ainv, av), mul_mtv(Mn, sig));  // A^-1 (a - V_r^T sigma_r)
-                if (bad3) sig.x = __builtin_nan("");
+                Ej = Ek; gj = gk; Vj = Vk;
+              } else if (edge && pos == ntop) {
+                // the clamped edge below the window: only its strip's interior and its coupling count
+                Tn = Tk; hn = hk; Vn = Vk;
+              } else {
+                S2 B = sub(sub(Ek, Tn), Sb);
+                V2 bv = sub(sub(gk, hn), sb);
+                if (pos + 1 < npos) {
+                  // bottom-up: row j > r
+                  const S2 Binv = sym_inv(B, bad3);
+                  db *= 2.0 * amax4(mul_smt(Binv, Vn));
+                  const M2 Wm = mul_sm(Binv, Vk);
+                  Sb = mul_mtm_sym(Vk, Wm);
+                  sb = mul_mtv(Vk, mul_sv(Binv, bv));
+                  Tn = Tk; hn = hk; Vn = Vk;
+                } else {
+                  // middle: row r
+                  if (r > lo) {  // Mn = V_r A_{r-1}^-1 from the top-down sweep
+                    B = sub(B, mul_mmt_sym(Mn, Vk));
+                    bv = sub(bv, mul_mv(Mn, av));
+                  }
+                  const S2 Binv = sym_inv(B, bad3);
+                  sig = mul_sv(Binv, bv);
+                  sprev = {0.0, 0.0};
+                  db *= 2.0 * amax4(mul_smt(Binv, Vn));
+                  if (r > lo) {
+                    sprev = sub(mul_sv(Ainv, av), mul_mtv(Mn, sig));  // A^-1 (a - V_r^T sigma_r)
+                    dt *= __builtin_fmax(1.0, 2.0 * amax4(mul_sm(Binv, Vk)));
+                    db *= __builtin_fmax(1.0, 2.0 * amax4(mul_smt(Ainv, Vk)));
+                  }
+                  if (bad3) sig.x = __builtin_nan("");
+                }
               }
             }
+            __builtin_amdgcn_s_setprio(0);
           }
-          __builtin_amdgcn_s_setprio(0);
+          STRIP_TICK(9);
+          __syncthreads();  // done with this batch
         }
-        STRIP_TICK(9);
-        __syncthreads();  // done with this batch
+        damp = dt > db ? dt : db;
+      };
+      const Window w = local_window(r, Ract);
+      sweep(w.lo, w.hiE, w.edge);
+      // accept the windowed result only if every system of the strip is damped far below the rounding level and
+      // met no failing pivot (those are re-examined on the whole utterance, so that the verdict never depends on
+      // the window)
+      const bool full_range = w.lo == 0 && !w.edge;
+      const bool lane_fine = !lane_ok || full_range || (damp < kDampTol && sig.x == sig.x);
+      const int accept = timed_out || __ballot(!lane_fine) == 0ull;
+      if (lane == 0) lds_misc[2] = accept;
+      if (!accept && lane == 0) {
+        // the whole utterance is needed: wait for all of its strips
+        int *cnt = a.ctrl + (1 + kMaxLists + g) * kCtrlLine;
+        int spins = 0, ok = 1;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < Ract) {
+          __builtin_amdgcn_s_sleep(32);
+          if (++spins > kSpinLimit) { ok = 0; break; }
+        }
+        if (!ok) atomicAdd(a.ctrl, 1);
+        lds_misc[1] = ok;
       }
+      __syncthreads();  // (S2b) the stagers learn the decision
+      if (!accept) {
+        timed_out = !__builtin_amdgcn_readfirstlane(lds_misc[1]);
+        sweep(0, Ract - 1, 0);
       }
     } else {
       bool bad3 = false;
@@ -725,36 +808,45 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       timed_out = !__builtin_amdgcn_readfirstlane(lds_misc[1]);
       constexpr int kSlots = (kStage + kW - 2) / (kW - 1);  // rows per stager per batch
       double sv[kSlots][kRec];
-      // staged record number p: rows 0 .. r, then rows Ract-1 .. r (see the sweep)
-      auto stage_load = [&](int p0, int kn) __attribute__((always_inline)) {
-        const int ntop_ = r > 0 ? r + 1 : 0;
+      // staged record number p of the window [lo, hi]: rows lo .. r, then rows hi .. r (see the sweep)
+      auto stage_load = [&](int lo, int hi, int p0, int kn) __attribute__((always_inline)) {
+        const int ntop_ = r > lo ? r - lo + 1 : 0;
 #pragma unroll
         for (int sl = 0; sl < kSlots; ++sl) {
           const int q = (wv - 1) + sl * (kW - 1);
           if (q < kn && !timed_out) {
             const int pos = p0 + q;
-            const int row = pos < ntop_ ? pos : Ract - 1 - (pos - ntop_);
+            const int row = pos < ntop_ ? lo + pos : hi - (pos - ntop_);
             const double *rp = a.rec + ((size_t)g * R + row) * (kRec * 64) + lane;
 #pragma unroll
             for (int k = 0; k < kRec; ++k) sv[sl][k] = ld_agent(rp + k * 64);
           }
         }
       };
-      const int ntop = r > 0 ? r + 1 : 0, npos = ntop + (Ract - r);
-      stage_load(0, npos < kStage ? npos : kStage);
-      for (int p0 = 0; p0 < npos; p0 += kStage) {
-        const int kn = npos - p0 < kStage ? npos - p0 : kStage;
+      auto stage = [&](const int lo, const int hi) __attribute__((always_inline)) {
+        const int ntop = r > lo ? r - lo + 1 : 0, npos = ntop + (hi - r + 1);
+        stage_load(lo, hi, 0, npos < kStage ? npos : kStage);
+        for (int p0 = 0; p0 < npos; p0 += kStage) {
+          const int kn = npos - p0 < kStage ? npos - p0 : kStage;
 #pragma unroll
-        for (int sl = 0; sl < kSlots; ++sl) {
-          const int q = (wv - 1) + sl * (kW - 1);
-          if (q < kn && !timed_out) {
+          for (int sl = 0; sl < kSlots; ++sl) {
+            const int q = (wv - 1) + sl * (kW - 1);
+            if (q < kn && !timed_out) {
 #pragma unroll
-            for (int k = 0; k < kRec; ++k) lds_stage[(q * kRec + k) * 64 + lane] = sv[sl][k];
+              for (int k = 0; k < kRec; ++k) lds_stage[(q * kRec + k) * 64 + lane] = sv[sl][k];
+            }
           }
+          __syncthreads();  // this batch is in LDS
+          if (p0 + kStage < npos) stage_load(lo, hi, p0 + kStage, npos - p0 - kStage < kStage ? npos - p0 - kStage : kStage);
+          __syncthreads();  // wavefront 0 has read this batch
         }
-        __syncthreads();  // this batch is in LDS
-        if (p0 + kStage < npos) stage_load(p0 + kStage, npos - p0 - kStage < kStage ? npos - p0 - kStage : kStage);
-        __syncthreads();  // wavefront 0 has read this batch
+      };
+      const Window w = local_window(r, Ract);
+      stage(w.lo, w.hiE);
+      __syncthreads();  // (S2b) wavefront 0's decision: is the window enough?
+      if (!__builtin_amdgcn_readfirstlane(lds_misc[2])) {
+        timed_out = !__builtin_amdgcn_readfirstlane(lds_misc[1]);
+        stage(0, Ract - 1);
       }
     }
   }
@@ -887,21 +979,21 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
 
 // ---- launcher ------------------------------------------------------------------------------------
 // Scratch layout for one launch: control words, then the records.
-inline size_t ctrl_bytes(int nsg) { return (ctrl_ints(nsg) * sizeof(int) + 255) / 256 * 256; }
+inline size_t ctrl_bytes(int nsg, int R) { return (ctrl_ints(nsg, R) * sizeof(int) + 255) / 256 * 256; }
 
 template <typename TIN, typename TOUT, bool BWD>
 int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, int ndg, int dgw) {
   Args a;
   const int nsg = p.B * ndg;
   a.ctrl = (int *)scratch_base;
-  a.rec = (double *)((char *)scratch_base + ctrl_bytes(nsg));
+  a.rec = (double *)((char *)scratch_base + ctrl_bytes(nsg, R));
   a.R = R;
   a.ndg = ndg;
   a.dgw = dgw;
   a.nsg = nsg;
   const long nitems = (long)nsg * R;
   a.nlists = nitems >= 512 ? kMaxLists : 1;  // a small launch may not put a workgroup on every XCD early: one list
-  MLPG_HIP_CHECK(hipMemsetAsync(a.ctrl, 0, ctrl_ints(nsg) * sizeof(int), st));
+  MLPG_HIP_CHECK(hipMemsetAsync(a.ctrl, 0, ctrl_ints(nsg, R) * sizeof(int), st));
   // persistent workgroups: as many as can be resident (two per CU), each draws items until the lists are empty
   int dev = 0, ncu = 256;
   MLPG_HIP_CHECK(hipGetDevice(&dev));

@@ -140,6 +140,42 @@ def test_strip_ill_conditioned(sigma, tol):
     assert err.max() <= tol
 
 
+@pytest.mark.parametrize("T", [1000, 2500])
+def test_strip_long_range_coupling_falls_back_to_full_sweep(T):
+    """Level 3 first tries the records of strips r-2 .. r+2 and accepts them when its damping bound is far below
+    rounding.  Static variances of 1e14 over most of the utterance leave only the dynamic features to tie the
+    trajectory down there, strips far apart stay coupled, the bound says so and those strips sweep the whole
+    utterance: the result still equals the oracle's / the generic kernel's.  (Mixed batch: utterance 1 is
+    ordinary and takes the window everywhere.)"""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(T)
+    B, sd = 3, 20
+    m = rng.randn(B, T, 3 * sd)
+    v = rng.rand(B, T, 3 * sd) + 0.1
+    v[0, 200:T - 200, :sd] = 1e14
+    v[2, 100:T - 300, :sd:2] = 1e12       # every other system only: lanes of one strip disagree about the window
+    lengths = np.array([T, T - 7, T], dtype=np.int32)
+    ref, _, rc = O.mlpg_batch(m, v, STD3, lengths)
+    assert rc == 0
+    mg, vg, L = torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(lengths).cuda()
+    out, status = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_STRIP)
+    gen, _ = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_GENERIC)
+    assert int(status.abs().max().item()) == 0
+    out, gen = out.cpu().numpy(), gen.cpu().numpy()
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    e_ref = (np.abs(out - ref) / scale).max()
+    e_gen = (np.abs(gen - ref) / scale).max()
+    print("T", T, "strip vs oracle", e_ref, "generic vs oracle", e_gen)
+    assert e_ref <= max(1e-9, 10 * e_gen)
+    # backward through the same operators
+    go = torch.from_numpy(rng.randn(B, T, sd)).cuda()
+    gs, _ = _hip.backward(vg, go, STD3, 3 * sd, L, out_dtype=torch.float64, algo=_hip.ALGO_STRIP)
+    gg, _ = _hip.backward(vg, go, STD3, 3 * sd, L, out_dtype=torch.float64, algo=_hip.ALGO_GENERIC)
+    assert float((gs - gg).abs().max()) <= 1e-7 * float(gg.abs().max())
+
+
 def test_strip_full_size_and_repeatability():
     """Config-2 size: linearity, batch-permutation equivariance (bitwise), repeated launches bitwise equal
     (the inter-workgroup protocol leaves no timing dependence in the numbers), spot parity vs the oracle."""

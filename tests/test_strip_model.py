@@ -56,3 +56,37 @@ def test_model_flags_indefinite():
     v[40, 0] = -0.05
     _, bad = S.mlpg_strip(m, v, WINDOW_SETS["std3"])
     assert bad[0] and not bad[1]
+
+
+def _long_range_case(T=1000, sd=2, seed=5):
+    """Static variances of 1e14 over frames 200 .. 800: there only the dynamic features tie the trajectory down,
+    so strips far apart stay coupled."""
+    rng = np.random.RandomState(seed)
+    m = rng.randn(T, 3 * sd)
+    v = rng.rand(T, 3 * sd) + 0.1
+    v[200:800, :sd] = 1e14
+    return m, v
+
+
+def test_model_local_window_level3():
+    """Level 3 restricted to strips r-2 .. r+2: accepted wherever the damping bound is below 1e-22, with the same
+    numbers as the sweep over the whole utterance; weakly damped strips are recognised and fall back."""
+    W3 = WINDOW_SETS["std3"]
+    m, v, _ = rand_case("std3", "f64", 1000, 2, salt=11)
+    stats = []
+    y, bad = S.mlpg_strip(m, v, W3, local_k=2, stats=stats)
+    assert not bad.any()
+    assert all(d < 1e-22 for d, _ in stats)                 # every strip accepts the window
+    assert max(e for _, e in stats) < 1e-13
+    assert rel_err(y, O.mlpg(m, v, W3)) < 1e-11
+    m, v = _long_range_case()
+    stats = []
+    y, bad = S.mlpg_strip(m, v, W3, local_k=2, stats=stats)
+    assert not bad.any()
+    rejected = [d >= 1e-22 for d, _ in stats]
+    assert any(rejected) and not all(rejected)
+    yf, _ = S.mlpg_strip(m, v, W3, local_k=0)
+    assert rel_err(y, yf) < 1e-12                           # accepted windows changed nothing
+    # the bound is what protects the result: forcing the window everywhere is visibly wrong
+    yw, _ = S.mlpg_strip(m, v, W3, local_k=2, local_tol=np.inf)
+    assert rel_err(yw, yf) > 1e-6

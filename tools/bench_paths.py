@@ -191,6 +191,13 @@ def main():
             ms_graph = gpu_time(graph.replay, steps=20)
         except Exception as e:  # noqa: BLE001
             ms_graph = "capture failed: %s" % str(e)[:120]
+        # the two kernels alone (unit variances, float32), wave-per-system vs strip
+        md = means.detach()
+        god = torch.rand(B, T, D // 3, device=dev)
+        for name, algo in (("wave", 2), ("strip", 3)):
+            kf = gpu_time(lambda: _hip.forward(md, None, WINDOWS, algo=algo, want_status=False), steps=20)
+            kb = gpu_time(lambda: _hip.backward(None, god, WINDOWS, D, out_dtype=torch.float32, algo=algo, want_status=False), steps=20)
+            emit(path="c3-kernels-" + name, ms_forward=kf, ms_backward=kb, ms=kf + kb, alg_bytes=by, GBps=by / (kf + kb) / 1e6)
         # reference CPU form: dense R @ means on torch CPU (autograd/_impl/mlpg.py:138,158), 1 thread
         torch.set_num_threads(1)
         Rc, mc = R.cpu(), means.detach().cpu().requires_grad_()

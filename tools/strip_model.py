@@ -282,60 +282,100 @@ def utterance_solve(recs):
     return sig, bad
 
 
-def utterance_solve_two_sided(recs, r):
-    """Level 3 as the kernel runs it in strip r: a top-down elimination of rows 0 .. r-1, a bottom-up elimination of
-    rows R-1 .. r+1, and the 2-block system of rows r-1, r in the middle.  Returns (sigma_{r-1}, sigma_r, bad);
-    no factor of either sweep is stored."""
+def utterance_solve_two_sided(recs, r, lo=None, hi=None, edge=False):
+    """Level 3 as the kernel runs it in strip r: a top-down elimination of rows lo .. r-1, a bottom-up elimination of
+    rows hi .. r+1, and the 2-block system of rows r-1, r in the middle.  Returns (sigma_{r-1}, sigma_r, bad, damp);
+    no factor of either sweep is stored.
+
+    lo = 0, hi = R-1: the exact solve.  A narrower window solves the rows lo .. hi with the separators just outside
+    it clamped to zero: separator lo-1 (record lo holds strip lo's interior and its coupling V_lo to that separator)
+    and, with ``edge``, separator hi+1 (record hi+1 is read for T, h -- strip hi+1's interior -- and its coupling
+    V_{hi+1} only).  What that ignores is exactly the terms V_lo u_{lo-1} and V_{hi+1}^T u_{hi+1} on the window's
+    first / last row, and they reach rows r-1, r through the transfer matrices of the two eliminations:
+
+        top:     |du_{r-1}| <= prod_{j=lo}^{r-1} |A_j^-1 V_j| |u_{lo-1}|,     du_r one more factor |S_r^-1 V_r|
+        bottom:  |du_r| <= |S_r^-1 V_{r+1}^T| prod_{j=r+1}^{hi} |B_j^-1 V_{j+1}^T| |u_{hi+1}|,
+                 du_{r-1} one more factor |A_{r-1}^-1 V_r^T|
+
+    (|.| of a 2x2 block bounded by twice its largest entry).  ``damp`` is the larger of the two products per system;
+    the kernel accepts the windowed result only if damp is far below the rounding level, else it repeats with the
+    full range."""
     R = len(recs)
+    lo = 0 if lo is None else lo
+    hi = R - 1 if hi is None else hi
     sd = recs[0]["E"][0].shape[0]
     zero2 = (np.zeros(sd), np.zeros(sd))
     bad = np.zeros(sd, dtype=bool)
     for rec in recs:
         bad |= rec["bad"]
+    amax = lambda M4: np.max(np.abs(np.stack(M4)), axis=0)   # noqa: E731
+    sym_mat = lambda S_, V: (S_[0] * V[0] + S_[1] * V[2], S_[0] * V[1] + S_[1] * V[3],    # noqa: E731
+                             S_[1] * V[0] + S_[2] * V[2], S_[1] * V[1] + S_[2] * V[3])   # S V
+    sym_matT = lambda S_, V: (S_[0] * V[0] + S_[1] * V[1], S_[0] * V[2] + S_[1] * V[3],   # noqa: E731
+                              S_[1] * V[0] + S_[2] * V[1], S_[1] * V[2] + S_[2] * V[3])  # S V^T
     # top-down: row j is finalised when row j+1 is at hand (its T, h and V)
     Ainv, av, Mn = None, None, None
-    for j in range(r):
+    damp_t = np.ones(sd) if lo > 0 else np.zeros(sd)
+    for j in range(lo, r):
         nxt = recs[j + 1]
         A = sub(recs[j]["E"], nxt["T"])
         aa = sub(recs[j]["g"], nxt["h"])
-        if j > 0:
+        if j > lo:
             A = sub(A, mat_matT_sym(Mn, recs[j]["V"]))
             aa = sub(aa, mat_vec(Mn, av))
         Ainv, b = sym_inv(A)
         bad |= b
         av = aa
         Mn = mat_sym(nxt["V"], Ainv)            # V_{j+1} A_j^-1
+        damp_t = damp_t * 2.0 * amax(sym_mat(Ainv, recs[j]["V"]))
     # bottom-up: Schur complement (S, s) of the rows below onto row j
     S, sv = (np.zeros(sd),) * 3, zero2
     Tn, hn = (np.zeros(sd),) * 3, zero2          # T, h of the row below
-    for j in range(R - 1, r, -1):
+    Vn = (np.zeros(sd),) * 4                     # its coupling to row j
+    damp_b = np.zeros(sd)
+    if edge:
+        Tn, hn, Vn = recs[hi + 1]["T"], recs[hi + 1]["h"], recs[hi + 1]["V"]
+        damp_b = np.ones(sd)
+    for j in range(hi, r, -1):
         B = sub(sub(recs[j]["E"], Tn), S)
         bv = sub(sub(recs[j]["g"], hn), sv)
         Binv, b = sym_inv(B)
         bad |= b
         V = recs[j]["V"]
-        W = (Binv[0] * V[0] + Binv[1] * V[2], Binv[0] * V[1] + Binv[1] * V[3],
-             Binv[1] * V[0] + Binv[2] * V[2], Binv[1] * V[1] + Binv[2] * V[3])     # Binv V
+        damp_b = damp_b * 2.0 * amax(sym_matT(Binv, Vn))
+        W = sym_mat(Binv, V)     # Binv V
         S = (V[0] * W[0] + V[2] * W[2], V[0] * W[1] + V[2] * W[3], V[1] * W[1] + V[3] * W[3])   # V^T Binv V
         sv = matT_vec(V, sym_vec(Binv, bv))
-        Tn, hn = recs[j]["T"], recs[j]["h"]
+        Tn, hn, Vn = recs[j]["T"], recs[j]["h"], V
     # middle: rows r-1 and r
     B = sub(sub(recs[r]["E"], Tn), S)
     bv = sub(sub(recs[r]["g"], hn), sv)
-    if r > 0:
-        Vr = recs[r]["V"]
+    Vr = recs[r]["V"]
+    if r > lo:
         B = sub(B, mat_matT_sym(Mn, Vr))         # Mn = V_r A_{r-1}^-1
         bv = sub(bv, mat_vec(Mn, av))
     Binv, b = sym_inv(B)
     bad |= b
     sig = sym_vec(Binv, bv)
     sprev = zero2
-    if r > 0:
+    damp_b = damp_b * 2.0 * amax(sym_matT(Binv, Vn))
+    if r > lo:
         sprev = sub(sym_vec(Ainv, av), matT_vec(Mn, sig))   # A^-1 (a - V_r^T sigma_r)
-    return sprev, sig, bad
+        damp_t = damp_t * np.maximum(1.0, 2.0 * amax(sym_mat(Binv, Vr)))
+        damp_b = damp_b * np.maximum(1.0, 2.0 * amax(sym_matT(Ainv, Vr)))
+    return sprev, sig, bad, np.maximum(damp_t, damp_b)
 
 
-def mlpg_strip(mean_frames, variance_frames, windows, W=4, T=None, two_sided=True):
+def local_window(r, R, k):
+    """The records strip r reads first: rows max(0, r-k) .. hi, plus record hi+1 as the clamped edge if ``edge``
+    (hi + 1 = r + k when that is not the utterance's last strip; otherwise the rows down to the last one)."""
+    lo = max(0, r - k)
+    if r + k < R - 1:
+        return lo, r + k - 1, True
+    return lo, R - 1, False
+
+
+def mlpg_strip(mean_frames, variance_frames, windows, W=4, T=None, two_sided=True, local_k=0, local_tol=1e-22, stats=None):
     """One utterance through the strip algorithm. (Tmax, D) -> (Tmax, sd); float64."""
     mean_frames = np.asarray(mean_frames, dtype=np.float64)
     Tmax, D = mean_frames.shape
@@ -354,6 +394,7 @@ def mlpg_strip(mean_frames, variance_frames, windows, W=4, T=None, two_sided=Tru
         else:
             tau[:mw, w] = 0.0
             tau[T - mw:, w] = 0.0
+    stats = [] if stats is None else stats
     out = np.zeros((Tmax, sd))
     if T == 0:
         return out, np.zeros(sd, dtype=bool)
@@ -374,8 +415,14 @@ def mlpg_strip(mean_frames, variance_frames, windows, W=4, T=None, two_sided=Tru
     for r in range(R):
         s = sig[r - 1] if r > 0 else zero2
         if two_sided:
-            s, sr, bad2 = utterance_solve_two_sided(recs, r)
+            s, sr, bad2, _ = utterance_solve_two_sided(recs, r)
             bad = bad | bad2
+            if local_k:
+                lo_, hi_, edge_ = local_window(r, R, local_k)
+                s2, sr2, _, damp = utterance_solve_two_sided(recs, r, lo_, hi_, edge_)
+                stats.append((float(damp.max()), float(max(np.abs(np.stack(sr2) - np.stack(sr)).max(), np.abs(np.stack(s2) - np.stack(s)).max()))))
+                if damp.max() < local_tol:
+                    s, sr = s2, sr2
         else:
             sr = sig[r]
         us = strip_backsub(facs[r], s, sr)
