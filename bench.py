@@ -289,18 +289,23 @@ def main():
                 tr = status.cpu().numpy()[:3840 * 4].reshape(-1, 4).astype(np.int64)
                 t0 = tr[:, 0]
                 t0 = (t0 - t0.min()) & 0x3FFFFFFF
-                order = np.argsort(t0, kind="stable")
-                print("strip trace (100 MHz ticks = 10 ns): item start times, then durations [arrived, level3 done, end]", file=sys.stderr)
-                print("  start histogram (per 500 ticks = 5 us):", np.bincount((t0 // 500).astype(int)).tolist(), file=sys.stderr)
-                print("  end   histogram (per 500 ticks = 5 us):", np.bincount(((t0 + tr[:, 3]) // 500).astype(int)).tolist(), file=sys.stderr)
-                for nm, col in (("to-arrived", 1), ("to-level3", 2), ("to-end", 3)):
-                    v = tr[:, col]
-                    print("  %-10s median %d  p10 %d  p90 %d  max %d" % (nm, np.median(v), np.percentile(v, 10), np.percentile(v, 90), v.max()), file=sys.stderr)
-                # per utterance: spread of the start times of its 16 strips
-                st_ = t0[:3840 // 16 * 16].reshape(-1, 16)
-                print("  start spread within an utterance (ticks): median %d  p90 %d  max %d" % (
-                    np.median(st_.max(1) - st_.min(1)), np.percentile(st_.max(1) - st_.min(1), 90), (st_.max(1) - st_.min(1)).max()), file=sys.stderr)
-                print("  first 40 items in start order (start, arrived, l3, end):", tr[order[:40]].tolist(), file=sys.stderr)
+                asm, arr = tr[:, 1] & 0xFFFF, tr[:, 1] >> 16
+                l3, end = tr[:, 2], tr[:, 3] & 0xFFFFFF
+                ph = (tr[:, 3] >> 28) & 1
+                print("strip trace (100 MHz ticks = 10 ns)", file=sys.stderr)
+                for nm, v in (("loads-done", asm), ("arrived", arr), ("level3", l3), ("end", end)):
+                    print("  to %-10s median %d  p10 %d  p90 %d  max %d" % (nm, np.median(v), np.percentile(v, 10), np.percentile(v, 90), v.max()), file=sys.stderr)
+                # how many workgroups are loading / in the chain / at all active, per 2 us
+                span = int((t0 + end).max()) + 1
+                loading = np.zeros(span + 1); active = np.zeros(span + 1)
+                np.add.at(loading, t0, 1); np.add.at(loading, t0 + asm, -1)
+                np.add.at(active, t0, 1); np.add.at(active, t0 + end, -1)
+                loading, active = np.cumsum(loading)[:span], np.cumsum(active)[:span]
+                nb = span // 200
+                print("  kernel span %d ticks; mean workgroups loading %.0f, active %.0f" % (span, loading.mean(), active.mean()), file=sys.stderr)
+                print("  loading per 2 us:", [int(x) for x in loading[:nb * 200].reshape(nb, 200).mean(1)][:160], file=sys.stderr)
+                print("  active  per 2 us:", [int(x) for x in active[:nb * 200].reshape(nb, 200).mean(1)][:160], file=sys.stderr)
+                print("  phase-1 items: %d; their first start %d" % (int(ph.sum()), int(t0[ph == 1].min()) if ph.any() else -1), file=sys.stderr)
             elif os.environ.get("MLPG_DUMP_STATUS") == "strip":
                 st = status.cpu().numpy()[:8 * 16 * 16].reshape(8, 16, 16)
                 names = "claim assemble eliminate barrier level2 publish poll barrier l3-stage l3-sweep l2-back barrier backsub store l3-first-read l3-row-loop".split()

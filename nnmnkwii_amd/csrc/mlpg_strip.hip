@@ -22,13 +22,22 @@ bool strip_supported(const Problem &p, const WinSet &ws) {
   return true;
 }
 
-// AUTO policy (measured on MI355X, profiles/r02_notes.md): the strip kernel puts static dims on lanes and strips of
-// one utterance on different CUs; its inter-workgroup level costs ~10 us per 64-frame strip, which the
-// wave-per-system kernel (whole utterance in one workgroup) does not pay.  At T <= 1024 the two tie on wide streams
-// with per-frame variances and the wave kernel wins where the traffic is lighter (global / unit variances,
-// backward); beyond that the wave kernel needs 32 frames per lane (register spills, one workgroup per CU) or does
-// not apply at all (T > 2048), and the strip kernel takes over.
-bool strip_preferred(const Problem &p, const WinSet &ws) { return strip_supported(p, ws) && p.sd >= 16 && p.Tmax > 1024; }
+// AUTO policy (measured on MI355X with tools/algo_sweep.py, profiles/r02_algo_sweep.txt): the strip kernel puts
+// static dims on lanes and the strips of one utterance on different CUs; the wave-per-system kernel keeps a whole
+// utterance in one workgroup.  The strip kernel wins when its lanes are filled (dims per 64-lane group >= 48: 60, 64,
+// 128 static dims; not 25 or 80 = 2 x 40) and the launch has enough 64-frame strips to occupy the persistent grid
+// (>= 512: two per CU); with per-frame variances in the forward direction that is 0.245 vs 0.29 ms on the
+// config-2 shape, 0.037 vs 0.075 ms at 256 x 100 frames.  Lighter traffic (global / unit variances, backward) ties
+// at T <= 1024 and stays with the wave kernel.  Beyond 1024 frames the wave kernel needs 32 frames per lane
+// (register spills, one workgroup per CU) or does not apply at all (T > 2048), and the strip kernel takes over
+// for every stream of >= 16 dims.
+bool strip_preferred(const Problem &p, const WinSet &ws, bool backward) {
+  if (!strip_supported(p, ws)) return false;
+  if (p.sd >= 16 && p.Tmax > 1024) return true;
+  const int ndg = (p.sd + 63) / 64, dgw = (p.sd + ndg - 1) / ndg;
+  const long nitems = (long)p.B * ndg * ((p.Tmax + kStripFrames - 1) / kStripFrames);
+  return !backward && p.var_mode == MLPG_HIP_VAR_FRAME && dgw >= 48 && nitems >= 512;
+}
 
 int launch_strip(hipStream_t st, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &ws,
                  int device) {
@@ -36,7 +45,7 @@ int launch_strip(hipStream_t st, int dtype, int out_dtype, bool backward, const 
   const int ndg = (p.sd + 63) / 64;
   const int dgw = (p.sd + ndg - 1) / ndg;
   const size_t nsg = (size_t)p.B * ndg;
-  const size_t ctrl = (((1 + 8 + nsg) * 32 + nsg * (size_t)((R + 31) / 32 * 32)) * sizeof(int) + 255) / 256 * 256;  // strip::ctrl_bytes
+  const size_t ctrl = (((1 + 16 + nsg) * 32 + nsg * (size_t)((R + 31) / 32 * 32)) * sizeof(int) + 255) / 256 * 256;  // >= strip::ctrl_bytes
   void *sc = scratch(device, st, 3, ctrl + nsg * R * kRecBytes);
   if (!sc) return MLPG_HIP_ENOMEM;
   if (!backward)

@@ -70,7 +70,10 @@ enum { rT00, rT01, rT11, rH0, rH1, rD11, rD12, rD22, rF1, rF2, rL11, rL12, rL21,
 //   line 0: spin time-outs;  lines 1 .. 8: ticket of work list x;  line 9 + g: arrivals of system group g;
 //   then one flag per strip, Rpad = R rounded up to a line per system group: flag[g * Rpad + r].
 constexpr int kCtrlLine = 32;
-constexpr int kMaxLists = 8;
+#ifndef MLPG_STRIP_PHASES
+#define MLPG_STRIP_PHASES 1
+#endif
+constexpr int kMaxLists = 8 * MLPG_STRIP_PHASES;
 constexpr int kLocal = 2;          // level 3 first looks at the records of strips r-2 .. r+2 only
 constexpr double kDampTol = 1e-22; // ... and accepts that if the window's edges are damped below this at rows r-1, r
 // the records strip r of Ract reads first: rows lo .. hiE; the last one only as the clamped edge (T, h, V) if `edge`
@@ -93,6 +96,8 @@ struct Args {
   int R;         // strips per system group (from Tmax)
   int ndg, dgw;  // dim groups per utterance, dims per group (<= 64)
   int nsg;       // system groups: B * ndg
+  double wc[kMaxWindows][9];  // per window: W[t,t-1], W[t,t], W[t,t+1] and their six products (host-computed, so
+                              // that the kernel holds them in scalar registers)
   int nlists;    // work lists: 8 (system group g belongs to list g % 8, drawn first by the workgroups that run on
                  // XCD g % 8, so that an utterance's strips share one L2) or 1 (small launches)
 };
@@ -277,15 +282,11 @@ __device__ __forceinline__ void accumulate(const TIN (&rv)[kHB], const TIN (&rm)
 }
 
 template <typename TIN, int VM>
-__device__ __forceinline__ WinCoef win_coef(const WinSet &ws, int w, const TIN *vglob, int sd) {
-  const int l = ws.l[w], u = ws.u[w];
-  const double *cw = ws.c + ws.off[w];
+__device__ __forceinline__ WinCoef win_coef(const double (*wc)[9], int w, const TIN *vglob, int sd) {
   WinCoef k;
-  k.cm = l ? cw[0] : 0.0;  // W[t,t-1], W[t,t], W[t,t+1]
-  k.c0 = cw[l];
-  k.cp = u ? cw[l + 1] : 0.0;
-  k.c00 = k.c0 * k.c0; k.cpp = k.cp * k.cp; k.cmm = k.cm * k.cm;
-  k.cp0 = k.cp * k.c0; k.c0m = k.c0 * k.cm; k.cpm = k.cp * k.cm;
+  k.cm = wc[w][0]; k.c0 = wc[w][1]; k.cp = wc[w][2];
+  k.c00 = wc[w][3]; k.cpp = wc[w][4]; k.cmm = wc[w][5];
+  k.cp0 = wc[w][6]; k.c0m = wc[w][7]; k.cpm = wc[w][8];
   k.tau_glob = 1.0;
   if (VM == MLPG_HIP_VAR_GLOBAL) k.tau_glob = tau_of<TIN>(vglob[w * sd]);
   k.w = w;
@@ -296,7 +297,7 @@ template <typename TIN, bool BWD, int VM, bool EDGE>
 __device__ __forceinline__ void assemble(__amdgpu_buffer_rsrc_t mrs, __amdgpu_buffer_rsrc_t vrs,
                                          __amdgpu_buffer_rsrc_t grs, const TIN *__restrict__ vglob, unsigned loff,
                                          long ldi, long ldg, int sd, int f0, int T, int Tmax, const WinSet &ws,
-                                         double (&Pd)[kM], double (&P1)[kM], double (&P2)[kM], double (&rhs)[kM],
+                                         const double (*wc)[9], double (&Pd)[kM], double (&P1)[kM], double (&P2)[kM], double (&rhs)[kM],
                                          double &ca, double &cb, double &cc) {
 #pragma unroll
   for (int i = 0; i < kM; ++i) Pd[i] = P1[i] = P2[i] = rhs[i] = 0.0;
@@ -321,7 +322,7 @@ __device__ __forceinline__ void assemble(__amdgpu_buffer_rsrc_t mrs, __amdgpu_bu
     }
   }
   for (int w = 0; w < nw; ++w) {
-    const WinCoef k = win_coef<TIN, VM>(ws, w, vglob, sd);
+    const WinCoef k = win_coef<TIN, VM>(wc, w, vglob, sd);
     const unsigned woff = (unsigned)w * win_bytes;
     const int lo = live_lo(w), hi = live_hi(w), cl = clo(w), ch = chi(w);
     // the six batches alternate between the two register sets; the window ends with the next window's batch 0 in
@@ -463,8 +464,9 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
   // A workgroup draws from the list of the XCD it runs on (HW_REG_XCC_ID) until that list is empty, then helps
   // with the other lists: which workgroup runs which item never matters for the result (all inter-workgroup
   // traffic is agent scope), only for speed.
-  const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (kMaxLists - 1);  // hwreg(HW_REG_XCC_ID, 0, 4)
+  const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;  // hwreg(HW_REG_XCC_ID, 0, 4)
   const int R = a.R;
+  const int phase = (MLPG_STRIP_PHASES > 1 && a.nlists > 1 && blockIdx.x >= gridDim.x / 2) ? 1 : 0;
   auto body = [&](const int g, const int r) __attribute__((always_inline)) {
   const int b = g / a.ndg, dg = g - b * a.ndg;
   const int sd = p.sd, Tmax = p.Tmax;
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
   STRIP_TICK(0);
 #ifdef MLPG_STRIP_TRACE
   const long long tr0 = (long long)__builtin_amdgcn_s_memrealtime();
-  long long tr1 = tr0, tr2 = tr0;
+  long long tr1 = tr0, tr2 = tr0, tra = tr0;
 #endif
   // ---- level 1 ----
   double Pd[kM], P1[kM], P2[kM], rhs[kM], ca, cb, cc;
@@ -523,9 +525,13 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
   bool bad = false;
   if (f0 < T) {
     const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < T - mw;
-    if (interior) assemble<TIN, BWD, VM, false>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, Tmax, ws, Pd, P1, P2, rhs, ca, cb, cc);
-    else assemble<TIN, BWD, VM, true>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, Tmax, ws, Pd, P1, P2, rhs, ca, cb, cc);
+    if (interior) assemble<TIN, BWD, VM, false>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, Tmax, ws, a.wc, Pd, P1, P2, rhs, ca, cb, cc);
+    else assemble<TIN, BWD, VM, true>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, Tmax, ws, a.wc, Pd, P1, P2, rhs, ca, cb, cc);
     STRIP_TICK(1);
+#ifdef MLPG_STRIP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tra = (long long)__builtin_amdgcn_s_memrealtime();   // this wavefront's loads have all landed
+#endif
     if (MLPG_STRIP_ABLATE < 2) bad = eliminate(Pd, P1, P2, rhs, ca, cb, cc, rec);
     else {
 #pragma unroll
@@ -938,8 +944,8 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
 #ifdef MLPG_STRIP_TRACE
   if (wv == 0 && lane == 0 && p.status && (g * R + r) * 4 + 3 < p.B * p.ld_status) {
     int *tp = p.status + (g * R + r) * 4;
-    tp[0] = (int)(tr0 & 0x3FFFFFFF); tp[1] = (int)(tr1 - tr0); tp[2] = (int)(tr2 - tr0);
-    tp[3] = (int)((long long)__builtin_amdgcn_s_memrealtime() - tr0) | (xcd << 24) | ((blockIdx.x & 0x3FF) << 14 >> 14 << 0) * 0;
+    tp[0] = (int)(tr0 & 0x3FFFFFFF); tp[1] = (int)(tra - tr0) | ((int)(tr1 - tr0) << 16); tp[2] = (int)(tr2 - tr0);
+    tp[3] = (int)((long long)__builtin_amdgcn_s_memrealtime() - tr0) | (xcd << 24) | (phase << 28);
   }
 #endif
   };  // body
@@ -950,11 +956,11 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
   // The two workgroups of a CU start together and would load, wait and solve in lockstep (the memory pipe idle
   // half of the time).  Blocks b and b + 256 of a launch usually share a CU: the second one starts half a period
   // late, and the offset persists because the periods are equal.  (A wrong guess about placement costs nothing.)
-  if (MLPG_STRIP_STAGGER && (blockIdx.x & 256))
+  if (MLPG_STRIP_STAGGER && (MLPG_STRIP_PHASES > 1 ? phase : (int)(blockIdx.x & 256)))
     for (int q = 0; q < MLPG_STRIP_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
 
   for (int k = 0; k < a.nlists; ++k) {
-    const int lst = (xcd + k) % a.nlists;
+    const int lst = (xcd + phase * 8 + k) % a.nlists;
     const int lim = ((a.nsg - lst + a.nlists - 1) / a.nlists) * R;  // items of this list
     int *ticket = a.ctrl + (1 + lst) * kCtrlLine;
     for (;;) {
@@ -991,6 +997,13 @@ int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_b
   a.ndg = ndg;
   a.dgw = dgw;
   a.nsg = nsg;
+  for (int w = 0; w < ws.nw; ++w) {
+    const int l = ws.l[w], u = ws.u[w];
+    const double *cw = ws.c + ws.off[w];
+    const double cm = l ? cw[0] : 0.0, c0 = cw[l], cp = u ? cw[l + 1] : 0.0;
+    const double v[9] = {cm, c0, cp, c0 * c0, cp * cp, cm * cm, cp * c0, c0 * cm, cp * cm};
+    for (int q = 0; q < 9; ++q) a.wc[w][q] = v[q];
+  }
   const long nitems = (long)nsg * R;
   a.nlists = nitems >= 512 ? kMaxLists : 1;  // a small launch may not put a workgroup on every XCD early: one list
   MLPG_HIP_CHECK(hipMemsetAsync(a.ctrl, 0, ctrl_ints(nsg, R) * sizeof(int), st));
