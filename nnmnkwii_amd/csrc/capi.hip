@@ -27,7 +27,9 @@ constexpr int kMaxDevices = 16, kSlots = 4;
 struct Slot {
   void *ptr = nullptr;
   size_t bytes = 0;
+  unsigned long long gen = 0;  // allocation number: a caller that remembers the buffer's content checks this
 };
+unsigned long long g_scratch_gen = 0;
 struct StreamScratch {
   Slot slot[kSlots];
 };
@@ -35,14 +37,17 @@ std::map<std::pair<int, hipStream_t>, StreamScratch> g_scratch;
 std::mutex g_mu;
 }  // namespace
 
-void *scratch(int device, hipStream_t stream, int slot, size_t bytes) {
+void *scratch(int device, hipStream_t stream, int slot, size_t bytes, unsigned long long *gen) {
   if (device < 0 || device >= kMaxDevices || slot < 0 || slot >= kSlots) {
     set_error("scratch: bad device/slot %d/%d", device, slot);
     return nullptr;
   }
   std::lock_guard<std::mutex> lk(g_mu);
   Slot &s = g_scratch[std::make_pair(device, stream)].slot[slot];
-  if (s.bytes >= bytes && s.ptr) return s.ptr;
+  if (s.bytes >= bytes && s.ptr) {
+    if (gen) *gen = s.gen;
+    return s.ptr;
+  }
   if (s.ptr) {
     // the previous users of this buffer were enqueued on this very stream
     (void)hipStreamSynchronize(stream);
@@ -63,6 +68,8 @@ void *scratch(int device, hipStream_t stream, int slot, size_t bytes) {
   }
   s.ptr = p;
   s.bytes = want;
+  s.gen = ++g_scratch_gen;
+  if (gen) *gen = s.gen;
   return p;
 }
 

@@ -47,7 +47,7 @@ struct Problem {
 void set_error(const char *fmt, ...);
 // Grow-only scratch, cached per (device, stream, slot): slot 0 generic factor, 1 fastdtw pyramids,
 // 2 generic status, 3 strip records.  Returns nullptr (and sets the error) on failure.
-void *scratch(int device, hipStream_t stream, int slot, size_t bytes);
+void *scratch(int device, hipStream_t stream, int slot, size_t bytes, unsigned long long *gen = nullptr);
 
 // launchers (one per translation unit)
 int launch_generic(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,

@@ -1,13 +1,16 @@
 // Strip MLPG kernels: dispatch (the kernels live in mlpg_strip_impl.h and are instantiated per
 // dtype in mlpg_strip_{fwd,bwd}_{f32,f64}.hip so that they compile in parallel).
+#include <map>
+#include <mutex>
+#include <utility>
 #include "common.h"
 
 namespace mlpg {
 
-int launch_strip_fwd_f64(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw);
-int launch_strip_fwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw);
-int launch_strip_bwd_f64(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw);
-int launch_strip_bwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw);
+int launch_strip_fwd_f64(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl);
+int launch_strip_fwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl);
+int launch_strip_bwd_f64(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl);
+int launch_strip_bwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl);
 
 namespace {
 constexpr int kStripFrames = 64;   // strip::kW * strip::kM
@@ -46,13 +49,29 @@ int launch_strip(hipStream_t st, int dtype, int out_dtype, bool backward, const 
   const int dgw = (p.sd + ndg - 1) / ndg;
   const size_t nsg = (size_t)p.B * ndg;
   const size_t ctrl = (((1 + 16 + nsg) * 32 + nsg * (size_t)((R + 31) / 32 * 32)) * sizeof(int) + 255) / 256 * 256;  // >= strip::ctrl_bytes
-  void *sc = scratch(device, st, 3, ctrl + nsg * R * kRecBytes);
+  unsigned long long gen = 0;
+  void *sc = scratch(device, st, 3, ctrl + nsg * R * kRecBytes, &gen);
   if (!sc) return MLPG_HIP_ENOMEM;
+  // The control words must be zero when the kernel starts.  verdict_kernel leaves them zero again, so a launch on
+  // the same scratch whose control area is not larger than the previous one's (everything beyond it held records)
+  // needs no memset -- one dependent launch less per call.  Never trusted while the stream is being captured
+  // into a graph: a replay may follow launches this bookkeeping has not seen.
+  bool zero_ctrl = true;
+  {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, std::pair<unsigned long long, size_t>> clean;  // allocation, zero bytes at its head
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> lk(mu);
+    auto &c = clean[{device, st}];
+    if (!capturing && c.first == gen && ctrl <= c.second) zero_ctrl = false;
+    c = {gen, capturing ? (size_t)0 : ctrl};
+  }
   if (!backward)
-    return dtype == MLPG_HIP_F32 ? launch_strip_fwd_f32(st, out_dtype, p, ws, sc, R, ndg, dgw)
-                                 : launch_strip_fwd_f64(st, out_dtype, p, ws, sc, R, ndg, dgw);
-  return dtype == MLPG_HIP_F32 ? launch_strip_bwd_f32(st, out_dtype, p, ws, sc, R, ndg, dgw)
-                               : launch_strip_bwd_f64(st, out_dtype, p, ws, sc, R, ndg, dgw);
+    return dtype == MLPG_HIP_F32 ? launch_strip_fwd_f32(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl)
+                                 : launch_strip_fwd_f64(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl);
+  return dtype == MLPG_HIP_F32 ? launch_strip_bwd_f32(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl)
+                               : launch_strip_bwd_f64(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl);
 }
 
 }  // namespace mlpg

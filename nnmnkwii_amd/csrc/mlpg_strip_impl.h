@@ -67,7 +67,8 @@ enum { rT00, rT01, rT11, rH0, rH1, rD11, rD12, rD22, rF1, rF2, rL11, rL12, rL21,
 
 // Control words, one per 128-byte line (32 ints) so that the pollers of one utterance, the ticket draws and the
 // arrivals of other utterances never queue on the same L2 line:
-//   line 0: spin time-outs;  lines 1 .. 8: ticket of work list x;  line 9 + g: arrivals of system group g;
+//   line 0: spin time-outs;  lines 1 .. 8: ticket of work list x;  line 9 + g: system group g -- word 0 arrivals,
+//   words 2-3 mask of the lanes (systems) that met a failing pivot, word 4 time-out seen;
 //   then one flag per strip, Rpad = R rounded up to a line per system group: flag[g * Rpad + r].
 constexpr int kCtrlLine = 32;
 #ifndef MLPG_STRIP_PHASES
@@ -871,20 +872,21 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
   if (MLPG_STRIP_ABLATE < 2) backsub(Pd, P1, P2, rhs, ca, cb, cc, ul, uo);
   STRIP_TICK(12);
 
-  // status (strip 0 only): the reference's natural-order first failing pivot; -1 = inter-workgroup wait timed
-  // out (never expected), -2 = the blocked elimination broke down although the natural-order scan found no
-  // failing pivot (numerically singular)
-  if (r == 0 && wv == 0) {
-    int status = 0;
+  // Verdict.  Strip 0 writes status 0; a strip that met a failing pivot (its own levels 1-2, or a level-3 block in
+  // its window: every failure is inside the window of at least the strip that holds it) or a time-out only marks
+  // its lanes in the utterance's mask -- the strips far away never learn of it now that level 3 is windowed.
+  // verdict_kernel (next launch on the stream) turns the marks into the reference's status and zero columns.
+  if (wv == 0) {
     const int to = __builtin_amdgcn_readfirstlane(timed_out);
-    if (to) status = -1;
-    else if (sys_bad && lane_ok) {
-      const SysView<TIN, BWD> view = make_view<TIN, BWD>(p, ws, b, d, T);
-      status = first_bad_pivot<2, TIN, BWD>(view, ws);
-      if (status == 0) status = -2;
+    const unsigned long long m = to ? ~0ull : __ballot(sys_bad && lane_ok);
+    if (m != 0ull && lane == 0) {
+      int *line = a.ctrl + (1 + kMaxLists + g) * kCtrlLine;
+      __hip_atomic_fetch_or(line + 2, (int)(unsigned)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_or(line + 3, (int)(unsigned)(m >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (to) __hip_atomic_store(line + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #if !defined(MLPG_STRIP_TIMING) && !defined(MLPG_STRIP_TRACE)
-    if (lane_ok && p.status) p.status[(size_t)b * p.ld_status + d] = status;
+    if (r == 0 && lane_ok && p.status) p.status[(size_t)b * p.ld_status + d] = 0;
 #endif
   }
   const bool zero_out = sys_bad || timed_out;
@@ -983,12 +985,55 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
   }
 }
 
+// ---- verdict ------------------------------------------------------------------------------------
+// One wavefront per system group, launched after strip_kernel on the same stream.  Marked lanes (see above) get the
+// reference's verdict: status = natural-order first failing pivot (-2 if that scan finds none: the blocked
+// elimination broke down on a numerically singular system; -1 after a time-out) and an all-zero output column,
+// exactly what the other kernels deliver.  It also re-zeroes the control words for the next launch.
+template <typename TIN, typename TOUT, bool BWD>
+__global__ void __launch_bounds__(256) verdict_kernel(const Problem p, const WinSet ws, const Args a) {
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= a.nsg) return;
+  int *line = a.ctrl + (1 + kMaxLists + g) * kCtrlLine;
+  const unsigned long long m = (unsigned long long)(unsigned)line[2] | ((unsigned long long)(unsigned)line[3] << 32);
+  const int timed_out = line[4];
+  // leave every control word as the next launch needs it: zero (launch_strip then skips its memset)
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 5) line[lane] = 0;
+  for (int i = lane; i < flag_pitch(a.R); i += 64) a.ctrl[(1 + kMaxLists + a.nsg) * kCtrlLine + (size_t)g * flag_pitch(a.R) + i] = 0;
+  if (g == 0)
+    for (int i = lane; i < (1 + kMaxLists) * kCtrlLine; i += 64) a.ctrl[i] = 0;
+  if (m == 0ull) return;
+  const int b = g / a.ndg, dg = g - b * a.ndg;
+  const int d0 = dg * a.dgw;
+  const int nd = p.sd - d0 < a.dgw ? p.sd - d0 : a.dgw;
+  if (lane >= nd || !((m >> lane) & 1ull)) return;
+  const int d = d0 + lane, Tmax = p.Tmax;
+  int T = p.lengths ? p.lengths[b] : Tmax;
+  T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
+  int status = -1;
+  if (!timed_out) {
+    const SysView<TIN, BWD> view = make_view<TIN, BWD>(p, ws, b, d, T);
+    status = first_bad_pivot<2, TIN, BWD>(view, ws);
+    if (status == 0) status = -2;
+  }
+  if (p.status) p.status[(size_t)b * p.ld_status + d] = status;
+  TOUT *out_b = (TOUT *)p.out + (size_t)b * Tmax * p.ld_out;
+  for (int t = 0; t < Tmax; ++t) {
+    if (!BWD) out_b[(size_t)t * p.ld_out + d] = (TOUT)0;
+    else
+      for (int w = 0; w < ws.nw; ++w) out_b[(size_t)t * p.ld_out + w * p.sd + d] = (TOUT)0;
+  }
+}
+
 // ---- launcher ------------------------------------------------------------------------------------
 // Scratch layout for one launch: control words, then the records.
 inline size_t ctrl_bytes(int nsg, int R) { return (ctrl_ints(nsg, R) * sizeof(int) + 255) / 256 * 256; }
 
 template <typename TIN, typename TOUT, bool BWD>
-int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, int ndg, int dgw) {
+int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, int ndg, int dgw,
+             bool zero_ctrl) {
   Args a;
   const int nsg = p.B * ndg;
   a.ctrl = (int *)scratch_base;
@@ -1006,7 +1051,7 @@ int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_b
   }
   const long nitems = (long)nsg * R;
   a.nlists = nitems >= 512 ? kMaxLists : 1;  // a small launch may not put a workgroup on every XCD early: one list
-  MLPG_HIP_CHECK(hipMemsetAsync(a.ctrl, 0, ctrl_ints(nsg, R) * sizeof(int), st));
+  if (zero_ctrl) MLPG_HIP_CHECK(hipMemsetAsync(a.ctrl, 0, ctrl_ints(nsg, R) * sizeof(int), st));
   // persistent workgroups: as many as can be resident (two per CU), each draws items until the lists are empty
   int dev = 0, ncu = 256;
   MLPG_HIP_CHECK(hipGetDevice(&dev));
@@ -1015,6 +1060,8 @@ int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_b
   auto go = [&](auto kern) -> int {
     MLPG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kW * 64), kLdsBytes, st, p, ws, a);
+    MLPG_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL((verdict_kernel<TIN, TOUT, BWD>), dim3((unsigned)((nsg + 3) / 4)), dim3(256), 0, st, p, ws, a);
     MLPG_HIP_CHECK(hipGetLastError());
     return 0;
   };

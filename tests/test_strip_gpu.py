@@ -122,6 +122,60 @@ def test_strip_not_pd_status():
                 assert np.abs(y[b, :, d] - yo[b, :, d]).max() <= TOL64 * np.abs(yo[b, :, d]).max()
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_strip_not_pd_far_from_strip0(dtype):
+    """Level 3 is windowed: a strip never sees a failing pivot 3+ strips away.  The verdict (status = the reference's
+    first failing natural-order pivot, all-zero column) must not depend on where the pivot fails: first, middle and
+    last strips of long utterances, two failures in one system, ragged lengths, forward and backward."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    npdt = np.float64 if dtype == "f64" else np.float32
+    rng = np.random.RandomState(3)
+    B, T, sd = 4, 1500, 6
+    m = rng.randn(B, T, 3 * sd).astype(npdt)
+    v = (rng.rand(B, T, 3 * sd) + 0.1).astype(npdt)
+    lengths = np.array([T, T - 100, T, 700], dtype=np.int32)
+    v[0, 1333, 1] = -1e-3             # strip 20 of 24
+    v[0, 5, 4] = -1e-3                # strip 0
+    v[1, 700, 0] = -1e-3              # middle
+    v[1, 1390, 2] = -1e-3             # last live strip of a ragged utterance
+    v[2, 640, 3] = -1e-3; v[2, 1200, 3] = -1e-3   # two failures in one system: the first one is reported
+    v[2, 1450, sd + 5] = -1e-4        # a delta variance near the end
+    v[3, 690, 5] = -1e-3              # just before the end of a short utterance
+    v[3, 900, 2] = -1e-3              # in the padding: not a failure
+    exp = np.zeros((B, sd), dtype=np.int32)
+    for b in range(B):
+        for d in range(sd):
+            cols = [d, sd + d, 2 * sd + d]
+            _, s1, _ = O.mlpg_batch(m[b:b + 1][:, :, cols], v[b:b + 1][:, :, cols], STD3, lengths[b:b + 1])
+            exp[b, d] = s1[0, 0]
+    assert exp[0, 1] == 1334 and exp[0, 4] == 6 and exp[2, 3] == 641 and exp[3, 2] == 0 and exp[2, 5] > 0
+    mg, vg, L = torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(lengths).cuda()
+    y, st = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_STRIP)
+    yg, stg = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_GENERIC)
+    assert np.array_equal(st.cpu().numpy().reshape(B, sd), exp)
+    assert np.array_equal(stg.cpu().numpy().reshape(B, sd), exp)
+    y, yg = y.cpu().numpy(), yg.cpu().numpy()
+    for b in range(B):
+        for d in range(sd):
+            if exp[b, d]:
+                assert not y[b, :, d].any(), (b, d)
+            else:
+                assert np.abs(y[b, :, d] - yg[b, :, d]).max() <= (1e-9 if dtype == "f64" else 2e-4) * np.abs(yg[b, :, d]).max(), (b, d)
+    go = torch.from_numpy(rng.randn(B, T, sd).astype(npdt)).cuda()
+    gs, sts = _hip.backward(vg, go, STD3, 3 * sd, L, out_dtype=torch.float64, algo=_hip.ALGO_STRIP)
+    gg, _ = _hip.backward(vg, go, STD3, 3 * sd, L, out_dtype=torch.float64, algo=_hip.ALGO_GENERIC)
+    assert np.array_equal(sts.cpu().numpy().reshape(B, sd), exp)
+    gs, gg = gs.cpu().numpy().reshape(B, T, 3, sd), gg.cpu().numpy().reshape(B, T, 3, sd)
+    for b in range(B):
+        for d in range(sd):
+            if exp[b, d]:
+                assert not gs[b, :, :, d].any(), (b, d)
+            else:
+                assert np.abs(gs[b, :, :, d] - gg[b, :, :, d]).max() <= 1e-6 * np.abs(gg[b, :, :, d]).max(), (b, d)
+
+
 @pytest.mark.parametrize("sigma,tol", [(2.0, 1e-9), (4.0, 1e-7), (6.0, 1e-5)])
 def test_strip_ill_conditioned(sigma, tol):
     import torch
