@@ -190,9 +190,12 @@ int mlpg_hip_delta_features(int device, void *stream, int dtype, const void *x,
  * with the original phase -- and transform back), and the gradient of the
  * power spectrum of autograd/_impl/modspec.py:30-60 (a Python loop over feature
  * dimensions with dense (n/2+1, T) cos/sin tables).
- * One workgroup per (utterance, feature column); the n-point FFT (n a power of
- * two <= 4096) lives in LDS.  All arrays float64, row-major; `ortho` selects
- * numpy's norm="ortho".
+ * Any DFT length n >= 2, as numpy's rfft / irfft.  A power of two <= 4096 (the
+ * reference's defaults are 2048 and 4096): one workgroup per (utterance, pair of
+ * feature columns), the n-point FFT lives in LDS, one launch per call.  Any
+ * other n: the direct transform (O(n) per output value, exact integer phases;
+ * two launches for smoothing / backward, the half spectrum in stream scratch).
+ * All arrays float64, row-major; `ortho` selects numpy's norm="ortho".
  *   x     : (B, T, D), T <= n, zero-padded to n internally
  *   ms    : (B, n/2+1, D)            phase : (B, n/2+1, D, 2) (re, im), may be NULL
  *   inv_modspec output (B, n, D); smoothing / backward output (B, T, D)
@@ -210,6 +213,9 @@ int mlpg_hip_modspec_smoothing(int device, void *stream, const double *x,
 int mlpg_hip_modspec_backward(int device, void *stream, const double *x,
                               const double *grad_ms, int B, int T, int D,
                               int n, int ortho, double *grad_x);
+/* Testing aid: on != 0 routes every DFT length through the direct transform
+ * (process-wide), so that tests can compare it with the FFT path. */
+void mlpg_hip_modspec_set_direct(int on);
 
 /*
  * Trailing-zero trim.  Replaces preprocessing.trim_zeros_frames with trim="b"

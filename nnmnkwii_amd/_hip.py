@@ -12,7 +12,7 @@ import threading
 import numpy as np
 
 F32, F64 = 0, 1
-ABI_VERSION = 7               # mlpg_hip_abi_version() of the library this binding was written for
+ABI_VERSION = 8               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE, ALGO_STRIP = 0, 1, 2, 3
 
@@ -36,6 +36,7 @@ EXPORTS = (
     "mlpg_hip_inv_modspec",
     "mlpg_hip_modspec_smoothing",
     "mlpg_hip_modspec_backward",
+    "mlpg_hip_modspec_set_direct",
     "mlpg_hip_trim_lengths",
     "mlpg_hip_fastdtw",
     "mlpg_hip_fastdtw_l2",
@@ -100,6 +101,8 @@ def lib():
         L.mlpg_hip_modspec_smoothing.argtypes = [ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
         L.mlpg_hip_modspec_backward.restype = ci
         L.mlpg_hip_modspec_backward.argtypes = [ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+        L.mlpg_hip_modspec_set_direct.restype = None
+        L.mlpg_hip_modspec_set_direct.argtypes = [ci]
         L.mlpg_hip_trim_lengths.restype = ci
         L.mlpg_hip_trim_lengths.argtypes = [ci, vp, ci, vp, ci, ci, ci, cd, vp]
         L.mlpg_hip_fastdtw_l2.restype = ci

@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -279,7 +280,7 @@ using namespace mlpg;
 
 extern "C" {
 
-__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 7; }
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 8; }
 
 __attribute__((visibility("default"))) const char *mlpg_hip_last_error(void) { return g_err; }
 
@@ -445,14 +446,15 @@ __attribute__((visibility("default"))) int mlpg_hip_delta_features(int device, v
 }
 
 namespace {
+std::atomic<bool> g_modspec_direct{false};
 int modspec_entry(int device, void *stream, int mode, const double *x, const double *ms, const double *ph, double *out,
                   double *out_ph, int B, int T, int D, int n, int ortho, int limit_bin, int log_domain) {
   if (B < 0 || T < 0 || D < 0 || n < 1) {
     set_error("modspec: negative size");
     return MLPG_HIP_EINVAL;
   }
-  if (n < 2 || n > 4096 || (n & (n - 1))) {
-    set_error("modspec: the DFT length must be a power of two in [2, 4096] (got %d)", n);
+  if (n < 2) {
+    set_error("modspec: the DFT length must be at least 2 (got %d)", n);
     return MLPG_HIP_EINVAL;
   }
   if (T > n) {
@@ -469,9 +471,17 @@ int modspec_entry(int device, void *stream, int mode, const double *x, const dou
     set_error("cannot select device %d", device);
     return MLPG_HIP_ERUNTIME;
   }
-  return launch_modspec((hipStream_t)stream, mode, x, ms, ph, out, out_ph, B, T, D, n, ortho, limit_bin, log_domain);
+  // powers of two up to 4096 (the reference's defaults are 2048 and 4096): the fused in-LDS FFT; any other length:
+  // the direct transform of modspec_dft.hip
+  if (n <= 4096 && !(n & (n - 1)) && !g_modspec_direct)
+    return launch_modspec((hipStream_t)stream, mode, x, ms, ph, out, out_ph, B, T, D, n, ortho, limit_bin, log_domain);
+  return launch_modspec_dft((hipStream_t)stream, device, mode, x, ms, ph, out, out_ph, B, T, D, n, ortho, limit_bin,
+                            log_domain);
 }
 }  // namespace
+
+// Testing aid: route every DFT length through the direct transform (so that it can be compared with the FFT path).
+__attribute__((visibility("default"))) void mlpg_hip_modspec_set_direct(int on) { g_modspec_direct = on != 0; }
 
 __attribute__((visibility("default"))) int mlpg_hip_modspec(int device, void *stream, const double *x, int B, int T,
                                                             int D, int n, int ortho, double *ms, double *phase) {

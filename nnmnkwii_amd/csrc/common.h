@@ -63,6 +63,9 @@ int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, con
                      int ncols, void *dst, long ld_dst);
 int launch_modspec(hipStream_t s, int mode, const double *x, const double *ms, const double *ph, double *out,
                    double *out_ph, int B, int T, int D, int n, int ortho, int limit_bin, int log_domain);
+int launch_modspec_dft(hipStream_t s, int device, int mode, const double *x, const double *ms, const double *ph,
+                       double *out, double *out_ph, int B, int T, int D, int n, int ortho, int limit_bin,
+                       int log_domain);
 int launch_delta(hipStream_t s, int dtype, const void *x, const int32_t *lengths, int B, int Tmax, int D,
                  const WinSet &w, void *out);
 int launch_trim(hipStream_t s, int dtype, const void *X, int N, int T, int D, double eps, int32_t *lengths);

@@ -26,8 +26,8 @@ def _norm_flag(norm):
 
 def _check_n(n):
     n = int(n)
-    if n < 2 or n > 4096 or n & (n - 1):
-        raise NotImplementedError("nnmnkwii_amd modspec kernels need a power-of-two DFT length <= 4096, got %d" % n)
+    if n < 2:
+        raise ValueError("the DFT length must be at least 2, got %d" % n)
     return n
 
 
@@ -113,7 +113,15 @@ def modspec_smoothing(x, modfs, n=4096, norm=None, cutoff=50, log_domain=True):
     n = _check_n(n)
     nb = n // 2 + 1
     limit_bin = nb if cutoff is None else min(int(n * cutoff / modfs) + 1, nb)   # :160-163
-    out = _hip.modspec_smoothing(t, n, limit_bin, log_domain, _norm_flag(norm))
+    if n % 2:
+        # the reference inverts through inv_modspec, i.e. at length 2 (K - 1) = n - 1 for an odd n: same here,
+        # composed from the three steps (the fused launch transforms back at n)
+        ms, ph = _hip.modspec(t, n, _norm_flag(norm), want_phase=True)
+        if limit_bin < nb:
+            ms[:, limit_bin:] = 1.0 if log_domain else 0.0     # exp(0) / 0
+        out = _hip.inv_modspec(ms, ph, _norm_flag(norm))[:, :T].contiguous()
+    else:
+        out = _hip.modspec_smoothing(t, n, limit_bin, log_domain, _norm_flag(norm))
     if not batched:
         out = out[0]
     return np.ascontiguousarray(out.cpu().numpy().astype(rdt, copy=False)) if is_np else out

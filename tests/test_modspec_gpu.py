@@ -85,8 +85,7 @@ def test_reference_assertions():
         P.modspec_smoothing(y, modfs, n=2048, cutoff=modfs // 2 + 1)
     with pytest.raises(RuntimeError):
         P.modspec_smoothing(y, modfs, n=32, cutoff=modfs // 2)
-    with pytest.raises(NotImplementedError):
-        P.modspec(y, n=100)                              # not a power of two: no CPU fallback
+    assert P.modspec(y, n=100).shape == (51, 2)          # any DFT length, as numpy
 
 
 @pytest.mark.parametrize("T,n", [(16, 16), (12, 32), (40, 256)])
@@ -106,6 +105,67 @@ def test_autograd_modspec_matches_reference(golden, T, n):
     y = torch.rand(8, 3, dtype=torch.float64, device="cuda", requires_grad=True)
     assert torch.autograd.gradcheck(lambda t: AF.ModSpec.apply(t, 16, None), (y,), eps=1e-6, atol=1e-6)
     assert torch.autograd.gradcheck(lambda t: AF.ModSpec.apply(t, 16, "ortho"), (y,), eps=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("T,n", [(5, 6), (7, 7), (64, 100), (100, 100), (333, 1000), (1000, 2047), (1500, 3000),
+                                 (2500, 5000), (3000, 8192), (50, 4097)])
+def test_any_dft_length(T, n):
+    """DFT lengths outside the in-LDS FFT (not a power of two, or > 4096): the direct transform against the numpy
+    restatement of the reference (oracle/modspec.py, pinned on the reference's goldens): spectrum, phase, inverse,
+    smoothing (odd n: the reference inverts at n - 1), analytic gradient; both norms."""
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd import autograd as AF
+    from nnmnkwii_amd import preprocessing as P
+    from oracle import modspec as OM
+    rng = np.random.RandomState(T + n)
+    x = rng.rand(T, 5)
+    for norm in (None, "ortho"):
+        ms, ph = P.modspec(x, n=n, norm=norm, return_phase=True)
+        mo, po = OM.modspec(x, n=n, norm=norm, return_phase=True)
+        _close(ms, mo, 1e-11)
+        big = mo > 1e-6 * mo.max()                        # the phase of a vanishing bin is noise
+        assert np.abs(ph - po)[big].max() < 1e-8
+        if n % 2 == 0:
+            _close(P.inv_modspec(mo, po, norm=norm), OM.inv_modspec(mo, po, norm=norm), 1e-11)
+        for log_domain in (True, False):
+            for cutoff in (100, 25, 60):
+                y = P.modspec_smoothing(x, 200, n=n, norm=norm, cutoff=cutoff, log_domain=log_domain)
+                _close(y, OM.modspec_smoothing(x, 200, n=n, norm=norm, cutoff=cutoff, log_domain=log_domain), 1e-9)
+        w = rng.rand(n // 2 + 1, 5)
+        yt = torch.from_numpy(x).cuda().requires_grad_()
+        (AF.modspec(yt, n=n, norm=norm) * torch.from_numpy(w).cuda()).sum().backward()
+        _close(yt.grad.cpu().numpy(), OM.modspec_grad(x, w, n, norm), 1e-10)
+    # batches, a column count that is not a multiple of the tile, float32 round trip
+    xb = rng.rand(3, T, 21)
+    msb = P.modspec(xb, n=n)
+    for b in range(3):
+        _close(msb[b], OM.modspec(xb[b], n=n), 1e-11)
+    assert P.modspec(xb.astype(np.float32), n=n).dtype == np.float32
+
+
+def test_direct_transform_equals_fft_path():
+    """The same power-of-two problems through both transforms (mlpg_hip_modspec_set_direct): all four modes."""
+    from nnmnkwii_amd import _hip
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(4, 700, 37, dtype=torch.float64, device="cuda", generator=gen)
+    g = torch.rand(4, 513, 37, dtype=torch.float64, device="cuda", generator=gen)
+    n = 1024
+
+    def run():
+        ms, ph = _hip.modspec(x, n, want_phase=True)
+        return (ms, ph, _hip.inv_modspec(ms, ph), _hip.modspec_smoothing(x, n, 100, log_domain=True),
+                _hip.modspec_smoothing(x, n, 100, log_domain=False, ortho=True), _hip.modspec_backward(x, g, n),
+                _hip.modspec_backward(x, g, n, True))
+    a = run()
+    _hip.lib().mlpg_hip_modspec_set_direct(1)
+    try:
+        b = run()
+    finally:
+        _hip.lib().mlpg_hip_modspec_set_direct(0)
+    for i, (u, v) in enumerate(zip(a, b)):
+        if i == 1:
+            continue                                      # phases of tiny bins differ; compared through the inverse
+        assert float((u - v).abs().max()) <= 1e-10 * float(v.abs().max()), i
 
 
 def test_full_size_properties():

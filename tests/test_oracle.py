@@ -177,3 +177,36 @@ def test_oracle_vs_compiled_reference():
             assert np.array_equal(O.mlpg(m32, v32, windows), G.mlpg(m32, v32, windows))
         R = G.unit_variance_mlpg_matrix(windows, 12)
         assert np.abs(R - O.unit_variance_mlpg_matrix(windows, 12)).max() <= 1e-7
+
+
+def test_modspec_oracle_matches_reference_goldens():
+    """oracle/modspec.py (numpy's FFT, as the reference) against every modulation-spectrum golden the reference
+    produced (make_golden.py): spectrum, phase, inverse, smoothing in both domains and norms, analytic gradient."""
+    import os
+    from oracle import modspec as OM
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mlpg_golden.npz"))
+    seen = 0
+    for key in [k for k in g.files if k.startswith("modspec/T") and k.endswith("/x")]:
+        case = key[:-2]
+        n = int(case.split("-n")[1])
+        x = g[key]
+        for norm in (None, "ortho"):
+            pre = "%s/%s/" % (case, norm or "none")
+            ms, ph = OM.modspec(x, n=n, norm=norm, return_phase=True)
+            np.testing.assert_allclose(ms, g[pre + "ms"], rtol=1e-12, atol=1e-12 * np.abs(g[pre + "ms"]).max())
+            np.testing.assert_allclose(ph, g[pre + "phase"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(OM.inv_modspec(g[pre + "ms"], g[pre + "phase"], norm=norm), g[pre + "inv"], rtol=0, atol=1e-12)
+            for k in [k for k in g.files if k.startswith(pre + "smooth-")]:
+                log_domain = bool(int(k.split("smooth-log")[1][0]))
+                cutoff = int(k.split("-c")[1])
+                y = OM.modspec_smoothing(x, 200, n=n, norm=norm, cutoff=cutoff, log_domain=log_domain)
+                np.testing.assert_allclose(y, g[k], rtol=0, atol=1e-11)
+                seen += 1
+    for key in [k for k in g.files if k.startswith("modspec_grad/") and k.endswith("/y")]:
+        case = key[:-2]
+        n = int(case.split("-n")[1].split("-")[0])
+        norm = None if case.endswith("-none") else "ortho"
+        grad = OM.modspec_grad(g[key], g[case + "/w"], n, norm)
+        np.testing.assert_allclose(grad, g[case + "/grad"], rtol=0, atol=2e-5 * np.abs(g[case + "/grad"]).max())   # float32 goldens
+        seen += 1
+    assert seen > 30
