@@ -59,9 +59,9 @@ def test_argument_validation_without_gpu(L):
     assert rc == -1 and b"does not fit" in L.mlpg_hip_last_error()
     rc = L.mlpg_hip_forward_streams(0, None, 1, 0, fake, fake, 0, 5, None, 1, 4, 0, None, 0, None, None, None, fake, 1, None)
     assert rc == 0
-    # modulation spectrum: DFT length must be a power of two <= 4096 and >= T
-    rc = L.mlpg_hip_modspec(0, None, fake, 1, 10, 2, 100, 0, fake, None)
-    assert rc == -1 and b"power of two" in L.mlpg_hip_last_error()
+    # modulation spectrum: DFT length >= 2 and >= T
+    rc = L.mlpg_hip_modspec(0, None, fake, 1, 1, 2, 1, 0, fake, None)
+    assert rc == -1 and b"at least 2" in L.mlpg_hip_last_error()
     rc = L.mlpg_hip_modspec_smoothing(0, None, fake, 1, 100, 2, 64, 0, 10, 1, fake)
     assert rc == -1 and b"time length" in L.mlpg_hip_last_error()
     rc = L.mlpg_hip_fastdtw_l2(0, None, fake, fake, fake, fake, 1, 4, 4, 2, 0, fake, fake, fake, fake)
