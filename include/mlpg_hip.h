@@ -102,6 +102,22 @@ int mlpg_hip_forward_host(int device, int dtype, int algo, const void *mean_h,
                           int num_windows, const int32_t *win_l_h,
                           const int32_t *win_u_h, const double *win_coef_h,
                           void *out_h, int32_t *status_h);
+
+/*
+ * mlpg_hip_fastdtw for N utterance pairs held in HOST memory: what DTWAligner.transform does per pair
+ * (preprocessing/alignment.py:46-50: trim_zeros_frames on both utterances, fastdtw) for the whole batch, cut into
+ * chunks of pairs that alternate between two internal streams (pinned staging, transfers under the kernels of the
+ * other chunk), like mlpg_hip_forward_host.  X_h (N, Tx, D), Y_h (N, Ty, D) of `dtype` (float32 is widened to
+ * float64 on the device: the distances are float64 either way).  lenx_h / leny_h: valid frames per utterance, or
+ * both NULL: trailing frames with sum_d |x| < trim_eps are dropped on the device (preprocessing/generic.py:291-332,
+ * eps 1e-7 there).  Outputs as mlpg_hip_fastdtw, in host memory; lenx_out_h / leny_out_h (may be NULL) receive the
+ * lengths that were used.  Blocking; one host-entry call at a time per process.
+ */
+int mlpg_hip_fastdtw_host(int device, int dtype, const void *X_h, const void *Y_h,
+                          const int32_t *lenx_h, const int32_t *leny_h, int N, int Tx, int Ty, int D,
+                          int radius, int dist_kind, double dist_scale, double trim_eps,
+                          int32_t *path_i_h, int32_t *path_j_h, int32_t *path_len_h, double *cost_h,
+                          int32_t *lenx_out_h, int32_t *leny_out_h);
 /* Pinned host memory for arrays that are handed to mlpg_hip_forward_host repeatedly (transferred in place). */
 void *mlpg_hip_host_alloc(size_t bytes);
 void mlpg_hip_host_free(void *p);

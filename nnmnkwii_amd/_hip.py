@@ -27,6 +27,7 @@ EXPORTS = (
     "mlpg_hip_shutdown",
     "mlpg_hip_forward",
     "mlpg_hip_forward_host",
+    "mlpg_hip_fastdtw_host",
     "mlpg_hip_host_alloc",
     "mlpg_hip_host_free",
     "mlpg_hip_forward_streams",
@@ -82,6 +83,9 @@ def lib():
         L.mlpg_hip_forward.argtypes = [ci, vp, ci, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
         L.mlpg_hip_forward_host.restype = ci
         L.mlpg_hip_forward_host.argtypes = [ci, ci, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
+        L.mlpg_hip_fastdtw_host.restype = ci
+        L.mlpg_hip_fastdtw_host.argtypes = [ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_double, ctypes.c_double,
+                                            vp, vp, vp, vp, vp, vp]
         L.mlpg_hip_host_alloc.restype = vp
         L.mlpg_hip_host_alloc.argtypes = [ctypes.c_size_t]
         L.mlpg_hip_host_free.restype = None
@@ -481,6 +485,37 @@ def fastdtw_l2(X, Y, lenx, leny, radius=1, dist_kind=DIST_L2, dist_scale=1.0):
                                 _p(cost))
     _check(rc, "mlpg_hip_fastdtw")
     return path_i, path_j, path_len, cost
+
+
+def fastdtw_host(X, Y, radius=1, dist_kind=DIST_L2, dist_scale=1.0, lenx=None, leny=None, eps=1e-7, device=0):
+    """fastdtw paths for N pairs held in numpy arrays (no framework tensor): mlpg_hip_fastdtw_host, chunked and
+    overlapped with the transfers.  X (N, Tx, D), Y (N, Ty, D) float32 / float64.  Without lengths the trailing
+    all-zero frames are trimmed on the device (eps as trim_zeros_frames).  Returns numpy
+    (path_i, path_j (N, Tx+Ty) int32, path_len (N,), cost (N,), lenx, leny)."""
+    L = lib()
+    X = np.ascontiguousarray(X)
+    Y = np.ascontiguousarray(Y)
+    if X.dtype not in (np.float32, np.float64):
+        X = X.astype(np.float64)
+    Y = Y.astype(X.dtype, copy=False)
+    assert X.ndim == 3 and Y.ndim == 3 and X.shape[0] == Y.shape[0] and X.shape[2] == Y.shape[2]
+    N, Tx, D = X.shape
+    Ty = Y.shape[1]
+    path_i = np.zeros((N, Tx + Ty), dtype=np.int32)
+    path_j = np.zeros((N, Tx + Ty), dtype=np.int32)
+    path_len = np.zeros((N,), dtype=np.int32)
+    cost = np.zeros((N,), dtype=np.float64)
+    lx_out = np.zeros((N,), dtype=np.int32)
+    ly_out = np.zeros((N,), dtype=np.int32)
+    if lenx is not None:
+        lenx = np.ascontiguousarray(lenx, dtype=np.int32)
+        leny = np.ascontiguousarray(leny, dtype=np.int32)
+    rc = L.mlpg_hip_fastdtw_host(int(device), F32 if X.dtype == np.float32 else F64, _np(X), _np(Y),
+                                 None if lenx is None else _np(lenx), None if leny is None else _np(leny), N, Tx, Ty, D,
+                                 int(radius), int(dist_kind), float(dist_scale), float(eps), _np(path_i), _np(path_j),
+                                 _np(path_len), _np(cost), _np(lx_out), _np(ly_out))
+    _check(rc, "mlpg_hip_fastdtw_host")
+    return path_i, path_j, path_len, cost, lx_out, ly_out
 
 
 def gather_path(src, path, path_len, Tout):

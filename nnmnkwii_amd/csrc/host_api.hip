@@ -98,6 +98,10 @@ int ensure(HostCtx &c, size_t in_bytes, size_t out_bytes, size_t dev_bytes) {
 
 inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+__global__ void widen_f32(const float *__restrict__ src, double *__restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (double)src[i];
+}
+
 }  // namespace
 }  // namespace mlpg
 
@@ -236,6 +240,143 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_host(int device, int
     MLPG_HIP_CHECK(hipMemcpyAsync(odst, d + o_out, (size_t)nb * utt_out, hipMemcpyDeviceToHost, st));
     MLPG_HIP_CHECK(hipMemcpyAsync((char *)c.pin_out[slot] + up256((size_t)cb * utt_out), d + o_status,
                                   (size_t)nb * sd * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MLPG_HIP_CHECK(hipEventRecord(c.done[slot], st));
+    pend[slot].active = true;
+    pend[slot].b0 = b0;
+    pend[slot].nb = nb;
+  }
+  if (int rc = finish(chunk & 1)) return rc;
+  if (int rc = finish((chunk + 1) & 1)) return rc;
+  return 0;
+}
+
+// fastdtw for N utterance pairs held in HOST memory: what DTWAligner.transform (preprocessing/alignment.py:41-76) does
+// per pair -- trim_zeros_frames on both utterances (:46-47, when lenx_h / leny_h are NULL: trailing frames with
+// sum |x| < eps are dropped on the device), fastdtw (:50) -- chunked over the pairs like mlpg_hip_forward_host, the
+// transfers of one chunk under the kernels of the other.  X_h (N, Tx, D), Y_h (N, Ty, D) float32 or float64 (float32
+// is widened on the device: the distances are computed in float64 either way).  Outputs as mlpg_hip_fastdtw;
+// lenx_out_h / leny_out_h (may be NULL) receive the lengths that were used.
+__attribute__((visibility("default"))) int mlpg_hip_fastdtw_host(int device, int dtype, const void *X_h, const void *Y_h,
+                                                                 const int32_t *lenx_h, const int32_t *leny_h, int N,
+                                                                 int Tx, int Ty, int D, int radius, int dist_kind,
+                                                                 double dist_scale, double trim_eps,
+                                                                 int32_t *path_i_h, int32_t *path_j_h,
+                                                                 int32_t *path_len_h, double *cost_h,
+                                                                 int32_t *lenx_out_h, int32_t *leny_out_h) {
+  if (N < 0 || Tx < 1 || Ty < 1 || D < 1 || radius < 1) {
+    set_error("fastdtw_host: need N >= 0, Tx, Ty, D >= 1 and radius >= 1");
+    return MLPG_HIP_EINVAL;
+  }
+  if (dtype != MLPG_HIP_F32 && dtype != MLPG_HIP_F64) {
+    set_error("dtype must be MLPG_HIP_F32 or MLPG_HIP_F64");
+    return MLPG_HIP_EINVAL;
+  }
+  if ((lenx_h == nullptr) != (leny_h == nullptr)) {
+    set_error("fastdtw_host: give both length arrays or neither");
+    return MLPG_HIP_EINVAL;
+  }
+  if (N == 0) return 0;
+  if (!X_h || !Y_h || !path_i_h || !path_j_h || !path_len_h || !cost_h) {
+    set_error("fastdtw_host: NULL pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  if (device < 0 || device >= 16) {
+    set_error("bad device %d", device);
+    return MLPG_HIP_EINVAL;
+  }
+  int prev = -1;
+  MLPG_HIP_CHECK(hipGetDevice(&prev));
+  if (prev != device) MLPG_HIP_CHECK(hipSetDevice(device));
+  struct Restore {
+    int prev, dev;
+    ~Restore() { if (prev != dev) (void)hipSetDevice(prev); }
+  } restore{prev, device};
+
+  const size_t esz = dtype == MLPG_HIP_F32 ? 4 : 8;
+  const size_t px = (size_t)Tx * D, py = (size_t)Ty * D, pl = (size_t)Tx + Ty;  // elements per pair: X, Y, path slots
+  long cb = (long)((64u << 20) / ((px + py) * esz));
+  cb = std::max<long>(1, std::min<long>(cb, (N + 3) / 4));
+  // pinned staging: in = X | Y;  out = path_i | path_j | path_len | lenx | leny | cost
+  const size_t in_bytes = up256((size_t)cb * px * esz) + (size_t)cb * py * esz;
+  const size_t so_pj = up256((size_t)cb * pl * 4), so_pl = 2 * so_pj, so_lx = so_pl + up256((size_t)cb * 4),
+               so_ly = so_lx + up256((size_t)cb * 4), so_c = so_ly + up256((size_t)cb * 4),
+               out_bytes = so_c + (size_t)cb * 8;
+  // device: X | Y | X64 | Y64 (float32 input only) | lenx | leny | path_i | path_j | path_len | cost
+  const size_t o_x = 0, o_y = up256((size_t)cb * px * esz), o_x64 = o_y + up256((size_t)cb * py * esz),
+               o_y64 = o_x64 + (dtype == MLPG_HIP_F32 ? up256((size_t)cb * px * 8) : 0),
+               o_lx = o_y64 + (dtype == MLPG_HIP_F32 ? up256((size_t)cb * py * 8) : 0), o_ly = o_lx + up256((size_t)cb * 4),
+               o_pi = o_ly + up256((size_t)cb * 4), o_pj = o_pi + so_pj, o_pl = o_pj + so_pj,
+               o_c = o_pl + up256((size_t)cb * 4), dev_bytes = o_c + up256((size_t)cb * 8);
+
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  HostCtx &c = g_host[device];
+  if (int rc = ensure(c, in_bytes, out_bytes, dev_bytes)) return rc;
+  const bool x_pinned = is_pinned(X_h), y_pinned = is_pinned(Y_h);
+
+  struct Pending {
+    bool active = false;
+    long b0 = 0, nb = 0;
+  } pend[2];
+  auto finish = [&](int slot) -> int {
+    if (!pend[slot].active) return 0;
+    MLPG_HIP_CHECK(hipEventSynchronize(c.done[slot]));
+    const long b0 = pend[slot].b0, nb = pend[slot].nb;
+    const char *o = (const char *)c.pin_out[slot];
+    memcpy(path_i_h + (size_t)b0 * pl, o, (size_t)nb * pl * 4);
+    memcpy(path_j_h + (size_t)b0 * pl, o + so_pj, (size_t)nb * pl * 4);
+    memcpy(path_len_h + b0, o + so_pl, (size_t)nb * 4);
+    if (lenx_out_h) memcpy(lenx_out_h + b0, o + so_lx, (size_t)nb * 4);
+    if (leny_out_h) memcpy(leny_out_h + b0, o + so_ly, (size_t)nb * 4);
+    memcpy(cost_h + b0, o + so_c, (size_t)nb * 8);
+    pend[slot].active = false;
+    return 0;
+  };
+
+  int chunk = 0;
+  for (long b0 = 0; b0 < N; b0 += cb, ++chunk) {
+    const int slot = chunk & 1;
+    const long nb = std::min<long>(cb, N - b0);
+    if (int rc = finish(slot)) return rc;
+    hipStream_t st = c.st[slot];
+    char *d = (char *)c.dev[slot];
+    const char *xs = (const char *)X_h + (size_t)b0 * px * esz, *ys = (const char *)Y_h + (size_t)b0 * py * esz;
+    if (!x_pinned) {
+      parallel_copy(c.pin_in[slot], xs, (size_t)nb * px * esz);
+      xs = (const char *)c.pin_in[slot];
+    }
+    MLPG_HIP_CHECK(hipMemcpyAsync(d + o_x, xs, (size_t)nb * px * esz, hipMemcpyHostToDevice, st));
+    if (!y_pinned) {
+      char *stage = (char *)c.pin_in[slot] + up256((size_t)cb * px * esz);
+      parallel_copy(stage, ys, (size_t)nb * py * esz);
+      ys = stage;
+    }
+    MLPG_HIP_CHECK(hipMemcpyAsync(d + o_y, ys, (size_t)nb * py * esz, hipMemcpyHostToDevice, st));
+    int32_t *lx = (int32_t *)(d + o_lx), *ly = (int32_t *)(d + o_ly);
+    if (lenx_h) {
+      MLPG_HIP_CHECK(hipMemcpyAsync(lx, lenx_h + b0, (size_t)nb * 4, hipMemcpyHostToDevice, st));
+      MLPG_HIP_CHECK(hipMemcpyAsync(ly, leny_h + b0, (size_t)nb * 4, hipMemcpyHostToDevice, st));
+    } else {
+      if (int rc = launch_trim(st, dtype, d + o_x, (int)nb, Tx, D, trim_eps, lx)) return rc;
+      if (int rc = launch_trim(st, dtype, d + o_y, (int)nb, Ty, D, trim_eps, ly)) return rc;
+    }
+    const double *x64 = (const double *)(d + o_x), *y64 = (const double *)(d + o_y);
+    if (dtype == MLPG_HIP_F32) {
+      hipLaunchKernelGGL(widen_f32, dim3(1024), dim3(256), 0, st, (const float *)(d + o_x), (double *)(d + o_x64), (size_t)nb * px);
+      hipLaunchKernelGGL(widen_f32, dim3(1024), dim3(256), 0, st, (const float *)(d + o_y), (double *)(d + o_y64), (size_t)nb * py);
+      MLPG_HIP_CHECK(hipGetLastError());
+      x64 = (const double *)(d + o_x64);
+      y64 = (const double *)(d + o_y64);
+    }
+    if (int rc = launch_fastdtw(st, device, x64, y64, lx, ly, (int)nb, Tx, Ty, D, radius, dist_kind, dist_scale,
+                                (int32_t *)(d + o_pi), (int32_t *)(d + o_pj), (int32_t *)(d + o_pl), (double *)(d + o_c)))
+      return rc;
+    char *o = (char *)c.pin_out[slot];
+    MLPG_HIP_CHECK(hipMemcpyAsync(o, d + o_pi, (size_t)nb * pl * 4, hipMemcpyDeviceToHost, st));
+    MLPG_HIP_CHECK(hipMemcpyAsync(o + so_pj, d + o_pj, (size_t)nb * pl * 4, hipMemcpyDeviceToHost, st));
+    MLPG_HIP_CHECK(hipMemcpyAsync(o + so_pl, d + o_pl, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+    MLPG_HIP_CHECK(hipMemcpyAsync(o + so_lx, lx, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+    MLPG_HIP_CHECK(hipMemcpyAsync(o + so_ly, ly, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+    MLPG_HIP_CHECK(hipMemcpyAsync(o + so_c, d + o_c, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
     MLPG_HIP_CHECK(hipEventRecord(c.done[slot], st));
     pend[slot].active = true;
     pend[slot].b0 = b0;

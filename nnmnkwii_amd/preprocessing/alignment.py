@@ -79,47 +79,42 @@ class DTWAligner(object):
         self.radius = radius
 
     def _paths(self, X, Y):
-        """Device-side trim + fastdtw. Returns torch tensors (Xd, Yd, path_i, path_j, path_len, cost, lenx, leny)."""
-        torch = _hip.torch_mod()
+        """Trim + fastdtw of every pair through the host-pointer entry point (chunks of pairs, transfers overlapped
+        with the kernels).  Returns numpy (path_i, path_j, path_len, cost, lenx, leny)."""
         dist_kind, dist_scale = _resolve_dist(self.dist)
-        dev = _hip.require_gpu()
-        Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
-        Yd = torch.from_numpy(np.ascontiguousarray(Y)).to(dev)
-        if Xd.dtype not in (torch.float32, torch.float64):
-            Xd = Xd.to(torch.float64)
-        if Yd.dtype not in (torch.float32, torch.float64):
-            Yd = Yd.to(torch.float64)
-        lenx = _hip.trim_lengths(Xd)                       # alignment.py:49
-        leny = _hip.trim_lengths(Yd)
-        X64 = Xd if Xd.dtype == torch.float64 else Xd.to(torch.float64)   # fastdtw casts to float
-        Y64 = Yd if Yd.dtype == torch.float64 else Yd.to(torch.float64)
-        path_i, path_j, path_len, cost = _hip.fastdtw_l2(X64, Y64, lenx, leny, self.radius, dist_kind, dist_scale)   # :50
-        return Xd, Yd, path_i, path_j, path_len, cost, lenx, leny
+        _hip.require_gpu()
+        return _hip.fastdtw_host(X, Y, self.radius, dist_kind, dist_scale)      # alignment.py:46-50
 
     def transform(self, XY):
-        torch = _hip.torch_mod()
         X, Y = XY
         assert X.ndim == 3 and Y.ndim == 3                 # alignment.py:42
         longer = X if X.shape[1] > Y.shape[1] else Y       # :44
         N = X.shape[0]
         if N == 0:
             return np.zeros_like(longer), np.zeros_like(longer)
-        Xd, Yd, path_i, path_j, path_len, cost, lenx, leny = self._paths(X, Y)
-        plen = path_len.cpu().numpy()
+        path_i, path_j, plen, cost, lenx, leny = self._paths(X, Y)
         if (plen <= 0).any():
             bad = int(np.flatnonzero(plen <= 0)[0])
             raise ValueError("DTWAligner: pair %d has an empty (all-zero) utterance or could not be aligned" % bad)
         T_out = max(int(longer.shape[1]), int(plen.max()))  # :55-71 (outputs only ever grow)
-        Xa = _hip.gather_path(Xd, path_i, path_len, T_out)  # :52-54,72
-        Ya = _hip.gather_path(Yd, path_j, path_len, T_out)  # :73
-        out_dtype = longer.dtype
-        Xa = Xa.cpu().numpy().astype(out_dtype, copy=False)
-        Ya = Ya.cpu().numpy().astype(out_dtype, copy=False)
+        Xa = _gather(X, path_i, plen, T_out, longer.dtype)  # :52-54,72
+        Ya = _gather(Y, path_j, plen, T_out, longer.dtype)  # :73
         if self.verbose > 0:
-            d = cost.cpu().numpy() / (lenx.cpu().numpy() + leny.cpu().numpy())   # :51
+            d = cost / (lenx + leny)                        # :51
             for idx in range(N):
                 print("{}, distance: {}".format(idx, d[idx]))
         return Xa, Ya
+
+
+def _gather(src, path, plen, T_out, dtype):
+    """out[n, k] = src[n, path[n, k]] for k < plen[n], zeros after: the reference's ``x[pathx]`` written into a
+    zero-padded buffer (alignment.py:52-54, 72-73) -- indexing only, for all pairs at once."""
+    idx = np.clip(path[:, :T_out], 0, src.shape[1] - 1)       # slots beyond plen hold no index
+    if idx.shape[1] < T_out:
+        idx = np.pad(idx, [(0, 0), (0, T_out - idx.shape[1])])
+    out = np.take_along_axis(src, idx[:, :, None].astype(np.intp), axis=1).astype(dtype, copy=False)
+    out[np.arange(T_out)[None, :] >= plen[:, None]] = 0
+    return out
 
 
 class IterativeDTWAligner(object):
@@ -163,8 +158,7 @@ class IterativeDTWAligner(object):
         path_x, plen = None, None
 
         for _ in range(self.n_iter):
-            Xd, Yd, path_i, path_j, path_len, cost, lenx, leny = aligner._paths(Xc, Y)
-            plen = path_len.cpu().numpy()
+            path_i, path_j, plen, cost, lenx, leny = aligner._paths(Xc, Y)
             if (plen <= 0).any():
                 bad = int(np.flatnonzero(plen <= 0)[0])
                 raise ValueError("IterativeDTWAligner: pair %d has an empty (all-zero) utterance" % bad)
@@ -173,14 +167,14 @@ class IterativeDTWAligner(object):
                 grow = [(0, 0), (0, T_out - X_aligned.shape[1]), (0, 0)]
                 X_aligned = np.pad(X_aligned, grow, mode="constant", constant_values=0)
                 Y_aligned = np.pad(Y_aligned, grow, mode="constant", constant_values=0)
-            Xg = _hip.gather_path(Xd, path_i, path_len, T_out).cpu().numpy()
-            Yg = _hip.gather_path(Yd, path_j, path_len, T_out).cpu().numpy()
+            Xg = _gather(Xc, path_i, plen, T_out, X_aligned.dtype)
+            Yg = _gather(Y, path_j, plen, T_out, Y_aligned.dtype)
             prefix = (np.arange(T_out)[None, :] < plen[:, None])[:, :, None]
-            X_aligned = np.where(prefix, Xg.astype(X_aligned.dtype, copy=False), X_aligned)   # prefix writes (:163-164)
-            Y_aligned = np.where(prefix, Yg.astype(Y_aligned.dtype, copy=False), Y_aligned)
-            path_x = path_i.cpu().numpy()
+            X_aligned = np.where(prefix, Xg, X_aligned)   # prefix writes (:163-164)
+            Y_aligned = np.where(prefix, Yg, Y_aligned)
+            path_x = path_i
             if self.verbose > 0:
-                dd = cost.cpu().numpy() / (lenx.cpu().numpy() + leny.cpu().numpy())
+                dd = cost / (lenx + leny)
                 for idx in range(N):
                     print("{}, distance: {}".format(idx, dd[idx]))
 
@@ -188,7 +182,7 @@ class IterativeDTWAligner(object):
             joint = np.concatenate((X_aligned, Y_aligned), axis=-1).reshape(-1, X.shape[-1] * 2)
             gmm.fit(joint)                                     # :170-178
             conv = MLPG(gmm, windows=[(0, 0, np.array([1.0]))])   # no delta: frame-wise conversion (:179-180)
-            nx = lenx.cpu().numpy()                            # trim_zeros_frames(Xc[idx]) of this iteration
+            nx = lenx                                          # trim_zeros_frames(Xc[idx]) of this iteration
             converted = conv.transform_batch([Xc[idx][: int(nx[idx])] for idx in range(N)])   # one launch (:181-183)
             for idx in range(N):
                 Xc[idx][: len(converted[idx])] = converted[idx]

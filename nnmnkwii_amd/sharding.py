@@ -57,14 +57,51 @@ def all_gather_shards(local, n_total, group=None):
     return torch.cat(parts, dim=0)
 
 
-def mlpg_batch_sharded(means, variances, windows, lengths=None, gather=True, group=None, compute=None):
+def _gather_sizes(n, device, group=None):
+    """[n of rank 0, n of rank 1, ...] on every rank."""
+    import torch
+    dist = _dist()
+    rank, world = _world(group)
+    if world == 1:
+        return [int(n)]
+    mine = torch.tensor([n], dtype=torch.int64, device=device)
+    ns = torch.empty((world,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(ns, mine, group=group)
+    return [int(x) for x in ns.cpu().tolist()]
+
+
+def all_gather_varsize(local, group=None):
+    """Gather shards whose leading sizes are known only to their owners (each rank loaded its own part of the
+    corpus): one small all-gather of the sizes, then one padded ``all_gather_into_tensor`` of the data.
+    Returns (full tensor in rank order, list of per-rank sizes)."""
+    import torch
+    dist = _dist()
+    rank, world = _world(group)
+    if world == 1:
+        return local, [int(local.shape[0])]
+    sizes = _gather_sizes(int(local.shape[0]), local.device, group)
+    mx = max(max(sizes), 1)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0), sizes
+
+
+def mlpg_batch_sharded(means, variances, windows, lengths=None, gather=True, group=None, compute=None,
+                       local_shards=False):
     """MLPG over a ``(B, Tmax, D)`` batch split across the ranks of ``group``.
 
-    Every rank passes the same full arrays (numpy or torch); rank ``r`` runs
+    ``local_shards=False``: every rank passes the same full arrays (numpy or torch); rank ``r`` runs
     ``paramgen.mlpg_batch`` on utterances ``shard_range(B, r, world)`` on its own
     GPU.  With ``gather=True`` the ``(B, Tmax, sd)`` result is all-gathered and
     returned on every rank (numpy in -> numpy out); with ``gather=False`` only
     the local shard is returned together with its ``(lo, hi)`` range.
+
+    ``local_shards=True``: every rank passes ONLY its own utterances (the way a multi-process data loader hands
+    them out: no rank ever holds the whole batch); shard sizes may differ (even be zero).  ``gather=True``
+    concatenates the results in rank order on every rank; ``gather=False`` returns the local result and this
+    rank's ``(lo, hi)`` position in that order.
 
     ``compute(means, variances, windows, lengths)`` overrides the per-shard
     kernel call (the CPU tests inject a checker there; the default is the HIP path).
@@ -72,7 +109,7 @@ def mlpg_batch_sharded(means, variances, windows, lengths=None, gather=True, gro
     import torch
     rank, world = _world(group)
     B = means.shape[0]
-    lo, hi = shard_range(B, rank, world)
+    lo, hi = (0, B) if local_shards else shard_range(B, rank, world)
     if compute is None:
         from .paramgen import mlpg_batch as compute
     is_np = not torch.is_tensor(means)
@@ -87,29 +124,37 @@ def mlpg_batch_sharded(means, variances, windows, lengths=None, gather=True, gro
     else:
         y = (np.zeros((0, means.shape[1], sd), dtype=means.dtype) if is_np
              else means.new_zeros((0, means.shape[1], sd)))
-    if not gather:
+    dist = _dist()
+    if not gather and not local_shards:
         return y, (lo, hi)
     yt = torch.from_numpy(np.ascontiguousarray(y)) if is_np else y
-    dist = _dist()
     if world > 1 and dist.get_backend(group) == "nccl" and not yt.is_cuda:
         yt = yt.cuda()
-    full = all_gather_shards(yt, B, group)
+    if local_shards:
+        if not gather:
+            sizes = _gather_sizes(int(yt.shape[0]), yt.device, group)
+            start = sum(sizes[:rank])
+            return y, (start, start + sizes[rank])
+        full = all_gather_varsize(yt, group)[0]
+    else:
+        full = all_gather_shards(yt, B, group)
     return full.cpu().numpy() if is_np else full
 
 
-def dtw_align_sharded(aligner, X, Y, group=None, transform=None):
+def dtw_align_sharded(aligner, X, Y, group=None, transform=None, local_shards=False):
     """``DTWAligner.transform`` over pairs split across the ranks of ``group``.
 
-    Every rank aligns pairs ``shard_range(N, r, world)``; the outputs are padded
+    Every rank aligns pairs ``shard_range(N, r, world)`` of the full arrays -- or, with ``local_shards=True``, the
+    pairs it was handed (no rank holds the whole corpus; shard sizes may differ); the outputs are padded
     to the global maximum length (the reference grows its outputs to the longest
-    warping path of the WHOLE batch, alignment.py:55-71) and all-gathered.
+    warping path of the WHOLE batch, alignment.py:55-71) and all-gathered in rank order.
     numpy in -> numpy out on every rank.
     """
     import torch
     dist = _dist()
     rank, world = _world(group)
     N = X.shape[0]
-    lo, hi = shard_range(N, rank, world)
+    lo, hi = (0, N) if local_shards else shard_range(N, rank, world)
     if transform is None:
         transform = aligner.transform
     longer = X if X.shape[1] > Y.shape[1] else Y
@@ -132,6 +177,8 @@ def dtw_align_sharded(aligner, X, Y, group=None, transform=None):
         out[:, : a.shape[1]] = a
         return torch.from_numpy(out).to(dev)
 
+    if local_shards:
+        return all_gather_varsize(pad(Xa), group)[0].cpu().numpy(), all_gather_varsize(pad(Ya), group)[0].cpu().numpy()
     Xf = all_gather_shards(pad(Xa), N, group).cpu().numpy()
     Yf = all_gather_shards(pad(Ya), N, group).cpu().numpy()
     return Xf, Yf

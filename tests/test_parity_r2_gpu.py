@@ -211,3 +211,38 @@ def test_host_entry_point_numpy_in_numpy_out():
     Vb[20, 100, 7] = -1e-3
     with pytest.raises(np.linalg.LinAlgError):
         G.mlpg_batch(M_, Vb, windows, lengths=None)
+
+
+def test_fastdtw_host_entry_equals_device_entry():
+    """mlpg_hip_fastdtw_host (chunks of pairs on two internal streams, device-side trim, pinned staging) returns
+    exactly what the device entry point returns on resident tensors: several chunks with a short last one,
+    float64 and float32 inputs, given and device-trimmed lengths, the melcd distance, pinned input arrays."""
+    import torch
+    from nnmnkwii_amd import _hip
+    X, Y = c4_pairs(11, seed=9)
+    Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+    lx, ly = _hip.trim_lengths(Xd), _hip.trim_lengths(Yd)
+    for kind, scale in ((_hip.DIST_L2, 1.0), (_hip.DIST_SCALED_L2_NP, 6.14185)):
+        pi, pj, pl, cost = _hip.fastdtw_l2(Xd, Yd, lx, ly, 1, kind, scale)
+        hi, hj, hl, hc, hx, hy = _hip.fastdtw_host(X, Y, 1, kind, scale)
+        assert np.array_equal(hx, lx.cpu().numpy()) and np.array_equal(hy, ly.cpu().numpy())
+        assert np.array_equal(hl, pl.cpu().numpy()) and np.array_equal(hc, cost.cpu().numpy())
+        for n in range(len(X)):
+            assert np.array_equal(hi[n, :hl[n]], pi[n, :hl[n]].cpu().numpy())
+            assert np.array_equal(hj[n, :hl[n]], pj[n, :hl[n]].cpu().numpy())
+    # explicit lengths (shorter than the trim would give), radius 2
+    lx2 = (lx.cpu().numpy() - 50).astype(np.int32)
+    ly2 = (ly.cpu().numpy() - 20).astype(np.int32)
+    pi, pj, pl, cost = _hip.fastdtw_l2(Xd, Yd, torch.from_numpy(lx2).cuda(), torch.from_numpy(ly2).cuda(), 2)
+    hi, hj, hl, hc, hx, hy = _hip.fastdtw_host(X, Y, 2, lenx=lx2, leny=ly2)
+    assert np.array_equal(hl, pl.cpu().numpy()) and np.array_equal(hc, cost.cpu().numpy()) and np.array_equal(hx, lx2)
+    # float32 arrays are widened on the device; pinned arrays are transferred in place
+    X32, Y32 = X.astype(np.float32), Y.astype(np.float32)
+    pi, pj, pl, cost = _hip.fastdtw_l2(torch.from_numpy(X32).cuda().double(), torch.from_numpy(Y32).cuda().double(), lx, ly, 1)
+    Xp, Yp = _hip.pinned_empty(X32.shape, np.float32), _hip.pinned_empty(Y32.shape, np.float32)
+    Xp[...] = X32
+    Yp[...] = Y32
+    for a, b in ((X32, Y32), (Xp, Yp)):
+        hi, hj, hl, hc, _, _ = _hip.fastdtw_host(a, b, 1)
+        assert np.array_equal(hl, pl.cpu().numpy()) and np.array_equal(hc, cost.cpu().numpy())
+        assert np.array_equal(hi[3, :hl[3]], pi[3, :hl[3]].cpu().numpy())

@@ -77,6 +77,19 @@ def _worker(rank, world, port, B, q):
         Xf, Yf = sharding.dtw_align_sharded(None, X, Y, transform=lambda xy: OD.dtw_align(xy[0], xy[1])[:2])
         Xo, Yo, _, _ = OD.dtw_align(X, Y)
         ok = ok and Xf.shape == Xo.shape and np.array_equal(Xf, Xo) and np.array_equal(Yf, Yo)
+
+        # per-rank shards: every rank holds only its own utterances, of different counts (rank 1 may hold none)
+        cut = B - 1 if B > 5 else B
+        mine = slice(0, cut) if rank == 0 else slice(cut, B)
+        full2 = sharding.mlpg_batch_sharded(M[mine], V[mine], windows, lengths[mine], gather=True, compute=compute,
+                                            local_shards=True)
+        ok = ok and full2.shape == ref.shape and np.array_equal(full2, ref)
+        loc2, (lo2, hi2) = sharding.mlpg_batch_sharded(M[mine], V[mine], windows, lengths[mine], gather=False,
+                                                       compute=compute, local_shards=True)
+        ok = ok and (lo2, hi2) == (mine.start, mine.stop) and np.array_equal(loc2, ref[mine])
+        Xf2, Yf2 = sharding.dtw_align_sharded(None, X[mine], Y[mine], transform=lambda xy: OD.dtw_align(xy[0], xy[1])[:2],
+                                              local_shards=True)
+        ok = ok and Xf2.shape == Xo.shape and np.array_equal(Xf2, Xo) and np.array_equal(Yf2, Yo)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
