@@ -71,6 +71,9 @@ enum { rT00, rT01, rT11, rH0, rH1, rD11, rD12, rD22, rF1, rF2, rL11, rL12, rL21,
 //   words 2-3 mask of the lanes (systems) that met a failing pivot, word 4 time-out seen;
 //   then one flag per strip, Rpad = R rounded up to a line per system group: flag[g * Rpad + r].
 constexpr int kCtrlLine = 32;
+#ifndef MLPG_STRIP_STREAM
+#define MLPG_STRIP_STREAM 1  // 0: window-major assembly, then elimination, also for three windows (A/B measurements)
+#endif
 #ifndef MLPG_STRIP_PHASES
 #define MLPG_STRIP_PHASES 1
 #endif
@@ -413,6 +416,180 @@ __device__ __forceinline__ bool eliminate(double (&Pd)[kM], double (&P1)[kM], do
   return bad;
 }
 
+// ---- level 1, streamed: assembly and interior elimination of one chunk in frame order (NW windows, known at
+// compile time) ----
+// The 18 frames f0-1 .. f0+16 are taken one at a time; a frame is NW rows of `var` and of `mean` (one load each per
+// lane) and feeds matrix rows t-1, t, t+1.  Row i is therefore final once frame i+1 has been accumulated, and is
+// eliminated right then: the recurrence of `eliminate` runs under the loads instead of after them.  A ring of kRing
+// frames is in flight from the first load to the last: as soon as a frame has been accumulated its registers are
+// refilled with the frame kRing further on.  Unlike the window-major order of `assemble`, rows that have not been
+// reached yet hold nothing, so the ring and the accumulators never peak together: this is what lets the loads
+// stream without spilling.  Arithmetic per entry: the same sums in a different order (frame-major).
+constexpr int kRing = 6;
+template <typename TIN, bool BWD, int VM, bool EDGE, int NW>
+__device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, __amdgpu_buffer_rsrc_t vrs,
+                                                   __amdgpu_buffer_rsrc_t grs, const TIN *__restrict__ vglob,
+                                                   unsigned loff, long ldi, long ldg, int sd, int f0, int T, int mw,
+                                                   const double (*wc)[9], double (&Pd)[kM], double (&P1)[kM],
+                                                   double (&P2)[kM], double (&rhs)[kM], double &ca, double &cb,
+                                                   double &cc, double (&rec)[kRec]) {
+  // No zero-fill: every accumulator is ASSIGNED by the first contribution that reaches it (window 0 of the frame
+  // noted below), so that a row costs no register before its first frame arrives.
+  const unsigned ldi_bytes = (unsigned)ldi * (unsigned)sizeof(TIN), win_bytes = (unsigned)sd * (unsigned)sizeof(TIN);
+  // live frames of a window: [0, T) for the static window, [mw, T - mw) for the dynamic ones (none if mw == 0)
+  int lo[NW], hi[NW], cl[NW], ch[NW];
+  WinCoef k[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    lo[w] = w ? mw : 0;
+    hi[w] = w ? (mw != 0 && T - mw > mw ? T - mw : mw) : T;
+    cl[w] = lo[w] < T ? lo[w] : T - 1;            // a window without live frames still loads (frame cl) and weighs 0
+    ch[w] = hi[w] > cl[w] ? hi[w] : cl[w] + 1;
+    k[w] = win_coef<TIN, VM>(wc, w, vglob, sd);
+  }
+  TIN rv[kRing][NW], rm[kRing][NW];
+  auto load_frame = [&](TIN (&v)[NW], TIN (&m)[NW], const int i) __attribute__((always_inline)) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      int t = f0 + i;
+      if (EDGE) t = t < cl[w] ? cl[w] : (t >= ch[w] ? ch[w] - 1 : t);
+      const unsigned soff = (unsigned)t * ldi_bytes + (unsigned)w * win_bytes;
+      if (VM == MLPG_HIP_VAR_FRAME) v[w] = ld_row<TIN>(vrs, soff, loff);
+      if (!BWD) m[w] = ld_row<TIN>(mrs, soff, loff);
+    }
+  };
+  auto accumulate_frame = [&](const TIN (&v)[NW], const TIN (&m)[NW], const int i) __attribute__((always_inline)) {
+    const int t = f0 + i;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      double tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[w]) : k[w].tau_glob;
+      if (EDGE) tau *= (t >= lo[w] && t < hi[w]) ? 1.0 : 0.0;  // wave-uniform weight
+      double tm = 0.0;
+      if (!BWD) tm = tau * (double)m[w];
+      const bool first = w == 0;  // first contribution to: Pd, rhs of row t+1; P1 of row t; P2 of row t-1
+      if (i >= 0 && i < kM) {  // row t
+        Pd[i] += k[w].c00 * tau;
+        P1[i] = first ? k[w].cp0 * tau : P1[i] + k[w].cp0 * tau;
+        if (!BWD) rhs[i] += k[w].c0 * tm;
+      }
+      if (i + 1 >= 0 && i + 1 < kM) {  // row t+1
+        Pd[i + 1] = first ? k[w].cpp * tau : Pd[i + 1] + k[w].cpp * tau;
+        if (!BWD) rhs[i + 1] = first ? k[w].cp * tm : rhs[i + 1] + k[w].cp * tm;
+      }
+      if (i - 1 >= 0 && i - 1 < kM) {  // row t-1
+        Pd[i - 1] += k[w].cmm * tau;
+        P1[i - 1] += k[w].c0m * tau;
+        P2[i - 1] = first ? k[w].cpm * tau : P2[i - 1] + k[w].cpm * tau;
+        if (!BWD) rhs[i - 1] += k[w].cm * tm;
+      }
+      // coupling of the chunk's first two rows to the previous chunk's separator:
+      // ca = P[f0, f0-2], cb = P[f0, f0-1], cc = P[f0+1, f0-1]
+      if (i == -1) {
+        ca = first ? k[w].cpm * tau : ca + k[w].cpm * tau;
+        cb = first ? k[w].cp0 * tau : cb + k[w].cp0 * tau;
+      }
+      if (i == 0) {
+        cb += k[w].c0m * tau;
+        cc = first ? k[w].cpm * tau : cc + k[w].cpm * tau;
+      }
+    }
+  };
+  // matrix edges (EDGE): rows >= T are identity rows, entries that would leave the T x T matrix vanish.  Wave-uniform
+  // 0/1 factors instead of branches (x * 1 and x * 1 + 0 are exact; dead frames enter with weight 0, so nothing
+  // that is multiplied by 0 here can be Inf or NaN unless the input is): straight-line code for the allocator.
+  auto fix_row = [&](const int i) __attribute__((always_inline)) {
+    const int f = f0 + i;
+    const double live = f < T ? 1.0 : 0.0, live1 = f + 1 < T ? 1.0 : 0.0, live2 = f + 2 < T ? 1.0 : 0.0;
+    Pd[i] = Pd[i] * live + (1.0 - live);
+    P1[i] *= live1;
+    P2[i] *= live2;
+    rhs[i] *= live;
+  };
+  // elimination state (see `eliminate`)
+  bool bad = false;
+  double t00 = 0.0, t01 = 0.0, t11 = 0.0, h0 = 0.0, h1 = 0.0;
+  double g1 = 0.0, g2 = 0.0, va1 = 0.0, va2 = 0.0, vb1 = 0.0, vb2 = 0.0;
+  double l1p = 0.0, l2p = 0.0, l2pp = 0.0;
+  auto elim_row = [&](const int i) __attribute__((always_inline)) {
+    if (EDGE) {
+      fix_row(i);
+      if (i == 0) {
+        const double keep = (f0 == 0 || f0 >= T) ? 0.0 : 1.0, keepc = f0 + 1 >= T ? 0.0 : 1.0;
+        ca *= keep;
+        cb *= keep;
+        cc *= keep * keepc;
+      }
+    }
+    const double dd = Pd[i];
+    bad |= !(dd > 0.0);
+    const double dinv = fast_rcp(dd);
+    const double e1 = P1[i], e2 = P2[i];
+    const double l1 = e1 * dinv, l2 = e2 * dinv;
+    Pd[i + 1] -= l1 * e1;
+    P1[i + 1] -= l2 * e1;
+    Pd[i + 2] -= l2 * e2;
+    const double gi = rhs[i] - l1p * g1 - l2pp * g2;
+    const double ba = (i == 0) ? ca : 0.0;
+    const double bb = (i == 0) ? cb : ((i == 1) ? cc : 0.0);
+    const double va = ba - l1p * va1 - l2pp * va2;
+    const double vb = bb - l1p * vb1 - l2pp * vb2;
+    const double wa = va * dinv, wb = vb * dinv;
+    t00 += wa * va;
+    t01 += wa * vb;
+    t11 += wb * vb;
+    h0 += wa * gi;
+    h1 += wb * gi;
+    Pd[i] = dinv;
+    P1[i] = l1;
+    P2[i] = l2;
+    rhs[i] = gi;
+    g2 = g1; g1 = gi;
+    va2 = va1; va1 = va;
+    vb2 = vb1; vb1 = vb;
+    l2pp = l2p; l2p = l2; l1p = l1;
+  };
+
+  // prologue: the first kRing frames (f0-1 ..) in flight
+#define STRIP_LD(S, I) load_frame(rv[S], rm[S], (I));
+  STRIP_LD(0, -1) STRIP_LD(1, 0) STRIP_LD(2, 1) STRIP_LD(3, 2) STRIP_LD(4, 3) STRIP_LD(5, 4)
+  static_assert(kRing == 6, "the unrolled schedule below is written for a ring of 6 frames");
+  if (BWD) {
+#pragma unroll
+    for (int i = 0; i < kM; ++i) {
+      int t = f0 + i;
+      if (EDGE) t = t >= T ? T - 1 : t;
+      rhs[i] = (double)ld_row<TIN>(grs, (unsigned)t * (unsigned)ldg * (unsigned)sizeof(TIN), loff);  // rows >= T are reset by fix_row
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // step S handles frame I = S - 1 in ring slot S % 6: accumulate, refill with frame I + 6, eliminate row I - 1
+#define STRIP_STEP(S)                                                                   \
+  accumulate_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1);                            \
+  __builtin_amdgcn_sched_barrier(0);                                                    \
+  if ((S) + kRing < kM + 2) { load_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1 + kRing); } \
+  __builtin_amdgcn_sched_barrier(0);                                                    \
+  if ((S)-2 >= 0 && (S)-2 < kN) { elim_row((S)-2); }                                    \
+  __builtin_amdgcn_sched_barrier(0);
+  STRIP_STEP(0) STRIP_STEP(1) STRIP_STEP(2) STRIP_STEP(3) STRIP_STEP(4) STRIP_STEP(5)
+  STRIP_STEP(6) STRIP_STEP(7) STRIP_STEP(8) STRIP_STEP(9) STRIP_STEP(10) STRIP_STEP(11)
+  STRIP_STEP(12) STRIP_STEP(13) STRIP_STEP(14) STRIP_STEP(15) STRIP_STEP(16) STRIP_STEP(17)
+#undef STRIP_STEP
+#undef STRIP_LD
+  if (EDGE) {
+    fix_row(kN);
+    fix_row(kN + 1);
+  }
+  rec[rT00] = t00; rec[rT01] = t01; rec[rT11] = t11; rec[rH0] = h0; rec[rH1] = h1;
+  rec[rD11] = Pd[kN]; rec[rD12] = P1[kN]; rec[rD22] = Pd[kN + 1];
+  rec[rF1] = rhs[kN] - (l1p * g1 + l2pp * g2);
+  rec[rF2] = rhs[kN + 1] - l2p * g1;
+  rec[rL11] = -(l1p * va1 + l2pp * va2);
+  rec[rL12] = -(l1p * vb1 + l2pp * vb2);
+  rec[rL21] = -(l2p * va1);
+  rec[rL22] = -(l2p * vb1);
+  return bad;
+}
+
 // ---- level 1: back-substitution; on return x[0..kM) is the chunk's solution -------------------
 __device__ __forceinline__ void backsub(const double (&Pd)[kM], const double (&P1)[kM], const double (&P2)[kM],
                                         double (&rhs)[kM], double ca, double cb, double cc, V2 ul, V2 u) {
@@ -526,6 +703,16 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
   bool bad = false;
   if (f0 < T) {
     const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < T - mw;
+    if (MLPG_STRIP_STREAM && nw == 3 && VM != MLPG_HIP_VAR_UNIT && MLPG_STRIP_ABLATE < 2) {
+      // the usual three windows: assembly and elimination streamed in frame order
+      if (interior) bad = assemble_eliminate<TIN, BWD, VM, false, 3>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, Pd, P1, P2, rhs, ca, cb, cc, rec);
+      else bad = assemble_eliminate<TIN, BWD, VM, true, 3>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, Pd, P1, P2, rhs, ca, cb, cc, rec);
+      STRIP_TICK(1);
+#ifdef MLPG_STRIP_TRACE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tra = (long long)__builtin_amdgcn_s_memrealtime();   // this wavefront's loads have all landed
+#endif
+    } else {
     if (interior) assemble<TIN, BWD, VM, false>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, Tmax, ws, a.wc, Pd, P1, P2, rhs, ca, cb, cc);
     else assemble<TIN, BWD, VM, true>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, Tmax, ws, a.wc, Pd, P1, P2, rhs, ca, cb, cc);
     STRIP_TICK(1);
@@ -538,6 +725,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
 #pragma unroll
       for (int k = 0; k < kRec; ++k) rec[k] = Pd[k] + rhs[k];
       rec[rD11] = rec[rD22] = 1.0; rec[rD12] = 0.0;
+    }
     }
   } else {
     // a chunk of identity rows behind the utterance's end (keeps the strip's separator chain regular)
