@@ -266,6 +266,20 @@ def main():
             emit(path="c4-fastdtw-kernel-1024pairs", pairs=8 * N, ms=ms8, pairs_per_s=8 * N / ms8 * 1e3, alg_bytes=8 * by,
                  GBps=8 * by / ms8 / 1e6)
             del X8, Y8
+            # the same 1024 pairs from HOST memory through mlpg_hip_fastdtw_host (device-side trim, chunks of pairs
+            # on two streams, PCIe-inclusive wall clock), pageable and pinned inputs
+            Xh, Yh = np.tile(X, (8, 1, 1)), np.tile(Y, (8, 1, 1))
+            for nm, (a_, b_) in (("pageable", (Xh, Yh)), ("pinned", (_hip.pinned_empty(Xh.shape), _hip.pinned_empty(Yh.shape)))):
+                if nm == "pinned":
+                    a_[...] = Xh
+                    b_[...] = Yh
+                _hip.fastdtw_host(a_, b_, 1)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    _hip.fastdtw_host(a_, b_, 1)
+                wall = (time.perf_counter() - t0) / 3 * 1e3
+                emit(path="c4h-fastdtw-host-1024pairs-" + nm, pairs=8 * N, ms=wall, pairs_per_s=8 * N / wall * 1e3,
+                     host_bytes=float(Xh.nbytes + Yh.nbytes))
         emit(path="c4-fastdtw-kernel", pairs=N, ms=ms, pairs_per_s=N / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6,
              cpu_oracle_c_pairs_per_s=1.0 / cpu_s, transform_numpy_to_numpy_ms=ms_full)
 
@@ -289,6 +303,16 @@ def main():
              fft_GFLOPs=fl / ms / 1e6, cpu_numpy_fft_frames_per_s=T / cpu_s)
         ms2 = gpu_time(lambda: _hip.modspec(x, n), steps=5)
         emit(path="ms-modspec-n4096", ms=ms2, frames_per_s=B * T / ms2 * 1e3)
+        # a DFT length outside the in-LDS FFT: the direct transform (modspec_dft.hip)
+        nd = 5000
+        ms3 = gpu_time(lambda: _hip.modspec_smoothing(x, nd, 600, True), steps=3, warmup=1)
+        t0 = time.perf_counter()
+        for b_ in range(2):
+            s_ = np.fft.rfft(xc[b_], n=nd, axis=0)
+            np.fft.irfft(np.abs(s_) * np.exp(1j * np.angle(s_)), n=nd, axis=0)[:T]
+        cpu3 = (time.perf_counter() - t0) / 2
+        emit(path="ms-modspec_smoothing-n5000-direct", ms=ms3, frames_per_s=B * T / ms3 * 1e3, alg_bytes=by, GBps=by / ms3 / 1e6,
+             cpu_numpy_fft_frames_per_s=T / cpu3)
         del x
 
     # ---- c5: Merlin-style multi-stream ----
