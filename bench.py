@@ -163,8 +163,11 @@ def measured_traffic(B, T, sd, algo):
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
         w = t["workload"]
-        if (w["batch_per_gpu"], w["frames"], w["static_dim"]) == (B, T, sd) and algo in t.get("algos", (0, 2)):
-            return float(t["traffic_bytes_per_launch"])
+        if (w["batch_per_gpu"], w["frames"], w["static_dim"]) == (B, T, sd):
+            if algo in t.get("algos", (0, 3)):
+                return float(t["traffic_bytes_per_launch"])
+            if algo == t.get("other", {}).get("algo"):
+                return float(t["other"]["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -378,7 +381,7 @@ def main():
                             "(%d columns), float64, per-frame variances, std 3 windows; mlpg_hip_forward via C ABI"
                             % (B, T, sd, D),
                 "batch_per_gpu": B, "frames": T, "static_dim": sd, "algo": args.algo,
-                "kernel": algo_names.get(args.algo, "?") + (" (= strip at this shape)" if args.algo == 0 and sd >= 16 else ""),
+                "kernel": algo_names.get(args.algo, "?") + (" (= strip at this shape: mlpg::strip::strip_kernel)" if args.algo == 0 else ""),
                 "parallelism": "batch-sharded x%d, no data-path collective" % world,
             },
             "roofline": {

@@ -183,7 +183,7 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     return MLPG_HIP_EINVAL;
   }
   if (algo == MLPG_HIP_ALGO_AUTO) {
-    if (strip_preferred(p, ws, backward) || (strip_supported(p, ws) && !wave_supported(p, ws))) algo = MLPG_HIP_ALGO_STRIP;
+    if (strip_preferred(p, ws, backward, in_dtype) || (strip_supported(p, ws) && !wave_supported(p, ws))) algo = MLPG_HIP_ALGO_STRIP;
     else algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
   }
   if (algo == MLPG_HIP_ALGO_STRIP) return launch_strip(st, in_dtype, out_dtype, backward, p, ws, device);

@@ -56,7 +56,7 @@ bool wave_supported(const Problem &p, const WinSet &w);
 int launch_wave(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
                 int device);
 bool strip_supported(const Problem &p, const WinSet &w);
-bool strip_preferred(const Problem &p, const WinSet &w, bool backward);
+bool strip_preferred(const Problem &p, const WinSet &w, bool backward, int in_dtype);
 int launch_strip(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
                  int device);
 int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,

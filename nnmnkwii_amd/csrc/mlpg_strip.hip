@@ -29,18 +29,21 @@ bool strip_supported(const Problem &p, const WinSet &ws) {
 // static dims on lanes and the strips of one utterance on different CUs; the wave-per-system kernel keeps a whole
 // utterance in one workgroup.  The strip kernel wins when its lanes are filled (dims per 64-lane group >= 48: 60, 64,
 // 128 static dims; not 25 or 80 = 2 x 40) and the launch has enough 64-frame strips to occupy the persistent grid
-// (>= 512: two per CU); with per-frame variances that is 0.236 vs 0.283 ms forward and 0.357 vs 0.375 ms backward
-// on the config-2 shape, 0.037 vs 0.075 ms at 256 x 100 frames.  Lighter traffic (global / unit variances) ties
+// (>= 512: two per CU); with per-frame variances that is 0.233 vs 0.285 ms forward (float32: 0.168 vs 0.239 ms)
+// on the config-2 shape, 0.032 vs 0.075 ms at 256 x 100 frames.  Lighter traffic (global / unit variances) ties
 // at T <= 1024 and stays with the wave kernel.  Beyond 1024 frames the wave kernel needs 32 frames per lane
 // (register spills, one workgroup per CU) or does not apply at all (T > 2048), and the strip kernel takes over
 // for every stream of >= 16 dims.
-bool strip_preferred(const Problem &p, const WinSet &ws, bool backward) {
+bool strip_preferred(const Problem &p, const WinSet &ws, bool backward, int in_dtype) {
   if (!strip_supported(p, ws)) return false;
   if (p.sd >= 16 && p.Tmax > 1024) return true;
   const int ndg = (p.sd + 63) / 64, dgw = (p.sd + ndg - 1) / ndg;
   const long nitems = (long)p.B * ndg * ((p.Tmax + kStripFrames - 1) / kStripFrames);
-  (void)backward;  // 0.357 vs 0.375 ms on the config-2 shape: the same rule both ways
-  return p.var_mode == MLPG_HIP_VAR_FRAME && dgw >= 48 && nitems >= 512;
+  if (p.var_mode != MLPG_HIP_VAR_FRAME || dgw < 48) return false;
+  // backward: the epilogue (three gradient rows per frame, variances re-read) does not get cheaper with float32
+  // inputs: 0.357 (strip) vs 0.396 ms (wave) in float64, 0.353 vs 0.308 ms in float32 on the config-2 shape
+  if (backward) return in_dtype == MLPG_HIP_F64 && nitems >= 1024;
+  return nitems >= 512;
 }
 
 int launch_strip(hipStream_t st, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &ws,

@@ -14,9 +14,12 @@ from tools.bench_paths import WINDOWS, gpu_time  # noqa: E402
 def main():
     import torch
     from nnmnkwii_amd import _hip
+    backward = "--backward" in sys.argv
     shapes = [(256, 1000, 60), (64, 1000, 60), (16, 1000, 60), (4, 1000, 60), (1, 1000, 60), (256, 300, 60), (64, 300, 60),
               (256, 1000, 25), (256, 1000, 16), (256, 1000, 8), (256, 1000, 5), (512, 2000, 5), (512, 2000, 1),
               (64, 500, 60), (32, 2000, 60), (8, 4000, 60), (256, 100, 60), (1024, 100, 60), (256, 1000, 64), (256, 1000, 80), (256, 1000, 128)]
+    if backward:
+        shapes = [(256, 1000, 60), (64, 1000, 60), (256, 300, 60), (64, 500, 60), (32, 2000, 60), (256, 1000, 25), (256, 1000, 128)]
     for dt in (torch.float64, torch.float32):
         for B, T, sd in shapes:
             m = torch.randn(B, T, 3 * sd, dtype=dt, device="cuda")
@@ -25,12 +28,16 @@ def main():
             row = []
             for algo in (_hip.ALGO_WAVE, _hip.ALGO_STRIP, _hip.ALGO_GENERIC):
                 try:
-                    ms = gpu_time(lambda: _hip.forward(m, v, pw, algo=algo), steps=20, warmup=3)
+                    if backward:
+                        go = m[:, :, :sd].contiguous()
+                        ms = gpu_time(lambda: _hip.backward(v, go, pw, 3 * sd, out_dtype=dt, algo=algo, want_status=False), steps=20, warmup=3)
+                    else:
+                        ms = gpu_time(lambda: _hip.forward(m, v, pw, algo=algo), steps=20, warmup=3)
                 except Exception as e:  # unsupported shape for that kernel
                     ms = float("nan")
                 row.append(ms)
             best = ["wave", "strip", "generic"][int(np.nanargmin(row))]
-            print("%s B=%4d T=%4d sd=%3d  wave %.4f  strip %.4f  generic %.4f  -> %s" % (str(dt)[6:], B, T, sd, row[0], row[1], row[2], best), flush=True)
+            print(("bwd " if backward else "fwd ") + "%s B=%4d T=%4d sd=%3d  wave %.4f  strip %.4f  generic %.4f  -> %s" % (str(dt)[6:], B, T, sd, row[0], row[1], row[2], best), flush=True)
             del m, v
 
 
