@@ -304,6 +304,19 @@ __attribute__((visibility("default"))) void mlpg_hip_shutdown(void) {
       if (kv.second.slot[s].ptr) (void)hipFree(kv.second.slot[s].ptr);
   }
   g_scratch.clear();
+  for (int d = 0; d < kMaxDevices; ++d) {
+    if (!g_side[d]) continue;
+    (void)hipSetDevice(d);
+    for (int q = 0; q < SideStreams::kN; ++q) {
+      (void)hipStreamSynchronize(g_side[d]->st[q]);
+      (void)hipStreamDestroy(g_side[d]->st[q]);
+      (void)hipEventDestroy(g_side[d]->join[q]);
+    }
+    (void)hipEventDestroy(g_side[d]->fork);
+    delete g_side[d];
+    g_side[d] = nullptr;
+  }
+  host_api_shutdown();
   if (prev >= 0) (void)hipSetDevice(prev);
 }
 

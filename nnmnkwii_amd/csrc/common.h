@@ -63,6 +63,7 @@ int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, con
                      int ncols, void *dst, long ld_dst);
 int launch_modspec(hipStream_t s, int mode, const double *x, const double *ms, const double *ph, double *out,
                    double *out_ph, int B, int T, int D, int n, int ortho, int limit_bin, int log_domain);
+void host_api_shutdown();  // host_api.hip: streams, events, pinned and device staging buffers of the _host entry points
 int launch_modspec_dft(hipStream_t s, int device, int mode, const double *x, const double *ms, const double *ph,
                        double *out, double *out_ph, int B, int T, int D, int n, int ortho, int limit_bin,
                        int log_domain);

@@ -103,6 +103,26 @@ __global__ void widen_f32(const float *__restrict__ src, double *__restrict__ ds
 }
 
 }  // namespace
+
+void host_api_shutdown() {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  for (int d = 0; d < 16; ++d) {
+    HostCtx &c = g_host[d];
+    if (!c.ok && !c.dev[0] && !c.pin_in[0] && !c.pin_out[0]) continue;
+    (void)hipSetDevice(d);
+    for (int k = 0; k < 2; ++k) {
+      if (c.st[k]) {
+        (void)hipStreamSynchronize(c.st[k]);
+        (void)hipStreamDestroy(c.st[k]);
+      }
+      if (c.done[k]) (void)hipEventDestroy(c.done[k]);
+      if (c.pin_in[k]) (void)hipHostFree(c.pin_in[k]);
+      if (c.pin_out[k]) (void)hipHostFree(c.pin_out[k]);
+      if (c.dev[k]) (void)hipFree(c.dev[k]);
+    }
+    c = HostCtx();
+  }
+}
 }  // namespace mlpg
 
 using namespace mlpg;

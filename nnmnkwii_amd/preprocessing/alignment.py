@@ -78,12 +78,37 @@ class DTWAligner(object):
         self.dist = dist
         self.radius = radius
 
+    # Batches below this many input bytes go through device tensors (upload once, trim + fastdtw + gather on the GPU,
+    # download the aligned arrays: 4-6 ms for 128 config-4 pairs); larger ones through the host-pointer entry point
+    # (chunked, transfers overlapped with the kernels) with the aligned arrays assembled on the host.
+    _HOST_ENTRY_BYTES = 64 << 20
+
     def _paths(self, X, Y):
-        """Trim + fastdtw of every pair through the host-pointer entry point (chunks of pairs, transfers overlapped
-        with the kernels).  Returns numpy (path_i, path_j, path_len, cost, lenx, leny)."""
+        """Trim + fastdtw of every pair.  Returns numpy (path_i, path_j, path_len, cost, lenx, leny) and a gather
+        function ``(src_is_x, path, plen, T_out, dtype) -> aligned array``."""
         dist_kind, dist_scale = _resolve_dist(self.dist)
-        _hip.require_gpu()
-        return _hip.fastdtw_host(X, Y, self.radius, dist_kind, dist_scale)      # alignment.py:46-50
+        dev = _hip.require_gpu()
+        if X.nbytes + Y.nbytes >= self._HOST_ENTRY_BYTES:
+            out = _hip.fastdtw_host(X, Y, self.radius, dist_kind, dist_scale)      # alignment.py:46-50
+            return out + ((lambda is_x, path, plen, T_out, dtype: _gather(X if is_x else Y, path, plen, T_out, dtype)),)
+        torch = _hip.torch_mod()
+        Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
+        Yd = torch.from_numpy(np.ascontiguousarray(Y)).to(dev)
+        if Xd.dtype not in (torch.float32, torch.float64):
+            Xd = Xd.to(torch.float64)
+        if Yd.dtype not in (torch.float32, torch.float64):
+            Yd = Yd.to(torch.float64)
+        lenx = _hip.trim_lengths(Xd)                       # alignment.py:46-49
+        leny = _hip.trim_lengths(Yd)
+        X64 = Xd if Xd.dtype == torch.float64 else Xd.to(torch.float64)   # fastdtw casts to float
+        Y64 = Yd if Yd.dtype == torch.float64 else Yd.to(torch.float64)
+        path_i, path_j, path_len, cost = _hip.fastdtw_l2(X64, Y64, lenx, leny, self.radius, dist_kind, dist_scale)   # :50
+
+        def gather(is_x, path, plen, T_out, dtype):
+            g = _hip.gather_path(Xd if is_x else Yd, path_i if is_x else path_j, path_len, T_out)   # :52-54,72-73
+            return g.cpu().numpy().astype(dtype, copy=False)
+        return (path_i.cpu().numpy(), path_j.cpu().numpy(), path_len.cpu().numpy(), cost.cpu().numpy(),
+                lenx.cpu().numpy(), leny.cpu().numpy(), gather)
 
     def transform(self, XY):
         X, Y = XY
@@ -92,13 +117,13 @@ class DTWAligner(object):
         N = X.shape[0]
         if N == 0:
             return np.zeros_like(longer), np.zeros_like(longer)
-        path_i, path_j, plen, cost, lenx, leny = self._paths(X, Y)
+        path_i, path_j, plen, cost, lenx, leny, gather = self._paths(X, Y)
         if (plen <= 0).any():
             bad = int(np.flatnonzero(plen <= 0)[0])
             raise ValueError("DTWAligner: pair %d has an empty (all-zero) utterance or could not be aligned" % bad)
         T_out = max(int(longer.shape[1]), int(plen.max()))  # :55-71 (outputs only ever grow)
-        Xa = _gather(X, path_i, plen, T_out, longer.dtype)  # :52-54,72
-        Ya = _gather(Y, path_j, plen, T_out, longer.dtype)  # :73
+        Xa = gather(True, path_i, plen, T_out, longer.dtype)   # :52-54,72
+        Ya = gather(False, path_j, plen, T_out, longer.dtype)  # :73
         if self.verbose > 0:
             d = cost / (lenx + leny)                        # :51
             for idx in range(N):
@@ -108,12 +133,15 @@ class DTWAligner(object):
 
 def _gather(src, path, plen, T_out, dtype):
     """out[n, k] = src[n, path[n, k]] for k < plen[n], zeros after: the reference's ``x[pathx]`` written into a
-    zero-padded buffer (alignment.py:52-54, 72-73) -- indexing only, for all pairs at once."""
-    idx = np.clip(path[:, :T_out], 0, src.shape[1] - 1)       # slots beyond plen hold no index
-    if idx.shape[1] < T_out:
-        idx = np.pad(idx, [(0, 0), (0, T_out - idx.shape[1])])
-    out = np.take_along_axis(src, idx[:, :, None].astype(np.intp), axis=1).astype(dtype, copy=False)
-    out[np.arange(T_out)[None, :] >= plen[:, None]] = 0
+    zero-padded buffer (alignment.py:52-54, 72-73) -- indexing only (row copies), pair by pair."""
+    out = np.zeros((src.shape[0], T_out, src.shape[2]), dtype=dtype)
+    same = src.dtype == out.dtype
+    for n in range(src.shape[0]):
+        k = int(plen[n])
+        if same:
+            np.take(src[n], path[n, :k], axis=0, out=out[n, :k])
+        else:
+            out[n, :k] = src[n][path[n, :k]]
     return out
 
 
@@ -158,7 +186,7 @@ class IterativeDTWAligner(object):
         path_x, plen = None, None
 
         for _ in range(self.n_iter):
-            path_i, path_j, plen, cost, lenx, leny = aligner._paths(Xc, Y)
+            path_i, path_j, plen, cost, lenx, leny, gather = aligner._paths(Xc, Y)
             if (plen <= 0).any():
                 bad = int(np.flatnonzero(plen <= 0)[0])
                 raise ValueError("IterativeDTWAligner: pair %d has an empty (all-zero) utterance" % bad)
@@ -167,8 +195,8 @@ class IterativeDTWAligner(object):
                 grow = [(0, 0), (0, T_out - X_aligned.shape[1]), (0, 0)]
                 X_aligned = np.pad(X_aligned, grow, mode="constant", constant_values=0)
                 Y_aligned = np.pad(Y_aligned, grow, mode="constant", constant_values=0)
-            Xg = _gather(Xc, path_i, plen, T_out, X_aligned.dtype)
-            Yg = _gather(Y, path_j, plen, T_out, Y_aligned.dtype)
+            Xg = gather(True, path_i, plen, T_out, X_aligned.dtype)
+            Yg = gather(False, path_j, plen, T_out, Y_aligned.dtype)
             prefix = (np.arange(T_out)[None, :] < plen[:, None])[:, :, None]
             X_aligned = np.where(prefix, Xg, X_aligned)   # prefix writes (:163-164)
             Y_aligned = np.where(prefix, Yg, Y_aligned)

@@ -246,3 +246,57 @@ def test_fastdtw_host_entry_equals_device_entry():
         hi, hj, hl, hc, _, _ = _hip.fastdtw_host(a, b, 1)
         assert np.array_equal(hl, pl.cpu().numpy()) and np.array_equal(hc, cost.cpu().numpy())
         assert np.array_equal(hi[3, :hl[3]], pi[3, :hl[3]].cpu().numpy())
+
+
+def test_dtw_aligner_host_entry_route_equals_device_route(monkeypatch):
+    """DTWAligner takes the host-pointer entry point for large batches and device tensors for small ones: the two
+    routes return the same arrays (forced here on one small batch), float64 and float32."""
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner, IterativeDTWAligner
+    X, Y = c4_pairs(5, seed=21)
+    for dt in (np.float64, np.float32):
+        Xc, Yc = X.astype(dt), Y.astype(dt)
+        a = DTWAligner().transform((Xc, Yc))
+        monkeypatch.setattr(DTWAligner, "_HOST_ENTRY_BYTES", 0)
+        b = DTWAligner().transform((Xc, Yc))
+        monkeypatch.undo()
+        assert a[0].dtype == b[0].dtype == dt and a[0].shape == b[0].shape
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    np.random.seed(0)
+    a = IterativeDTWAligner(n_iter=1, n_components_gmm=2, max_iter_gmm=5).transform((X[:3, :200], Y[:3, :200]))
+    monkeypatch.setattr(DTWAligner, "_HOST_ENTRY_BYTES", 0)
+    np.random.seed(0)
+    b = IterativeDTWAligner(n_iter=1, n_components_gmm=2, max_iter_gmm=5).transform((X[:3, :200], Y[:3, :200]))
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_shutdown_releases_everything_and_the_library_keeps_working():
+    """mlpg_hip_shutdown frees the per-stream scratch, the side streams of the multi-stream entry and the staging
+    buffers / streams of the host entry points; every path must come up again afterwards with the same results."""
+    import torch
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd import paramgen as G
+    windows = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(8)
+    M_ = rng.randn(9, 200, 180)
+    V_ = rng.rand(9, 200, 180) + 0.1
+
+    def run():
+        y_host = G.mlpg_batch(M_, V_, windows)                                        # host entry
+        m, v = torch.from_numpy(M_).cuda(), torch.from_numpy(V_).cuda()
+        y_strip, _ = _hip.forward(m, v, windows, algo=_hip.ALGO_STRIP)
+        y_gen, _ = _hip.forward(m, v, windows, algo=_hip.ALGO_GENERIC)
+        ys = G.multi_stream_mlpg(M_[:, :, :186], V_[0, 0, :186], windows, [180, 3, 3], [True, True, True])
+        X, Y = c4_pairs(3, seed=2)
+        paths = _hip.fastdtw_host(X, Y, 1)
+        torch.cuda.synchronize()
+        return y_host, y_strip.cpu().numpy(), y_gen.cpu().numpy(), ys, paths[0], paths[3]
+    a = run()
+    _hip.lib().mlpg_hip_shutdown()
+    b = run()
+    _hip.lib().mlpg_hip_shutdown()
+    _hip.lib().mlpg_hip_shutdown()           # idempotent
+    c = run()
+    for u, v, w in zip(a, b, c):
+        assert np.array_equal(u, v) and np.array_equal(u, w)
