@@ -287,7 +287,7 @@ def test_shutdown_releases_everything_and_the_library_keeps_working():
         m, v = torch.from_numpy(M_).cuda(), torch.from_numpy(V_).cuda()
         y_strip, _ = _hip.forward(m, v, windows, algo=_hip.ALGO_STRIP)
         y_gen, _ = _hip.forward(m, v, windows, algo=_hip.ALGO_GENERIC)
-        ys = G.multi_stream_mlpg(M_[:, :, :186], V_[0, 0, :186], windows, [180, 3, 3], [True, True, True])
+        ys = G.multi_stream_mlpg(M_[:, :, :129], V_[0, 0, :129], windows, [120, 3, 6], [True, True, True])
         X, Y = c4_pairs(3, seed=2)
         paths = _hip.fastdtw_host(X, Y, 1)
         torch.cuda.synchronize()
