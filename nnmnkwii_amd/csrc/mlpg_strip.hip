@@ -40,9 +40,10 @@ bool strip_preferred(const Problem &p, const WinSet &ws, bool backward, int in_d
   const int ndg = (p.sd + 63) / 64, dgw = (p.sd + ndg - 1) / ndg;
   const long nitems = (long)p.B * ndg * ((p.Tmax + kStripFrames - 1) / kStripFrames);
   if (p.var_mode != MLPG_HIP_VAR_FRAME || dgw < 48) return false;
-  // backward: the epilogue (three gradient rows per frame, variances re-read) does not get cheaper with float32
-  // inputs: 0.357 (strip) vs 0.396 ms (wave) in float64, 0.353 vs 0.308 ms in float32 on the config-2 shape
-  if (backward) return in_dtype == MLPG_HIP_F64 && nitems >= 1024;
+  // backward (config-2 shape): 0.296 (strip) vs 0.397 ms (wave) in float64, 0.273 vs 0.314 ms in float32; 64 x 500:
+  // 0.044 vs 0.053 ms -- the same rule both ways
+  (void)backward;
+  (void)in_dtype;
   return nitems >= 512;
 }
 

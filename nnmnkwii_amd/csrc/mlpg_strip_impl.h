@@ -1110,13 +1110,24 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
     // grad[t, w*sd+d] = tau_w[t] * (cm x[t-1] + c0 x[t] + cp x[t+1])  (paramgen/_mlpg.py:202-281).  The row whose
     // right neighbour lives in the next chunk is written by that chunk: this wavefront writes rows f0-1 .. f0+14,
     // and row f0+15 only if it is the utterance's last frame or padding.
-    for (int w = 0; w < nw; ++w) {
-      const int l = ws.l[w], u = ws.u[w];
-      const double *cw = ws.c + ws.off[w];
-      const double cm = l ? cw[0] : 0.0, c0 = cw[l], cp = u ? cw[l + 1] : 0.0;
+    // The variances are read again here (the 51 reciprocals of the assembly are not kept).  All of a window's 17
+    // loads are issued before its stores, and the next window's before this window's arithmetic: written as
+    // load -> reciprocal -> store per row, the compiler cannot move a load above the preceding store (the two
+    // pointers may alias) and the epilogue becomes 51 round trips.
+    const unsigned ldi_bytes = (unsigned)ldi * (unsigned)sizeof(TIN), win_bytes = (unsigned)sd * (unsigned)sizeof(TIN);
+    auto load_w = [&](TIN (&v)[kM + 1], const int w) __attribute__((always_inline)) {
+      if (VM != MLPG_HIP_VAR_FRAME) return;
+#pragma unroll
+      for (int i = -1; i < kM; ++i) {
+        int t = f0 + i;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);  // in bounds; a row that is not live is not used
+        v[i + 1] = ld_row<TIN>(vrs, (unsigned)t * ldi_bytes + (unsigned)w * win_bytes, loff);
+      }
+    };
+    auto emit_w = [&](const TIN (&v)[kM + 1], const int w) __attribute__((always_inline)) {
+      const double cm = a.wc[w][0], c0 = a.wc[w][1], cp = a.wc[w][2];
       double tau_glob = 1.0;
       if (VM == MLPG_HIP_VAR_GLOBAL) tau_glob = tau_of<TIN>(vglob[w * sd]);
-      const TIN *vw_col = VM == MLPG_HIP_VAR_FRAME ? vcol + (size_t)w * sd : nullptr;
       TOUT *ow = out_b + (size_t)w * sd + d;
 #pragma unroll
       for (int i = -1; i < kM; ++i) {
@@ -1130,12 +1141,26 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         if (i == kM - 1 && t != T - 1) continue;    // the next chunk writes it
         const bool lv = w ? (mw != 0 && t >= mw && t < T - mw) : true;
         double tau = 0.0;
-        if (lv) tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(vw_col[(size_t)t * ldi]) : tau_glob;
+        if (lv) tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[i + 1]) : tau_glob;
         const double xm = (i == -1) ? ul.x : ((i == 0) ? ul.y : rhs[i > 0 ? i - 1 : 0]);
         const double x0 = (i == -1) ? ul.y : rhs[i >= 0 ? i : 0];
         const double xp = (i == kM - 1) ? 0.0 : rhs[i + 1];
         const double gval = tau * (cm * xm + c0 * x0 + cp * xp);
         ow[(size_t)t * ldo] = zero_out ? (TOUT)0 : (TOUT)gval;
+      }
+    };
+    TIN tvA[kM + 1], tvB[kM + 1];
+    load_w(tvA, 0);
+    for (int w = 0; w < nw; w += 2) {
+      if (w + 1 < nw) load_w(tvB, w + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      emit_w(tvA, w);
+      __builtin_amdgcn_sched_barrier(0);
+      if (w + 1 < nw) {
+        if (w + 2 < nw) load_w(tvA, w + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        emit_w(tvB, w + 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
