@@ -79,6 +79,7 @@ constexpr int kCtrlLine = 32;
 #endif
 constexpr int kMaxLists = 8 * MLPG_STRIP_PHASES;
 constexpr int kLocal = 2;          // level 3 first looks at the records of strips r-2 .. r+2 only
+constexpr double kRouteTol = 1e-11; // a strip whose own transfer factor 2 max|E^-1 V| exceeds this does not try the window
 constexpr double kDampTol = 1e-22; // ... and accepts that if the window's edges are damped below this at rows r-1, r
 // the records strip r of Ract reads first: rows lo .. hiE; the last one only as the clamped edge (T, h, V) if `edge`
 struct Window { int lo, hiE, edge; };
@@ -798,6 +799,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
     E_s = E;
     g_s = gg;
     STRIP_TICK(4);
+    bool route_full = false;
     if (xwg) {
       // publish the strip's record, then announce it
       double *rp = a.rec + ((size_t)g * R + r) * (kRec * 64) + lane;
@@ -828,13 +830,25 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(flags + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // wait for the strips of the local window only: lane l polls the flag of strip wlo + l
+      // Route, from this strip's own data alone (so that the choice -- and with it every bit of the result -- never
+      // depends on timing): its own transfer factor 2 max|E^-1 V| is one of the ~2 factors of the window's damping
+      // bound; if it is not below sqrt(kDampTol) the window would be rejected (variances whose dynamic features are
+      // much tighter than the static ones couple strips over hundreds of frames) and the strip waits for the whole
+      // utterance right away.
+      {
+        bool badr = false;
+        const double t_own = 2.0 * amax4(mul_sm(sym_inv(E, badr), V));
+        route_full = __ballot(lane_ok && !(t_own <= kRouteTol)) != 0ull;
+        if (lane == 0) lds_misc[3] = route_full;
+      }
+      // wait for the strips of the local window only (lane l polls the flag of strip wlo + l), or for the whole utterance
       {
         const Window w = local_window(r, Ract);
         int spins = 0, ok = 1;
         for (;;) {
           int f = 1;
-          if (lane <= w.hiE - w.lo) f = __hip_atomic_load(flags + w.lo + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (route_full) f = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= Ract;
+          else if (lane <= w.hiE - w.lo) f = __hip_atomic_load(flags + w.lo + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (__ballot(f == 0) == 0ull) break;
           __builtin_amdgcn_s_sleep(16);
           if (++spins > kSpinLimit) { ok = 0; break; }
@@ -957,11 +971,14 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         damp = dt > db ? dt : db;
       };
       const Window w = local_window(r, Ract);
+      const bool full_range = w.lo == 0 && !w.edge;
+      if (route_full) {
+        sweep(0, Ract - 1, 0);
+      } else {
       sweep(w.lo, w.hiE, w.edge);
       // accept the windowed result only if every system of the strip is damped far below the rounding level and
       // met no failing pivot (those are re-examined on the whole utterance, so that the verdict never depends on
       // the window)
-      const bool full_range = w.lo == 0 && !w.edge;
       const bool lane_fine = !lane_ok || full_range || (damp < kDampTol && sig.x == sig.x);
       const int accept = timed_out || __ballot(!lane_fine) == 0ull;
       if (lane == 0) lds_misc[2] = accept;
@@ -980,6 +997,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       if (!accept) {
         timed_out = !__builtin_amdgcn_readfirstlane(lds_misc[1]);
         sweep(0, Ract - 1, 0);
+      }
       }
     } else {
       bool bad3 = false;
@@ -1054,12 +1072,17 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         }
       };
       const Window w = local_window(r, Ract);
-      stage(w.lo, w.hiE);
-      __syncthreads();  // (S2b) wavefront 0's decision: is the window enough?
-      if (!__builtin_amdgcn_readfirstlane(lds_misc[2])) {
-        timed_out = !__builtin_amdgcn_readfirstlane(lds_misc[1]);
-        skip_own = false;  // the full sweep stages every row from HBM (several batches reuse the slots)
+      if (__builtin_amdgcn_readfirstlane(lds_misc[3])) {  // wavefront 0's route: straight to the full sweep
+        skip_own = false;
         stage(0, Ract - 1);
+      } else {
+        stage(w.lo, w.hiE);
+        __syncthreads();  // (S2b) wavefront 0's decision: is the window enough?
+        if (!__builtin_amdgcn_readfirstlane(lds_misc[2])) {
+          timed_out = !__builtin_amdgcn_readfirstlane(lds_misc[1]);
+          skip_own = false;  // the full sweep stages every row from HBM (several batches reuse the slots)
+          stage(0, Ract - 1);
+        }
       }
     }
   }

@@ -284,3 +284,38 @@ def test_strip_two_streams_concurrently():
     torch.cuda.synchronize()
     for k in range(2):
         assert torch.equal(outs[k], ref[k])
+
+
+def test_strip_tight_dynamic_variances_every_window_rejected():
+    """Variances as acoustic models have them (delta / delta-delta 100 x / 1000 x tighter than static): the coupling
+    between strips decays by only ~1e-2 per strip, a 5-strip window would be rejected by the damping bound, and the
+    strips route themselves to the full-utterance sweep from their own transfer factor.  Same numbers as the
+    generic kernel and the oracle; mixed in one batch with an utterance of ordinary variances; bitwise repeatable."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(77)
+    B, T, sd = 6, 1100, 60
+    m = rng.randn(B, T, 3 * sd)
+    v = rng.rand(B, T, 3 * sd) + 0.1
+    v[:5, :, sd:2 * sd] *= 1e-2
+    v[:5, :, 2 * sd:] *= 1e-3
+    lengths = np.array([T, T - 3, 700, T, 65, T], dtype=np.int32)
+    mg, vg, L = torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(lengths).cuda()
+    out, status = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_STRIP)
+    gen, _ = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_GENERIC)
+    assert int(status.abs().max().item()) == 0
+    out, gen = out.cpu().numpy(), gen.cpu().numpy()
+    # oracle on a subset of the systems (3 of the 60 dims)
+    cols = [0, 31, 59]
+    sel = [c + w * sd for w in range(3) for c in cols]
+    ref, _, rc = O.mlpg_batch(m[:, :, sel], v[:, :, sel], STD3, lengths)
+    assert rc == 0
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    e_gen = (np.abs(gen[:, :, cols] - ref) / scale).max()
+    e_ref = (np.abs(out[:, :, cols] - ref) / scale).max()
+    print("tight dynamic variances: strip vs oracle", e_ref, "generic vs oracle", e_gen)
+    assert e_ref <= max(1e-9, 10 * e_gen)
+    assert (np.abs(out - gen) / (np.abs(gen).max(axis=1, keepdims=True) + 1e-300)).max() <= 1e-8
+    a, _ = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_STRIP)
+    assert np.array_equal(a.cpu().numpy(), out)       # the route depends on the data only

@@ -85,6 +85,16 @@ def main():
             ms = gpu_time(lambda: _hip.backward(v, go, WINDOWS, 3 * sd, out_dtype=torch.float64, algo=algo, want_status=False))
             byb = 8.0 * 7 * sd * B * T
             emit(path="c2k-backward-f64-" + name, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=byb, GBps=byb / ms / 1e6)
+        # The same shape with variances as TTS acoustic models have them: the dynamic features 100 x / 1000 x tighter
+        # than the static ones.  The trajectory is then smooth over hundreds of frames, the strip kernel's 5-strip
+        # level-3 window is rejected by its damping bound and every strip sweeps the whole utterance.
+        vt = v.clone()
+        vt[:, :, sd:2 * sd] *= 1e-2
+        vt[:, :, 2 * sd:] *= 1e-3
+        for name, algo in (("wave", 2), ("strip", 3)):
+            ms = gpu_time(lambda: _hip.forward(m, vt, WINDOWS, algo=algo, want_status=False), steps=20)
+            emit(path="c2t-forward-tight-dynamic-variances-" + name, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
+        del vt
         # delta_features (the step before MLPG): read sd, write 3 sd per frame
         x = torch.randn(B, T, sd, dtype=torch.float64, device=dev, generator=gen)
         ms = gpu_time(lambda: _hip.delta_features(x, WINDOWS))
