@@ -30,8 +30,7 @@ bool strip_supported(const Problem &p, const WinSet &ws) {
 // utterance in one workgroup.  The strip kernel wins when its lanes are filled (dims per 64-lane group >= 48: 60, 64,
 // 128 static dims; not 25 or 80 = 2 x 40) and the launch has enough 64-frame strips to occupy the persistent grid
 // (>= 512: two per CU); with per-frame variances that is 0.233 vs 0.285 ms forward (float32: 0.168 vs 0.239 ms)
-// on the config-2 shape, 0.032 vs 0.075 ms at 256 x 100 frames.  Lighter traffic (global / unit variances) ties
-// at T <= 1024 and stays with the wave kernel.  Beyond 1024 frames the wave kernel needs 32 frames per lane
+// on the config-2 shape, 0.032 vs 0.075 ms at 256 x 100 frames.  Beyond 1024 frames the wave kernel needs 32 frames per lane
 // (register spills, one workgroup per CU) or does not apply at all (T > 2048), and the strip kernel takes over
 // for every stream of >= 16 dims.
 bool strip_preferred(const Problem &p, const WinSet &ws, bool backward, int in_dtype) {
@@ -39,7 +38,11 @@ bool strip_preferred(const Problem &p, const WinSet &ws, bool backward, int in_d
   if (p.sd >= 16 && p.Tmax > 1024) return true;
   const int ndg = (p.sd + 63) / 64, dgw = (p.sd + ndg - 1) / ndg;
   const long nitems = (long)p.B * ndg * ((p.Tmax + kStripFrames - 1) / kStripFrames);
-  if (p.var_mode != MLPG_HIP_VAR_FRAME || dgw < 48) return false;
+  if (dgw < 48) return false;
+  // global (D,) variances, forward: 0.172 (strip) vs 0.196 ms (wave) in float64, 0.136 vs 0.141 ms in float32; unit
+  // variances tie (0.182 vs 0.180 ms; that instantiation still assembles window by window) and stay with the wave kernel
+  if (p.var_mode == MLPG_HIP_VAR_GLOBAL) return !backward && nitems >= 512;
+  if (p.var_mode != MLPG_HIP_VAR_FRAME) return false;
   // backward (config-2 shape): 0.296 (strip) vs 0.397 ms (wave) in float64, 0.273 vs 0.314 ms in float32; 64 x 500:
   // 0.044 vs 0.053 ms -- the same rule both ways
   (void)backward;
