@@ -39,9 +39,10 @@ bool strip_preferred(const Problem &p, const WinSet &ws, bool backward, int in_d
   const int ndg = (p.sd + 63) / 64, dgw = (p.sd + ndg - 1) / ndg;
   const long nitems = (long)p.B * ndg * ((p.Tmax + kStripFrames - 1) / kStripFrames);
   if (dgw < 48) return false;
-  // global (D,) variances, forward: 0.172 (strip) vs 0.196 ms (wave) in float64, 0.136 vs 0.141 ms in float32; unit
-  // variances tie (0.182 vs 0.180 ms; that instantiation still assembles window by window) and stay with the wave kernel
-  if (p.var_mode == MLPG_HIP_VAR_GLOBAL) return !backward && nitems >= 512;
+  // global (D,) variances: 0.172 ms (strip) vs 0.196 ms (wave) when the windows hold, but 0.213 ms when some static
+  // dim's delta variance is several times tighter than its static one (then every strip of the group sweeps the
+  // whole utterance) -- the usual case for variances taken from data statistics; unit variances tie (0.169 vs 0.177 ms
+  // float64, 0.137 vs 0.128 ms float32).  Both stay with the wave kernel.
   if (p.var_mode != MLPG_HIP_VAR_FRAME) return false;
   // backward (config-2 shape): 0.296 (strip) vs 0.397 ms (wave) in float64, 0.273 vs 0.314 ms in float32; 64 x 500:
   // 0.044 vs 0.053 ms -- the same rule both ways

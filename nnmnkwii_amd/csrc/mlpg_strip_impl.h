@@ -101,6 +101,7 @@ struct Args {
   int R;         // strips per system group (from Tmax)
   int ndg, dgw;  // dim groups per utterance, dims per group (<= 64)
   int nsg;       // system groups: B * ndg
+  double one;                 // 1.0, from the host: the unit-variance precision as a run-time value (see assemble_eliminate)
   double wc[kMaxWindows][9];  // per window: W[t,t-1], W[t,t], W[t,t+1] and their six products (host-computed, so
                               // that the kernel holds them in scalar registers)
   int nlists;    // work lists: 8 (system group g belongs to list g % 8, drawn first by the workgroups that run on
@@ -431,7 +432,7 @@ template <typename TIN, bool BWD, int VM, bool EDGE, int NW>
 __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, __amdgpu_buffer_rsrc_t vrs,
                                                    __amdgpu_buffer_rsrc_t grs, const TIN *__restrict__ vglob,
                                                    unsigned loff, long ldi, long ldg, int sd, int f0, int T, int mw,
-                                                   const double (*wc)[9], double (&Pd)[kM], double (&P1)[kM],
+                                                   const double (*wc)[9], const double one, double (&Pd)[kM], double (&P1)[kM],
                                                    double (&P2)[kM], double (&rhs)[kM], double &ca, double &cb,
                                                    double &cc, double (&rec)[kRec]) {
   // No zero-fill: every accumulator is ASSIGNED by the first contribution that reaches it (window 0 of the frame
@@ -447,6 +448,13 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
     cl[w] = lo[w] < T ? lo[w] : T - 1;            // a window without live frames still loads (frame cl) and weighs 0
     ch[w] = hi[w] > cl[w] ? hi[w] : cl[w] + 1;
     k[w] = win_coef<TIN, VM>(wc, w, vglob, sd);
+    // unit variances: the precision 1.0 as an opaque per-lane run-time value.  As a literal (or any wave-uniform value)
+    // the whole matrix becomes uniform arithmetic that the compiler hoists above the stream and spills (544-880 B/lane).
+    if (VM == MLPG_HIP_VAR_UNIT) {
+      double t1 = one;
+      asm volatile("" : "+v"(t1));  // a per-lane value as far as the compiler can tell
+      k[w].tau_glob = t1;
+    }
   }
   TIN rv[kRing][NW], rm[kRing][NW];
   auto load_frame = [&](TIN (&v)[NW], TIN (&m)[NW], const int i) __attribute__((always_inline)) {
@@ -704,10 +712,10 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
   bool bad = false;
   if (f0 < T) {
     const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < T - mw;
-    if (MLPG_STRIP_STREAM && nw == 3 && VM != MLPG_HIP_VAR_UNIT && MLPG_STRIP_ABLATE < 2) {
+    if (MLPG_STRIP_STREAM && nw == 3 && MLPG_STRIP_ABLATE < 2) {
       // the usual three windows: assembly and elimination streamed in frame order
-      if (interior) bad = assemble_eliminate<TIN, BWD, VM, false, 3>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, Pd, P1, P2, rhs, ca, cb, cc, rec);
-      else bad = assemble_eliminate<TIN, BWD, VM, true, 3>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, Pd, P1, P2, rhs, ca, cb, cc, rec);
+      if (interior) bad = assemble_eliminate<TIN, BWD, VM, false, 3>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
+      else bad = assemble_eliminate<TIN, BWD, VM, true, 3>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
       STRIP_TICK(1);
 #ifdef MLPG_STRIP_TRACE
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1296,6 +1304,7 @@ int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_b
   a.ndg = ndg;
   a.dgw = dgw;
   a.nsg = nsg;
+  a.one = 1.0;
   for (int w = 0; w < ws.nw; ++w) {
     const int l = ws.l[w], u = ws.u[w];
     const double *cw = ws.c + ws.off[w];
