@@ -12,25 +12,32 @@
 // The solve is a three-level substructured LDL^T (tools/strip_model.py is the executable
 // specification, pinned against the oracle by tests/test_strip_model.py):
 //   level 1 (wavefront, registers): assemble the chunk's rows of P = sum_w W_w^T diag(tau_w) W_w
-//     and b from the frames f0-1 .. f0+16, eliminate the 14 interior frames carrying the two
-//     "left spike" columns that couple the chunk to the previous chunk's last two frames (its
-//     separator), run the elimination on into the chunk's own separator -> 14 numbers per lane;
+//     and b from the frames f0-1 .. f0+16 -- streamed in frame order with a ring of 6 frames of loads
+//     in flight (assemble_eliminate; window-major assemble + eliminate for window sets other than
+//     three windows) -- and eliminate the 14 interior frames as their rows complete, carrying the
+//     two "left spike" columns that couple the chunk to the previous chunk's last two frames (its
+//     separator); the elimination runs on into the chunk's own separator -> 14 numbers per lane;
 //   level 2 (workgroup, LDS): the block-tridiagonal system (2x2 blocks) of the strip's W
 //     separators is eliminated sequentially, lanes = dims in lockstep, carrying the spike block
 //     that couples the strip to the previous strip's last separator -> one 14-number record;
 //   level 3 (utterance, HBM): the strips publish their records (agent-scope write-through
-//     stores + arrival counter), every strip gathers all records of its utterance and runs the
-//     same forward sweep over them; the solution on its own two separators comes out of the sweep
-//     as an affine function of the last separator's, so no factor of the sweep is stored;
+//     stores, a flag per strip, an arrival counter per utterance).  A strip first solves over the
+//     records of strips r-2 .. r+2 only, with a rigorous bound on what the strips outside that
+//     window could contribute; where the bound is not far below rounding (or the strip's own
+//     transfer factor says so beforehand) it waits for the whole utterance and sweeps all records.
+//     Either way a two-sided block sweep (top-down, bottom-up, 2-block system in the middle) over
+//     records staged through LDS by wavefronts 1-3; no factor of the sweep is stored;
 //   back-substitution in the reverse order; trajectory rows stored straight from registers.
 // Edge rules (frames >= T, zeroed dynamic precisions on the first/last mw frames) are
-// wave-uniform in this mapping: interior chunks run a branch- and select-free path.
+// wave-uniform in this mapping: clamped load rows and 0/1 factors, no branches.
 //
-// Inter-workgroup protocol (cdna_hip_programming.md G16, placement independent): work items are
-// handed out by an atomic ticket in (utterance, strip) order, so the strips a workgroup waits for
-// are always held by running workgroups (dispatch order is not assumed); record words are stored
-// and loaded with agent scope (sc1), the arrival counter is one relaxed agent-scope atomic per
-// strip, polled by one lane; the control words are zeroed by a memset node ahead of every launch.
+// Inter-workgroup protocol (cdna_hip_programming.md G16, placement independent): a persistent
+// grid of resident workgroups draws (dim group, strip) items from per-XCD atomic ticket lists in
+// (utterance, strip) order, so the strips a workgroup waits for are always held by running
+// workgroups (dispatch order is not assumed); record words are stored and loaded with agent scope
+// (sc1); flags and counters are relaxed agent-scope atomics polled by one wavefront with bounded
+// spins; the control words are zero at launch (memset, or left so by verdict_kernel).  Systems
+// with a failing pivot are marked per utterance and settled by verdict_kernel behind the main kernel.
 //
 // Reference semantics as in mlpg_wave_impl.h (paramgen/_mlpg.py:92-199, :202-281).
 #pragma once
