@@ -78,6 +78,9 @@ enum { rT00, rT01, rT11, rH0, rH1, rD11, rD12, rD22, rF1, rF2, rL11, rL12, rL21,
 //   words 2-3 mask of the lanes (systems) that met a failing pivot, word 4 time-out seen;
 //   then one flag per strip, Rpad = R rounded up to a line per system group: flag[g * Rpad + r].
 constexpr int kCtrlLine = 32;
+#ifndef MLPG_STRIP_POLL_SLEEP
+#define MLPG_STRIP_POLL_SLEEP 16  // x 64 cycles between two looks at the neighbours' flags (4 .. 64 measured: no difference)
+#endif
 #ifndef MLPG_STRIP_STREAM
 #define MLPG_STRIP_STREAM 1  // 0: window-major assembly, then elimination, also for three windows (A/B measurements)
 #endif
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
           if (route_full) f = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= Ract;
           else if (lane <= w.hiE - w.lo) f = __hip_atomic_load(flags + w.lo + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (__ballot(f == 0) == 0ull) break;
-          __builtin_amdgcn_s_sleep(16);
+          __builtin_amdgcn_s_sleep(MLPG_STRIP_POLL_SLEEP);
           if (++spins > kSpinLimit) { ok = 0; break; }
         }
         if (lane == 0) {
