@@ -100,6 +100,27 @@ __device__ __forceinline__ Window local_window(int r, int Ract) {
   w.hiE = w.edge ? r + kLocal : Ract - 1;
   return w;
 }
+// Staged order of the records of rows lo .. hiE around strip r: pairs (top row, bottom row) moving inwards from both
+// ends while both sides have rows -- the two eliminations are independent chains, a pair is handled in one
+// straight-line block so that their latencies overlap -- then the rest of the longer side, row r last.
+struct Order { int lo, hiE, r, nt, nb, m, npos; };
+__device__ __forceinline__ Order make_order(int r, int lo, int hiE) {
+  Order o;
+  o.lo = lo; o.hiE = hiE; o.r = r;
+  o.nt = r - lo;    // top rows lo .. r-1
+  o.nb = hiE - r;   // bottom rows hiE .. r+1
+  o.m = o.nt < o.nb ? o.nt : o.nb;
+  o.npos = o.nt + o.nb + 1;
+  return o;
+}
+__device__ __forceinline__ int row_of(const Order &o, int pos) {
+  if (pos < 2 * o.m) return (pos & 1) ? o.hiE - (pos >> 1) : o.lo + (pos >> 1);
+  if (pos < o.nt + o.nb) {
+    const int k = o.m + (pos - 2 * o.m);
+    return o.nt > o.nb ? o.lo + k : o.hiE - k;
+  }
+  return o.r;
+}
 __host__ __device__ inline int flag_pitch(int R) { return (R + kCtrlLine - 1) / kCtrlLine * kCtrlLine; }
 __host__ __device__ inline size_t ctrl_ints(int nsg, int R) {
   return (size_t)(1 + kMaxLists + nsg) * kCtrlLine + (size_t)nsg * flag_pitch(R);
@@ -827,17 +848,13 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       st_agent(rp + 9 * 64, Ts.a); st_agent(rp + 10 * 64, Ts.b); st_agent(rp + 11 * 64, Ts.c);
       st_agent(rp + 12 * 64, hs.x); st_agent(rp + 13 * 64, hs.y);
       {
-        // the windowed sweep takes this strip's own record from here (its two places in the staged order), not
-        // from HBM: a third less record traffic.  (lds_rec, the same bytes, has been consumed by level 2.)
+        // the windowed sweep takes this strip's own record from here (the last place of the staged order), not
+        // from HBM.  (lds_rec, the same bytes, has been consumed by level 2.)
         const Window w = local_window(r, Ract);
-        const int ntop = r > w.lo ? r - w.lo + 1 : 0;
+        const Order o = make_order(r, w.lo, w.hiE);
         const double own[kRec] = {E.a, E.b, E.c, gg.x, gg.y, V.a, V.b, V.c, V.d, Ts.a, Ts.b, Ts.c, hs.x, hs.y};
-        const int q_bot = ntop + (w.hiE - r);
 #pragma unroll
-        for (int k = 0; k < kRec; ++k) {
-          lds_stage[(q_bot * kRec + k) * 64 + lane] = own[k];
-          if (ntop) lds_stage[((ntop - 1) * kRec + k) * 64 + lane] = own[k];
-        }
+        for (int k = 0; k < kRec; ++k) lds_stage[((o.npos - 1) * kRec + k) * 64 + lane] = own[k];
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       STRIP_TICK(5);
@@ -890,8 +907,9 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       // Two sweeps over the records of rows lo .. hiE, no factor stored: top-down over rows lo .. r-1 (row j is
       // finalised when row j+1 is at hand: A_j = E_j - T_{j+1} - Mn_j V_j^T with Mn_j = V_j A_{j-1}^-1, a_j likewise),
       // bottom-up over rows hiE .. r+1 (the Schur complement (S, s) of the rows below row j: B_j = E_j - T_{j+1} - S,
-      // S' = V_j^T B_j^-1 V_j), and the 2-block system of rows r-1 and r in the middle.  The records are staged in
-      // exactly that order: rows lo .. r, then rows hiE .. r (row r twice; nothing of the first part if r = lo).
+      // S' = V_j^T B_j^-1 V_j), and the 2-block system of rows r-1 and r in the middle.  The two eliminations are
+      // independent chains: the records are staged as (top row, bottom row) pairs moving inwards (Order), a pair is
+      // one straight-line block, row r comes last.
       // With lo = 0, hiE = Ract-1 this is the exact solve.  A narrower window clamps the separators just outside it
       // to zero: separator lo-1 (record lo holds strip lo's interior and its coupling V_lo to that separator) and,
       // with `edge`, separator hiE (record hiE is read for T, h -- that strip's interior -- and its coupling V only).
@@ -906,7 +924,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       // whole utterance.  tools/strip_model.py: utterance_solve_two_sided.
       double damp = 0.0;
       auto sweep = [&](const int lo, const int hiE, const int edge) __attribute__((always_inline)) {
-        const int ntop = r > lo ? r - lo + 1 : 0, npos = ntop + (hiE - r + 1);
+        const Order o = make_order(r, lo, hiE);
         S2 Ainv = {0.0, 0.0, 0.0};
         V2 av = {0.0, 0.0};
         M2 Mn = {0.0, 0.0, 0.0, 0.0};
@@ -919,66 +937,92 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         S2 Ej = {0.0, 0.0, 0.0};
         V2 gj = {0.0, 0.0};
         M2 Vj = {0.0, 0.0, 0.0, 0.0};
-        for (int p0 = 0; p0 < npos; p0 += kStage) {
-          const int kn = npos - p0 < kStage ? npos - p0 : kStage;
+        struct Rec { S2 E; V2 g; M2 V; S2 T; V2 h; };
+        auto rd = [&](const int q) __attribute__((always_inline)) {
+          double c[kRec];
+#pragma unroll
+          for (int kk = 0; kk < kRec; ++kk) c[kk] = lds_stage[(q * kRec + kk) * 64 + lane];
+          return Rec{{c[0], c[1], c[2]}, {c[3], c[4]}, {c[5], c[6], c[7], c[8]}, {c[9], c[10], c[11]}, {c[12], c[13]}};
+        };
+        // top-down: the next row has arrived; the pending one is finalised (Mn = 0 for the window's first row)
+        auto top_finalize = [&](const Rec &k) __attribute__((always_inline)) {
+          const S2 A = sub(sub(Ej, k.T), mul_mmt_sym(Mn, Vj));
+          const V2 aa = sub(sub(gj, k.h), mul_mv(Mn, av));
+          Ainv = sym_inv(A, bad3);
+          av = aa;
+          Mn = mul_ms(k.V, Ainv);  // V_{j+1} A_j^-1
+          dt *= 2.0 * amax4(mul_sm(Ainv, Vj));
+        };
+        auto top_pend = [&](const Rec &k) __attribute__((always_inline)) { Ej = k.E; gj = k.g; Vj = k.V; };
+        // bottom-up: row j > r; the clamped edge below a window contributes its strip's interior and its coupling only
+        auto bot_edge = [&](const Rec &k) __attribute__((always_inline)) { Tn = k.T; hn = k.h; Vn = k.V; };
+        auto bot_row = [&](const Rec &k) __attribute__((always_inline)) {
+          const S2 B = sub(sub(k.E, Tn), Sb);
+          const V2 bv = sub(sub(k.g, hn), sb);
+          const S2 Binv = sym_inv(B, bad3);
+          db *= 2.0 * amax4(mul_smt(Binv, Vn));
+          const M2 Wm = mul_sm(Binv, k.V);
+          Sb = mul_mtm_sym(k.V, Wm);
+          sb = mul_mtv(k.V, mul_sv(Binv, bv));
+          Tn = k.T; hn = k.h; Vn = k.V;
+        };
+        for (int p0 = 0; p0 < o.npos; p0 += kStage) {
+          const int kn = o.npos - p0 < kStage ? o.npos - p0 : kStage;
           __syncthreads();  // this batch is in LDS
           STRIP_TICK(8);
           if (!timed_out) {
 #ifndef MLPG_L3_NOPRIO
             __builtin_amdgcn_s_setprio(2);  // the whole workgroup waits for this chain
 #endif
-            for (int q = 0; q < kn; ++q) {
+            int q = 0;
+            while (q < kn) {
               const int pos = p0 + q;
-              double cur[kRec];
-#pragma unroll
-              for (int kk = 0; kk < kRec; ++kk) cur[kk] = lds_stage[(q * kRec + kk) * 64 + lane];
-              const S2 Ek = {cur[0], cur[1], cur[2]};
-              const V2 gk = {cur[3], cur[4]};
-              const M2 Vk = {cur[5], cur[6], cur[7], cur[8]};
-              const S2 Tk = {cur[9], cur[10], cur[11]};
-              const V2 hk = {cur[12], cur[13]};
-              if (pos < ntop) {
-                // top-down: row lo + pos has arrived; the row before it is finalised
-                if (pos > 0) {
-                  const S2 A = sub(sub(Ej, Tk), mul_mmt_sym(Mn, Vj));  // Mn = 0 for the window's first row
-                  const V2 aa = sub(sub(gj, hk), mul_mv(Mn, av));
-                  Ainv = sym_inv(A, bad3);
-                  av = aa;
-                  Mn = mul_ms(Vk, Ainv);  // V_{j+1} A_j^-1
-                  dt *= 2.0 * amax4(mul_sm(Ainv, Vj));
-                }
-                Ej = Ek; gj = gk; Vj = Vk;
-              } else if (edge && pos == ntop) {
-                // the clamped edge below the window: only its strip's interior and its coupling count
-                Tn = Tk; hn = hk; Vn = Vk;
-              } else {
-                S2 B = sub(sub(Ek, Tn), Sb);
-                V2 bv = sub(sub(gk, hn), sb);
-                if (pos + 1 < npos) {
-                  // bottom-up: row j > r
-                  const S2 Binv = sym_inv(B, bad3);
-                  db *= 2.0 * amax4(mul_smt(Binv, Vn));
-                  const M2 Wm = mul_sm(Binv, Vk);
-                  Sb = mul_mtm_sym(Vk, Wm);
-                  sb = mul_mtv(Vk, mul_sv(Binv, bv));
-                  Tn = Tk; hn = hk; Vn = Vk;
+              if (pos < 2 * o.m) {
+                // a pair: top row lo + idx and bottom row hiE - idx (kStage is even: a pair never straddles batches)
+                const int idx = pos >> 1;
+                const Rec kt = rd(q), kb = rd(q + 1);
+                if (idx == 0) {
+                  top_pend(kt);
+                  if (edge) bot_edge(kb);
+                  else bot_row(kb);
                 } else {
-                  // middle: row r
-                  if (r > lo) {  // Mn = V_r A_{r-1}^-1 from the top-down sweep
-                    B = sub(B, mul_mmt_sym(Mn, Vk));
-                    bv = sub(bv, mul_mv(Mn, av));
-                  }
-                  const S2 Binv = sym_inv(B, bad3);
-                  sig = mul_sv(Binv, bv);
-                  sprev = {0.0, 0.0};
-                  db *= 2.0 * amax4(mul_smt(Binv, Vn));
-                  if (r > lo) {
-                    sprev = sub(mul_sv(Ainv, av), mul_mtv(Mn, sig));  // A^-1 (a - V_r^T sigma_r)
-                    dt *= __builtin_fmax(1.0, 2.0 * amax4(mul_sm(Binv, Vk)));
-                    db *= __builtin_fmax(1.0, 2.0 * amax4(mul_smt(Ainv, Vk)));
-                  }
-                  if (bad3) sig.x = __builtin_nan("");
+                  top_finalize(kt);  // two independent chains in one block
+                  bot_row(kb);
+                  top_pend(kt);
                 }
+                q += 2;
+              } else if (pos < o.nt + o.nb) {
+                const int idx = o.m + (pos - 2 * o.m);
+                const Rec k = rd(q);
+                if (o.nt > o.nb) {
+                  if (idx > 0) top_finalize(k);
+                  top_pend(k);
+                } else {
+                  if (idx == 0 && edge) bot_edge(k);
+                  else bot_row(k);
+                }
+                q += 1;
+              } else {
+                // row r: the last top row is finalised, then the 2-block system of rows r-1, r
+                const Rec k = rd(q);
+                if (o.nt > 0) top_finalize(k);  // Mn = V_r A_{r-1}^-1
+                S2 B = sub(sub(k.E, Tn), Sb);
+                V2 bv = sub(sub(k.g, hn), sb);
+                if (o.nt > 0) {
+                  B = sub(B, mul_mmt_sym(Mn, k.V));
+                  bv = sub(bv, mul_mv(Mn, av));
+                }
+                const S2 Binv = sym_inv(B, bad3);
+                sig = mul_sv(Binv, bv);
+                sprev = {0.0, 0.0};
+                db *= 2.0 * amax4(mul_smt(Binv, Vn));
+                if (o.nt > 0) {
+                  sprev = sub(mul_sv(Ainv, av), mul_mtv(Mn, sig));  // A^-1 (a - V_r^T sigma_r)
+                  dt *= __builtin_fmax(1.0, 2.0 * amax4(mul_sm(Binv, k.V)));
+                  db *= __builtin_fmax(1.0, 2.0 * amax4(mul_smt(Ainv, k.V)));
+                }
+                if (bad3) sig.x = __builtin_nan("");
+                q += 1;
               }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -1053,16 +1097,16 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       constexpr int kSlots = (kStage + kW - 2) / (kW - 1);  // rows per stager per batch
       double sv[kSlots][kRec];
       bool own_slot[kSlots];
-      // staged record number p of the window [lo, hi]: rows lo .. r, then rows hi .. r (see the sweep)
+      // staged record number p of the window [lo, hi]: row_of(make_order(r, lo, hi), p)
       bool skip_own = true;  // windowed sweep: wavefront 0 has put this strip's own record into its LDS slots
       auto stage_load = [&](int lo, int hi, int p0, int kn) __attribute__((always_inline)) {
-        const int ntop_ = r > lo ? r - lo + 1 : 0;
+        const Order o = make_order(r, lo, hi);
 #pragma unroll
         for (int sl = 0; sl < kSlots; ++sl) {
           const int q = (wv - 1) + sl * (kW - 1);
           const int pos = p0 + q;
-          const int row_ = pos < ntop_ ? lo + pos : hi - (pos - ntop_);
-          own_slot[sl] = skip_own && row_ == r;
+          const int row_ = row_of(o, pos);
+          own_slot[sl] = skip_own && pos == o.npos - 1;
           if (q < kn && !timed_out && !own_slot[sl]) {
             const int row = row_;
             const double *rp = a.rec + ((size_t)g * R + row) * (kRec * 64) + lane;
@@ -1072,7 +1116,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         }
       };
       auto stage = [&](const int lo, const int hi) __attribute__((always_inline)) {
-        const int ntop = r > lo ? r - lo + 1 : 0, npos = ntop + (hi - r + 1);
+        const int npos = hi - lo + 1;
         stage_load(lo, hi, 0, npos < kStage ? npos : kStage);
         for (int p0 = 0; p0 < npos; p0 += kStage) {
           const int kn = npos - p0 < kStage ? npos - p0 : kStage;
