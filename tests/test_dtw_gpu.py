@@ -155,3 +155,38 @@ def test_trim_zeros_frames():
         x[60] = 1e-9   # below eps -> still "zero" but interior
         assert trim_zeros_frames(x).shape == (70, 10)
     assert trim_zeros_frames(np.zeros((8, 3))).shape == (0, 3)
+
+
+def test_against_the_real_fastdtw_package_when_installed():
+    """The DTW oracle restates slaypni/fastdtw from its published algorithm (parity unpinned: the package is not in
+    this image).  Wherever it IS installed this test pins oracle and kernel against it: random, tie-heavy
+    (quantised) and constant inputs, radius 1 and 2, the aligner's default distance."""
+    fastdtw_mod = pytest.importorskip("fastdtw")
+    import torch
+    from numpy.linalg import norm
+    from nnmnkwii_amd import _hip
+    from oracle import dtw as OD
+    rng = np.random.RandomState(12)
+    cases = []
+    for k in range(6):
+        a, b = rng.randint(20, 120, size=2)
+        x, y = np.cumsum(rng.randn(a, 5), 0), np.cumsum(rng.randn(b, 5), 0)
+        if k % 3 == 1:
+            x, y = np.round(x), np.round(y)                  # ties
+        if k % 3 == 2:
+            x[:] = 1.0
+            y[:] = 1.0                                       # every path costs the same
+        cases.append((x, y))
+    for radius in (1, 2):
+        for x, y in cases:
+            d_ref, p_ref = fastdtw_mod.fastdtw(x, y, radius=radius, dist=lambda u, v: norm(u - v))
+            d_o, p_o = OD.fastdtw(x, y, radius)
+            assert [tuple(p) for p in p_ref] == [tuple(p) for p in p_o]
+            assert abs(d_ref - d_o) <= 1e-12 * max(1.0, abs(d_ref))
+            X = torch.from_numpy(x[None].copy()).cuda()
+            Y = torch.from_numpy(y[None].copy()).cuda()
+            lx = torch.tensor([len(x)], dtype=torch.int32, device="cuda")
+            ly = torch.tensor([len(y)], dtype=torch.int32, device="cuda")
+            pi, pj, pl, cost = _hip.fastdtw_l2(X, Y, lx, ly, radius)
+            n = int(pl[0])
+            assert list(zip(pi[0, :n].tolist(), pj[0, :n].tolist())) == [tuple(p) for p in p_ref]
