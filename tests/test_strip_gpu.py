@@ -319,3 +319,38 @@ def test_strip_tight_dynamic_variances_every_window_rejected():
     assert (np.abs(out - gen) / (np.abs(gen).max(axis=1, keepdims=True) + 1e-300)).max() <= 1e-8
     a, _ = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_STRIP)
     assert np.array_equal(a.cpu().numpy(), out)       # the route depends on the data only
+
+
+def test_strip_kernel_inside_a_hip_graph():
+    """The strip launch (control-word memset, main kernel, verdict kernel) captured into a HIP graph and replayed on
+    new data, interleaved with eager launches of another shape on the same scratch: every replay must start from
+    zeroed control words (the memset is always part of a captured launch)."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    B, T, sd = 8, 700, 60
+    m = torch.randn(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=gen)
+    v = torch.rand(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=gen) + 0.1
+    pw = _hip.prepack_windows(STD3)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        _hip.forward(m, v, pw, algo=_hip.ALGO_STRIP)                 # warm the scratch of this stream
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            y, st = _hip.forward(m, v, pw, algo=_hip.ALGO_STRIP)
+        for k in range(3):
+            m.copy_(torch.randn(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=gen))
+            if k == 1:
+                v[2, 300, 7] = -1e-3                                  # a failing system in this replay only
+            ref, sref = _hip.forward(m, v, pw, algo=_hip.ALGO_GENERIC)
+            # an eager strip launch of another shape in between (same stream, same scratch, larger control area)
+            _hip.forward(m[:, :100].contiguous().repeat(3, 1, 1), v[:, :100].contiguous().repeat(3, 1, 1), pw, algo=_hip.ALGO_STRIP)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(st, sref)
+            assert float((y - ref).abs().max()) <= 1e-9 * float(ref.abs().max())
+            if k == 1:
+                assert int(st.reshape(B, sd)[2, 7]) == 301 and not y[2, :, 7].any()
+                v[2, 300, 7] = 0.5
