@@ -89,15 +89,18 @@ constexpr int kCtrlLine = 32;
 #endif
 constexpr int kMaxLists = 8 * MLPG_STRIP_PHASES;
 constexpr int kLocal = 2;          // level 3 first looks at the records of strips r-2 .. r+2 only
-constexpr double kRouteTol = 1e-11; // a strip whose own transfer factor 2 max|E^-1 V| exceeds this does not try the window
+constexpr int kLocalWide = 4;      // ... or r-4 .. r+4 when the strip's own transfer factor calls for it (see the route)
+constexpr double kRouteTol = 1e-11; // a strip whose own transfer factor 2 max|E^-1 V| exceeds this (= kDampTol^(1/2)) does not
+                                    // try the 5-strip window
+constexpr double kRouteTolWide = 3e-6;  // ... and beyond this (~ kDampTol^(1/4)) not the 9-strip window either
 constexpr double kDampTol = 1e-22; // ... and accepts that if the window's edges are damped below this at rows r-1, r
 // the records strip r of Ract reads first: rows lo .. hiE; the last one only as the clamped edge (T, h, V) if `edge`
 struct Window { int lo, hiE, edge; };
-__device__ __forceinline__ Window local_window(int r, int Ract) {
+__device__ __forceinline__ Window local_window(int r, int Ract, int k) {
   Window w;
-  w.lo = r - kLocal < 0 ? 0 : r - kLocal;
-  w.edge = r + kLocal < Ract - 1;
-  w.hiE = w.edge ? r + kLocal : Ract - 1;
+  w.lo = r - k < 0 ? 0 : r - k;
+  w.edge = r + k < Ract - 1;
+  w.hiE = w.edge ? r + k : Ract - 1;
   return w;
 }
 // Staged order of the records of rows lo .. hiE around strip r: pairs (top row, bottom row) moving inwards from both
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
     E_s = E;
     g_s = gg;
     STRIP_TICK(4);
-    bool route_full = false;
+    int route = 0;  // 0: 5-strip window, 2: 9-strip window, 1: the whole utterance
     if (xwg) {
       // publish the strip's record, then announce it
       double *rp = a.rec + ((size_t)g * R + r) * (kRec * 64) + lane;
@@ -847,10 +850,25 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       st_agent(rp + 5 * 64, V.a); st_agent(rp + 6 * 64, V.b); st_agent(rp + 7 * 64, V.c); st_agent(rp + 8 * 64, V.d);
       st_agent(rp + 9 * 64, Ts.a); st_agent(rp + 10 * 64, Ts.b); st_agent(rp + 11 * 64, Ts.c);
       st_agent(rp + 12 * 64, hs.x); st_agent(rp + 13 * 64, hs.y);
+      // Route, from this strip's own data alone (so that the choice -- and with it every bit of the result -- never
+      // depends on timing): its own transfer factor t = 2 max|E^-1 V| is one of the factors of the window's damping
+      // bound (2 per side in the 5-strip window, 4 in the 9-strip one).  t <= kDampTol^(1/2): the narrow window;
+      // t <= kDampTol^(1/4): the wide one; beyond that any window would be rejected (variances whose dynamic features
+      // are much tighter than the static ones couple strips over hundreds of frames) and the strip waits for the
+      // whole utterance right away.  The bound still decides whether a window's result is accepted.
       {
-        // the windowed sweep takes this strip's own record from here (the last place of the staged order), not
-        // from HBM.  (lds_rec, the same bytes, has been consumed by level 2.)
-        const Window w = local_window(r, Ract);
+        bool badr = false;
+        const double t_own = 2.0 * amax4(mul_sm(sym_inv(E, badr), V));
+        const bool over = __ballot(lane_ok && !(t_own <= kRouteTol)) != 0ull;
+        const bool over_wide = __ballot(lane_ok && !(t_own <= kRouteTolWide)) != 0ull;
+        route = over_wide ? 1 : (over ? 2 : 0);
+        if (lane == 0) lds_misc[3] = route;
+      }
+      const int kwin = route == 2 ? kLocalWide : kLocal;
+      if (route == 0) {
+        // the narrow window's sweep takes this strip's own record from here (the last place of the staged order),
+        // not from HBM.  (lds_rec, the same bytes, has been consumed by level 2.)
+        const Window w = local_window(r, Ract, kLocal);
         const Order o = make_order(r, w.lo, w.hiE);
         const double own[kRec] = {E.a, E.b, E.c, gg.x, gg.y, V.a, V.b, V.c, V.d, Ts.a, Ts.b, Ts.c, hs.x, hs.y};
 #pragma unroll
@@ -865,24 +883,13 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(flags + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // Route, from this strip's own data alone (so that the choice -- and with it every bit of the result -- never
-      // depends on timing): its own transfer factor 2 max|E^-1 V| is one of the ~2 factors of the window's damping
-      // bound; if it is not below sqrt(kDampTol) the window would be rejected (variances whose dynamic features are
-      // much tighter than the static ones couple strips over hundreds of frames) and the strip waits for the whole
-      // utterance right away.
-      {
-        bool badr = false;
-        const double t_own = 2.0 * amax4(mul_sm(sym_inv(E, badr), V));
-        route_full = __ballot(lane_ok && !(t_own <= kRouteTol)) != 0ull;
-        if (lane == 0) lds_misc[3] = route_full;
-      }
       // wait for the strips of the local window only (lane l polls the flag of strip wlo + l), or for the whole utterance
       {
-        const Window w = local_window(r, Ract);
+        const Window w = local_window(r, Ract, kwin);
         int spins = 0, ok = 1;
         for (;;) {
           int f = 1;
-          if (route_full) f = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= Ract;
+          if (route == 1) f = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= Ract;
           else if (lane <= w.hiE - w.lo) f = __hip_atomic_load(flags + w.lo + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (__ballot(f == 0) == 0ull) break;
           __builtin_amdgcn_s_sleep(MLPG_STRIP_POLL_SLEEP);
@@ -1032,9 +1039,9 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         }
         damp = dt > db ? dt : db;
       };
-      const Window w = local_window(r, Ract);
+      const Window w = local_window(r, Ract, route == 2 ? kLocalWide : kLocal);
       const bool full_range = w.lo == 0 && !w.edge;
-      if (route_full) {
+      if (route == 1) {
         sweep(0, Ract - 1, 0);
       } else {
       sweep(w.lo, w.hiE, w.edge);
@@ -1133,11 +1140,13 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
           __syncthreads();  // wavefront 0 has read this batch
         }
       };
-      const Window w = local_window(r, Ract);
-      if (__builtin_amdgcn_readfirstlane(lds_misc[3])) {  // wavefront 0's route: straight to the full sweep
+      const int route = __builtin_amdgcn_readfirstlane(lds_misc[3]);  // wavefront 0's choice (see there)
+      const Window w = local_window(r, Ract, route == 2 ? kLocalWide : kLocal);
+      if (route == 1) {
         skip_own = false;
         stage(0, Ract - 1);
       } else {
+        skip_own = route == 0;  // only the narrow window has this strip's own record in LDS already
         stage(w.lo, w.hiE);
         __syncthreads();  // (S2b) wavefront 0's decision: is the window enough?
         if (!__builtin_amdgcn_readfirstlane(lds_misc[2])) {

@@ -289,8 +289,9 @@ def test_strip_two_streams_concurrently():
 def test_strip_tight_dynamic_variances_every_window_rejected():
     """Variances as acoustic models have them (delta / delta-delta 100 x / 1000 x tighter than static): the coupling
     between strips decays by only ~1e-2 per strip, a 5-strip window would be rejected by the damping bound, and the
-    strips route themselves to the full-utterance sweep from their own transfer factor.  Same numbers as the
-    generic kernel and the oracle; mixed in one batch with an utterance of ordinary variances; bitwise repeatable."""
+    strips route themselves to the full-utterance sweep from their own transfer factor; with 10 x / 100 x they take
+    the 9-strip window.  Same numbers as the generic kernel and the oracle; mixed in one batch with an utterance of
+    ordinary variances (5-strip window); bitwise repeatable."""
     import torch
     from nnmnkwii_amd import _hip
     STD3 = WINDOW_SETS["std3"]
@@ -298,8 +299,10 @@ def test_strip_tight_dynamic_variances_every_window_rejected():
     B, T, sd = 6, 1100, 60
     m = rng.randn(B, T, 3 * sd)
     v = rng.rand(B, T, 3 * sd) + 0.1
-    v[:5, :, sd:2 * sd] *= 1e-2
-    v[:5, :, 2 * sd:] *= 1e-3
+    v[:3, :, sd:2 * sd] *= 1e-2
+    v[:3, :, 2 * sd:] *= 1e-3
+    v[3:5, :, sd:2 * sd] *= 1e-1          # moderately tight: the 9-strip window (route 2)
+    v[3:5, :, 2 * sd:] *= 1e-2
     lengths = np.array([T, T - 3, 700, T, 65, T], dtype=np.int32)
     mg, vg, L = torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(lengths).cuda()
     out, status = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_STRIP)

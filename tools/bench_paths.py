@@ -94,6 +94,11 @@ def main():
         for name, algo in (("wave", 2), ("strip", 3)):
             ms = gpu_time(lambda: _hip.forward(m, vt, WINDOWS, algo=algo, want_status=False), steps=20)
             emit(path="c2t-forward-tight-dynamic-variances-" + name, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
+        vt = v.clone()                      # moderately tight (10 x / 100 x): the 9-strip window
+        vt[:, :, sd:2 * sd] *= 1e-1
+        vt[:, :, 2 * sd:] *= 1e-2
+        ms = gpu_time(lambda: _hip.forward(m, vt, WINDOWS, algo=3, want_status=False), steps=20)
+        emit(path="c2t-forward-moderately-tight-dynamic-variances-strip", ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
         del vt
         # delta_features (the step before MLPG): read sd, write 3 sd per frame
         x = torch.randn(B, T, sd, dtype=torch.float64, device=dev, generator=gen)
