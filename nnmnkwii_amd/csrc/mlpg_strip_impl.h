@@ -89,10 +89,9 @@ constexpr int kCtrlLine = 32;
 #endif
 constexpr int kMaxLists = 8 * MLPG_STRIP_PHASES;
 constexpr int kLocal = 2;          // level 3 first looks at the records of strips r-2 .. r+2 only
-constexpr int kLocalWide = 4;      // ... or r-4 .. r+4 when the strip's own transfer factor calls for it (see the route)
+                                   // (wider windows -- 4, 8, 16 strips per side -- when the strip's own transfer factor calls for them)
 constexpr double kRouteTol = 1e-11; // a strip whose own transfer factor 2 max|E^-1 V| exceeds this (= kDampTol^(1/2)) does not
-                                    // try the 5-strip window
-constexpr double kRouteTolWide = 3e-6;  // ... and beyond this (~ kDampTol^(1/4)) not the 9-strip window either
+                                    // try the 5-strip window (see the route)
 constexpr double kDampTol = 1e-22; // ... and accepts that if the window's edges are damped below this at rows r-1, r
 // the records strip r of Ract reads first: rows lo .. hiE; the last one only as the clamped edge (T, h, V) if `edge`
 struct Window { int lo, hiE, edge; };
@@ -841,7 +840,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
     E_s = E;
     g_s = gg;
     STRIP_TICK(4);
-    int route = 0;  // 0: 5-strip window, 2: 9-strip window, 1: the whole utterance
+    int route = kLocal;  // strips per side of the level-3 window (2, 4, 8 or 16); 0: the whole utterance
     if (xwg) {
       // publish the strip's record, then announce it
       double *rp = a.rec + ((size_t)g * R + r) * (kRec * 64) + lane;
@@ -852,20 +851,22 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       st_agent(rp + 12 * 64, hs.x); st_agent(rp + 13 * 64, hs.y);
       // Route, from this strip's own data alone (so that the choice -- and with it every bit of the result -- never
       // depends on timing): its own transfer factor t = 2 max|E^-1 V| is one of the factors of the window's damping
-      // bound (2 per side in the 5-strip window, 4 in the 9-strip one).  t <= kDampTol^(1/2): the narrow window;
-      // t <= kDampTol^(1/4): the wide one; beyond that any window would be rejected (variances whose dynamic features
-      // are much tighter than the static ones couple strips over hundreds of frames) and the strip waits for the
-      // whole utterance right away.  The bound still decides whether a window's result is accepted.
+      // bound (k per side in a window of k strips per side).  t <= kDampTol^(1/2): the narrow window; otherwise the
+      // smallest k in {4, 8, 16} with t^k <~ kDampTol; beyond that, or if such a window spans the utterance anyway
+      // (variances whose dynamic features are much tighter than the static ones couple strips over hundreds of
+      // frames), the strip waits for the whole utterance right away.  The bound still decides whether a window's
+      // result is accepted.
       {
         bool badr = false;
         const double t_own = 2.0 * amax4(mul_sm(sym_inv(E, badr), V));
-        const bool over = __ballot(lane_ok && !(t_own <= kRouteTol)) != 0ull;
-        const bool over_wide = __ballot(lane_ok && !(t_own <= kRouteTolWide)) != 0ull;
-        route = over_wide ? 1 : (over ? 2 : 0);
+        // k strips per side need t^k <~ kDampTol: 2 (t <= 1e-11), 4 (3e-6), 8 (1.8e-3), 16 (4.2e-2); 0 = whole utterance
+        auto any_over = [&](const double tol) { return __ballot(lane_ok && !(t_own <= tol)) != 0ull; };  // NaN counts
+        route = !any_over(kRouteTol) ? kLocal : !any_over(3e-6) ? 4 : !any_over(1.8e-3) ? 8 : !any_over(4.2e-2) ? 16 : 0;
+        if (2 * route + 1 >= Ract) route = route > kLocal ? 0 : route;  // a window as wide as the utterance: sweep it all
         if (lane == 0) lds_misc[3] = route;
       }
-      const int kwin = route == 2 ? kLocalWide : kLocal;
-      if (route == 0) {
+      const int kwin = route ? route : kLocal;
+      if (route == kLocal) {
         // the narrow window's sweep takes this strip's own record from here (the last place of the staged order),
         // not from HBM.  (lds_rec, the same bytes, has been consumed by level 2.)
         const Window w = local_window(r, Ract, kLocal);
@@ -889,7 +890,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         int spins = 0, ok = 1;
         for (;;) {
           int f = 1;
-          if (route == 1) f = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= Ract;
+          if (route == 0) f = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= Ract;
           else if (lane <= w.hiE - w.lo) f = __hip_atomic_load(flags + w.lo + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (__ballot(f == 0) == 0ull) break;
           __builtin_amdgcn_s_sleep(MLPG_STRIP_POLL_SLEEP);
@@ -1039,9 +1040,9 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         }
         damp = dt > db ? dt : db;
       };
-      const Window w = local_window(r, Ract, route == 2 ? kLocalWide : kLocal);
+      const Window w = local_window(r, Ract, route ? route : kLocal);
       const bool full_range = w.lo == 0 && !w.edge;
-      if (route == 1) {
+      if (route == 0) {
         sweep(0, Ract - 1, 0);
       } else {
       sweep(w.lo, w.hiE, w.edge);
@@ -1141,12 +1142,12 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         }
       };
       const int route = __builtin_amdgcn_readfirstlane(lds_misc[3]);  // wavefront 0's choice (see there)
-      const Window w = local_window(r, Ract, route == 2 ? kLocalWide : kLocal);
-      if (route == 1) {
+      const Window w = local_window(r, Ract, route ? route : kLocal);
+      if (route == 0) {
         skip_own = false;
         stage(0, Ract - 1);
       } else {
-        skip_own = route == 0;  // only the narrow window has this strip's own record in LDS already
+        skip_own = route == kLocal;  // only the narrow window has this strip's own record in LDS already
         stage(w.lo, w.hiE);
         __syncthreads();  // (S2b) wavefront 0's decision: is the window enough?
         if (!__builtin_amdgcn_readfirstlane(lds_misc[2])) {

@@ -286,7 +286,8 @@ def test_strip_two_streams_concurrently():
         assert torch.equal(outs[k], ref[k])
 
 
-def test_strip_tight_dynamic_variances_every_window_rejected():
+@pytest.mark.parametrize("T", [1100, 3000])
+def test_strip_tight_dynamic_variances_every_window_rejected(T):
     """Variances as acoustic models have them (delta / delta-delta 100 x / 1000 x tighter than static): the coupling
     between strips decays by only ~1e-2 per strip, a 5-strip window would be rejected by the damping bound, and the
     strips route themselves to the full-utterance sweep from their own transfer factor; with 10 x / 100 x they take
@@ -296,7 +297,7 @@ def test_strip_tight_dynamic_variances_every_window_rejected():
     from nnmnkwii_amd import _hip
     STD3 = WINDOW_SETS["std3"]
     rng = np.random.RandomState(77)
-    B, T, sd = 6, 1100, 60
+    B, sd = 6, 60                    # T = 3000 (47 strips): the tight utterances take windows of 8 / 16 strips per side
     m = rng.randn(B, T, 3 * sd)
     v = rng.rand(B, T, 3 * sd) + 0.1
     v[:3, :, sd:2 * sd] *= 1e-2

@@ -113,6 +113,10 @@ def main():
         for name, algo in (("generic", 1), ("strip", 3)):
             ms = gpu_time(lambda: _hip.forward(m2, v2, WINDOWS, algo=algo, want_status=False), steps=5)
             emit(path="long-T4000-forward-" + name, ms=ms, frames_per_s=B2 * T2 / ms * 1e3, alg_bytes=by2, GBps=by2 / ms / 1e6)
+        v2[:, :, sd:2 * sd] *= 1e-2          # the same with tight dynamic variances: windows of 8 / 16 strips per side
+        v2[:, :, 2 * sd:] *= 1e-3
+        ms = gpu_time(lambda: _hip.forward(m2, v2, WINDOWS, algo=3, want_status=False), steps=5)
+        emit(path="long-T4000-forward-tight-dynamic-variances-strip", ms=ms, frames_per_s=B2 * T2 / ms * 1e3, alg_bytes=by2, GBps=by2 / ms / 1e6)
         del m, v, x, m2, v2
 
     # ---- c2g: global / unit variances ----
