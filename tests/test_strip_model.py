@@ -90,3 +90,20 @@ def test_model_local_window_level3():
     # the bound is what protects the result: forcing the window everywhere is visibly wrong
     yw, _ = S.mlpg_strip(m, v, W3, local_k=2, local_tol=np.inf)
     assert rel_err(yw, yf) > 1e-6
+
+
+def test_model_wider_windows_for_tighter_dynamic_variances():
+    """Dynamic variances 10 x / 100 x tighter than the static ones: the 5-strip window's bound (~1e-13) is not below
+    1e-22, the 9-strip window's (~1e-27) is, and its result equals the full sweep's."""
+    W3 = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(4)
+    T, sd = 1100, 3
+    m = rng.randn(T, 3 * sd)
+    v = np.concatenate([rng.rand(T, sd) + 0.1, 0.1 * (rng.rand(T, sd) + 0.1), 0.01 * (rng.rand(T, sd) + 0.1)], axis=1)
+    s2, s4 = [], []
+    S.mlpg_strip(m, v, W3, local_k=2, stats=s2)
+    y4, bad = S.mlpg_strip(m, v, W3, local_k=4, stats=s4)
+    assert not bad.any()
+    assert max(d for d, _ in s2) > 1e-22 and max(d for d, _ in s4) < 1e-22
+    assert max(e for _, e in s4) < 1e-13
+    assert rel_err(y4, O.mlpg(m, v, W3)) < 1e-10
