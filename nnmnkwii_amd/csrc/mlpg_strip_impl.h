@@ -81,6 +81,9 @@ constexpr int kCtrlLine = 32;
 #ifndef MLPG_STRIP_POLL_SLEEP
 #define MLPG_STRIP_POLL_SLEEP 16  // x 64 cycles between two looks at the neighbours' flags (4 .. 64 measured: no difference)
 #endif
+#ifndef MLPG_STRIP_RING_F32
+#define MLPG_STRIP_RING_F32 6
+#endif
 #ifndef MLPG_STRIP_STREAM
 #define MLPG_STRIP_STREAM 1  // 0: window-major assembly, then elimination, also for three windows (A/B measurements)
 #endif
@@ -460,7 +463,10 @@ __device__ __forceinline__ bool eliminate(double (&Pd)[kM], double (&P1)[kM], do
 // refilled with the frame kRing further on.  Unlike the window-major order of `assemble`, rows that have not been
 // reached yet hold nothing, so the ring and the accumulators never peak together: this is what lets the loads
 // stream without spilling.  Arithmetic per entry: the same sums in a different order (frame-major).
-constexpr int kRing = 6;
+template <typename TIN>
+struct RingDepth { static constexpr int value = 6; };   // frames of loads in flight per wavefront (float64: 36 loads, 18 KB)
+template <>
+struct RingDepth<float> { static constexpr int value = MLPG_STRIP_RING_F32; };  // float32 values take half the registers
 template <typename TIN, bool BWD, int VM, bool EDGE, int NW>
 __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, __amdgpu_buffer_rsrc_t vrs,
                                                    __amdgpu_buffer_rsrc_t grs, const TIN *__restrict__ vglob,
@@ -489,6 +495,7 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
       k[w].tau_glob = t1;
     }
   }
+  constexpr int kRing = RingDepth<TIN>::value;
   TIN rv[kRing][NW], rm[kRing][NW];
   auto load_frame = [&](TIN (&v)[NW], TIN (&m)[NW], const int i) __attribute__((always_inline)) {
 #pragma unroll
@@ -592,9 +599,9 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
   };
 
   // prologue: the first kRing frames (f0-1 ..) in flight
-#define STRIP_LD(S, I) load_frame(rv[S], rm[S], (I));
-  STRIP_LD(0, -1) STRIP_LD(1, 0) STRIP_LD(2, 1) STRIP_LD(3, 2) STRIP_LD(4, 3) STRIP_LD(5, 4)
-  static_assert(kRing == 6, "the unrolled schedule below is written for a ring of 6 frames");
+#pragma unroll
+  for (int sl = 0; sl < kRing; ++sl) load_frame(rv[sl], rm[sl], sl - 1);
+  static_assert(kRing >= 2 && kRing <= kM + 2, "ring depth");
   if (BWD) {
 #pragma unroll
     for (int i = 0; i < kM; ++i) {
@@ -616,7 +623,6 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
   STRIP_STEP(6) STRIP_STEP(7) STRIP_STEP(8) STRIP_STEP(9) STRIP_STEP(10) STRIP_STEP(11)
   STRIP_STEP(12) STRIP_STEP(13) STRIP_STEP(14) STRIP_STEP(15) STRIP_STEP(16) STRIP_STEP(17)
 #undef STRIP_STEP
-#undef STRIP_LD
   if (EDGE) {
     fix_row(kN);
     fix_row(kN + 1);
