@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Soak test of the strip kernel's inter-workgroup protocol: random shapes / dtypes / variance modes / directions, every
+launch compared with the generic kernel; reports the worst deviation, any non-zero status and the wall time."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from nnmnkwii_amd import _hip  # noqa: E402
+from tools.bench_paths import WINDOWS  # noqa: E402
+
+
+def main(seconds=60.0, seed=0):
+    rng = np.random.RandomState(seed)
+    pw = _hip.prepack_windows(WINDOWS)
+    t0 = time.time()
+    n = 0
+    worst = 0.0
+    while time.time() - t0 < seconds:
+        B = int(rng.randint(1, 48))
+        T = int(rng.choice([1, 2, 17, 63, 64, 65, 130, 500, 1000, 1100, 2049, 3000]))
+        sd = int(rng.choice([1, 3, 16, 25, 60, 64, 65, 128]))
+        dt = torch.float64 if rng.rand() < 0.6 else torch.float32
+        mode = int(rng.randint(0, 3))
+        m = torch.randn(B, T, 3 * sd, dtype=dt, device="cuda")
+        scale = torch.ones(3 * sd, dtype=dt, device="cuda")
+        tight = rng.rand()
+        if tight < 0.3:                                  # tight dynamic variances: wider windows / full sweeps
+            scale[sd:2 * sd] = 10.0 ** -rng.randint(1, 4)
+            scale[2 * sd:] = 10.0 ** -rng.randint(2, 5)
+        v = None if mode == 2 else ((torch.rand(3 * sd, dtype=dt, device="cuda") + 0.1) * scale if mode == 1
+                                   else (torch.rand(B, T, 3 * sd, dtype=dt, device="cuda") + 0.1) * scale)
+        L = torch.from_numpy(rng.randint(0 if rng.rand() < 0.1 else 1, T + 1, size=B).astype(np.int32)).cuda()
+        if rng.rand() < 0.5:
+            a, sa = _hip.forward(m, v, pw, L, algo=_hip.ALGO_STRIP)
+            b, sb = _hip.forward(m, v, pw, L, algo=_hip.ALGO_GENERIC)
+        else:
+            go = torch.randn(B, T, sd, dtype=dt, device="cuda")
+            a, sa = _hip.backward(v, go, pw, 3 * sd, L, out_dtype=torch.float64, algo=_hip.ALGO_STRIP)
+            b, sb = _hip.backward(v, go, pw, 3 * sd, L, out_dtype=torch.float64, algo=_hip.ALGO_GENERIC)
+        assert int(sa.abs().max()) == 0 and int(sb.abs().max()) == 0, (B, T, sd, dt, mode, int(sa.min()), int(sa.max()))
+        den = float(b.abs().max()) + 1e-300
+        err = float((a.double() - b.double()).abs().max()) / den
+        tol = 1e-3 if tight < 0.3 else (1e-7 if dt == torch.float64 else 1e-3)   # tight variances: ill-conditioned by construction
+        assert err <= tol, (B, T, sd, dt, mode, err)
+        worst = max(worst, err if tight >= 0.3 and dt == torch.float64 else 0.0)
+        n += 1
+    print("soak: %d launches pairs in %.0f s, no status, worst f64 deviation (ordinary variances) %.2e" % (n, time.time() - t0, worst))
+
+
+if __name__ == "__main__":
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
