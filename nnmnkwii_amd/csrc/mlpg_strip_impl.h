@@ -84,6 +84,9 @@ constexpr int kCtrlLine = 32;
 #ifndef MLPG_STRIP_RING_F32
 #define MLPG_STRIP_RING_F32 6
 #endif
+#ifndef MLPG_STRIP_ROUTE1_TOL
+#define MLPG_STRIP_ROUTE1_TOL 0.0  // own transfer factor below which a 3-strip window is tried first (0: never)
+#endif
 #ifndef MLPG_STRIP_STREAM
 #define MLPG_STRIP_STREAM 1  // 0: window-major assembly, then elimination, also for three windows (A/B measurements)
 #endif
@@ -867,15 +870,15 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         const double t_own = 2.0 * amax4(mul_sm(sym_inv(E, badr), V));
         // k strips per side need t^k <~ kDampTol: 2 (t <= 1e-11), 4 (3e-6), 8 (1.8e-3), 16 (4.2e-2); 0 = whole utterance
         auto any_over = [&](const double tol) { return __ballot(lane_ok && !(t_own <= tol)) != 0ull; };  // NaN counts
-        route = !any_over(kRouteTol) ? kLocal : !any_over(3e-6) ? 4 : !any_over(1.8e-3) ? 8 : !any_over(4.2e-2) ? 16 : 0;
+        route = !any_over(MLPG_STRIP_ROUTE1_TOL) ? 1 : !any_over(kRouteTol) ? kLocal : !any_over(3e-6) ? 4 : !any_over(1.8e-3) ? 8 : !any_over(4.2e-2) ? 16 : 0;
         if (2 * route + 1 >= Ract) route = route > kLocal ? 0 : route;  // a window as wide as the utterance: sweep it all
         if (lane == 0) lds_misc[3] = route;
       }
       const int kwin = route ? route : kLocal;
-      if (route == kLocal) {
-        // the narrow window's sweep takes this strip's own record from here (the last place of the staged order),
+      if (route && route <= kLocal) {
+        // the narrow windows' sweep takes this strip's own record from here (the last place of the staged order),
         // not from HBM.  (lds_rec, the same bytes, has been consumed by level 2.)
-        const Window w = local_window(r, Ract, kLocal);
+        const Window w = local_window(r, Ract, route);
         const Order o = make_order(r, w.lo, w.hiE);
         const double own[kRec] = {E.a, E.b, E.c, gg.x, gg.y, V.a, V.b, V.c, V.d, Ts.a, Ts.b, Ts.c, hs.x, hs.y};
 #pragma unroll
@@ -1153,7 +1156,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         skip_own = false;
         stage(0, Ract - 1);
       } else {
-        skip_own = route == kLocal;  // only the narrow window has this strip's own record in LDS already
+        skip_own = route <= kLocal;  // only the narrow (single-batch) windows have this strip's own record in LDS already
         stage(w.lo, w.hiE);
         __syncthreads();  // (S2b) wavefront 0's decision: is the window enough?
         if (!__builtin_amdgcn_readfirstlane(lds_misc[2])) {
