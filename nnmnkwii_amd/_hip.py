@@ -7,6 +7,7 @@ raise.
 """
 import ctypes
 import os
+import sys
 import threading
 
 import numpy as np
@@ -238,11 +239,29 @@ def forward(mean, var, windows, lengths=None, algo=ALGO_AUTO, want_status=True):
     return out, status
 
 
-def forward_host(mean, var, windows, lengths=None, algo=ALGO_AUTO, device=0):
+def current_device_index(device=None):
+    """GPU index for the host-pointer entry points: an explicit int / "cuda:1" / object with .index, otherwise the
+    process's current device (what torch.cuda.set_device(local_rank) selected in a one-process-per-GPU job; 0 when
+    torch has not been imported -- the entry points themselves need no torch)."""
+    if device is not None:
+        idx = getattr(device, "index", device)
+        if isinstance(idx, str):
+            idx = idx.split(":")[-1] if ":" in idx else None
+        if idx is not None:
+            return int(idx)
+    t = sys.modules.get("torch")
+    if t is not None and t.cuda.is_available():
+        return int(t.cuda.current_device())
+    return 0
+
+
+def forward_host(mean, var, windows, lengths=None, algo=ALGO_AUTO, device=None):
     """Batched MLPG, numpy in -> numpy out through mlpg_hip_forward_host (no torch involved): mean (B, T, D)
-    float32/float64 C-contiguous, var same shape / (D,) / None, lengths int32 (B,) or None.
+    float32/float64 C-contiguous, var same shape / (D,) / None, lengths int32 (B,) or None; device: GPU index
+    (default: the current device, see current_device_index).
     Returns (out (B, T, sd) ndarray, status int32 (B, sd))."""
     L = lib()
+    device = current_device_index(device)
     if L.mlpg_hip_device_count() <= 0:
         raise HipExtensionError("nnmnkwii_amd needs an AMD GPU (none visible to the HIP runtime); there is no CPU fallback")
     assert mean.ndim == 3 and mean.flags.c_contiguous and mean.dtype in (np.float32, np.float64)
@@ -487,17 +506,20 @@ def fastdtw_l2(X, Y, lenx, leny, radius=1, dist_kind=DIST_L2, dist_scale=1.0):
     return path_i, path_j, path_len, cost
 
 
-def fastdtw_host(X, Y, radius=1, dist_kind=DIST_L2, dist_scale=1.0, lenx=None, leny=None, eps=1e-7, device=0):
+def fastdtw_host(X, Y, radius=1, dist_kind=DIST_L2, dist_scale=1.0, lenx=None, leny=None, eps=1e-7, device=None):
     """fastdtw paths for N pairs held in numpy arrays (no framework tensor): mlpg_hip_fastdtw_host, chunked and
     overlapped with the transfers.  X (N, Tx, D), Y (N, Ty, D) float32 / float64.  Without lengths the trailing
     all-zero frames are trimmed on the device (eps as trim_zeros_frames).  Returns numpy
     (path_i, path_j (N, Tx+Ty) int32, path_len (N,), cost (N,), lenx, leny)."""
     L = lib()
+    device = current_device_index(device)
     X = np.ascontiguousarray(X)
     Y = np.ascontiguousarray(Y)
-    if X.dtype not in (np.float32, np.float64):
-        X = X.astype(np.float64)
-    Y = Y.astype(X.dtype, copy=False)
+    # one dtype for the C entry point; mixed or non-float inputs are WIDENED to float64 (each array from its own
+    # dtype, as the device route and the reference's fastdtw do), never narrowed
+    if X.dtype != Y.dtype or X.dtype not in (np.float32, np.float64):
+        X = X.astype(np.float64, copy=False)
+        Y = Y.astype(np.float64, copy=False)
     assert X.ndim == 3 and Y.ndim == 3 and X.shape[0] == Y.shape[0] and X.shape[2] == Y.shape[2]
     N, Tx, D = X.shape
     Ty = Y.shape[1]

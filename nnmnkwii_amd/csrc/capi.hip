@@ -81,6 +81,7 @@ struct SideStreams {
   static constexpr int kN = 3;
   hipStream_t st[kN];
   hipEvent_t fork, join[kN];
+  std::mutex mu;  // held by mlpg_hip_forward_streams while it enqueues (two host threads on one device)
 };
 SideStreams *g_side[kMaxDevices] = {};
 
@@ -389,37 +390,67 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
       widest = k;
   hipStream_t main_st = (hipStream_t)stream;
   SideStreams *side = side_streams(device);
+  // one caller at a time per device: the side streams and their fork/join events are shared
+  std::unique_lock<std::mutex> side_lock;
+  if (side) side_lock = std::unique_lock<std::mutex>(side->mu);
   int nside = 0;
-  bool forked = false;
-  int status_col = 0;
-  for (int k = 0; k < num_streams; ++k) {
+  // The fork is recorded BEFORE anything of this call is queued on the caller's stream and the widest stream is
+  // launched last: the narrow streams' kernels then only wait for what preceded the call, not for the wide kernel.
+  int n_narrow = 0;
+  for (int k = 0; k < num_streams; ++k) n_narrow += streams_h[k].static_dim > 0 && k != widest;
+  if (side && n_narrow > 0) MLPG_HIP_CHECK(hipEventRecord(side->fork, main_st));
+  auto join_side = [&]() -> int {  // also on the error paths: an unjoined side stream would break a graph capture
+    for (int q = 0; q < nside; ++q) {
+      MLPG_HIP_CHECK(hipEventRecord(side->join[q], side->st[q]));
+      MLPG_HIP_CHECK(hipStreamWaitEvent(main_st, side->join[q], 0));
+    }
+    nside = 0;
+    return 0;
+  };
+  int status_cols[64];
+  {
+    int c = 0;
+    for (int k = 0; k < num_streams && k < 64; ++k) { status_cols[k] = c; c += streams_h[k].static_dim; }
+  }
+  if (num_streams > 64) {
+    set_error("forward_streams: more than 64 streams");
+    return MLPG_HIP_EINVAL;
+  }
+  auto run_stream = [&](const int k, hipStream_t st) -> int {
     const mlpg_hip_stream_t &sm = streams_h[k];
-    if (sm.static_dim > 0) {
-      hipStream_t st = main_st;
-      if (side && k != widest && nside < SideStreams::kN) {
-        if (!forked) {
-          MLPG_HIP_CHECK(hipEventRecord(side->fork, main_st));
-          forked = true;
-        }
-        st = side->st[nside];
-        MLPG_HIP_CHECK(hipStreamWaitEvent(st, side->fork, 0));
+    if (int rc = stream_entry(device, st, dtype, algo, mean, var, var_mode, (long)ld_in, lengths, B, Tmax, sm, win_l_h,
+                              win_u_h, win_coef_h, out, (long)ld_out, status, (int)sd_total, status_cols[k]))
+      return rc;
+    if (sm.num_windows == 0 && status) {
+      // pass-through streams cannot fail: their status columns are cleared
+      MLPG_HIP_CHECK(hipMemset2DAsync(status + status_cols[k], sizeof(int32_t) * (size_t)sd_total, 0,
+                                      sizeof(int32_t) * (size_t)sm.static_dim, (size_t)B, st));
+    }
+    return 0;
+  };
+  for (int k = 0; k < num_streams; ++k) {
+    if (streams_h[k].static_dim <= 0 || k == widest) continue;
+    hipStream_t st = main_st;
+    if (side && nside < SideStreams::kN) {
+      st = side->st[nside];
+      if (hipStreamWaitEvent(st, side->fork, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        st = main_st;
+      } else {
         ++nside;
       }
-      if (int rc = stream_entry(device, st, dtype, algo, mean, var, var_mode, (long)ld_in, lengths, B, Tmax, sm, win_l_h,
-                                win_u_h, win_coef_h, out, (long)ld_out, status, (int)sd_total, status_col))
-        return rc;
-      if (sm.num_windows == 0 && status) {
-        // pass-through streams cannot fail: their status columns are cleared
-        MLPG_HIP_CHECK(hipMemset2DAsync(status + status_col, sizeof(int32_t) * (size_t)sd_total, 0,
-                                        sizeof(int32_t) * (size_t)sm.static_dim, (size_t)B, st));
-      }
     }
-    status_col += sm.static_dim;
+    if (int rc = run_stream(k, st)) {
+      (void)join_side();
+      return rc;
+    }
   }
-  for (int q = 0; q < nside; ++q) {
-    MLPG_HIP_CHECK(hipEventRecord(side->join[q], side->st[q]));
-    MLPG_HIP_CHECK(hipStreamWaitEvent(main_st, side->join[q], 0));
-  }
+  if (widest >= 0)
+    if (int rc = run_stream(widest, main_st)) {
+      (void)join_side();
+      return rc;
+    }
+  if (int rc = join_side()) return rc;
   return 0;
 }
 

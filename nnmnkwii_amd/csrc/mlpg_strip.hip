@@ -16,6 +16,7 @@ namespace {
 constexpr int kStripFrames = 64;   // strip::kW * strip::kM
 constexpr int kMaxStrips = 256;    // strips of one utterance must be able to be resident together (2 per CU)
 constexpr int kRecBytes = 14 * 64 * 8;
+constexpr int kStripNotResident = -1000;  // = strip::kNotResident (mlpg_strip_impl.h)
 }  // namespace
 
 bool strip_supported(const Problem &p, const WinSet &ws) {
@@ -76,11 +77,19 @@ int launch_strip(hipStream_t st, int dtype, int out_dtype, bool backward, const 
     if (!capturing && c.first == gen && ctrl <= c.second) zero_ctrl = false;
     c = {gen, capturing ? (size_t)0 : ctrl};
   }
+  int rc;
   if (!backward)
-    return dtype == MLPG_HIP_F32 ? launch_strip_fwd_f32(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl)
-                                 : launch_strip_fwd_f64(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl);
-  return dtype == MLPG_HIP_F32 ? launch_strip_bwd_f32(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl)
+    rc = dtype == MLPG_HIP_F32 ? launch_strip_fwd_f32(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl)
+                               : launch_strip_fwd_f64(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl);
+  else
+    rc = dtype == MLPG_HIP_F32 ? launch_strip_bwd_f32(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl)
                                : launch_strip_bwd_f64(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl);
+  if (rc == kStripNotResident) {
+    // fewer workgroups can be resident than an utterance has strips (a smaller device, or an occupancy the runtime
+    // reports lower than expected): nothing was enqueued; the natural-order kernel has no such requirement
+    return launch_generic(st, dtype, out_dtype, backward, p, ws, device);
+  }
+  return rc;
 }
 
 }  // namespace mlpg

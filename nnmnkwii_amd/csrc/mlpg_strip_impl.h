@@ -41,6 +41,8 @@
 //
 // Reference semantics as in mlpg_wave_impl.h (paramgen/_mlpg.py:92-199, :202-281).
 #pragma once
+#include <mutex>
+#include <vector>
 #include "assemble.h"
 
 #ifndef MLPG_STRIP_ABLATE
@@ -1366,6 +1368,35 @@ __global__ void __launch_bounds__(256) verdict_kernel(const Problem p, const Win
 // Scratch layout for one launch: control words, then the records.
 inline size_t ctrl_bytes(int nsg, int R) { return (ctrl_ints(nsg, R) * sizeof(int) + 255) / 256 * 256; }
 
+constexpr int kNotResident = -1000;  // launch_t: the grid cannot hold an utterance's strips; nothing was enqueued
+
+// Workgroups of `kern` (threads, dynamic LDS bytes) that are resident at once on the current device: the occupancy
+// the runtime reports x the CU count.  Queried (and the dynamic-LDS attribute set) once per kernel and device.
+inline int resident_grid(const void *kern, int threads, size_t lds, int *out) {
+  struct Entry { const void *kern; int dev, grid; };
+  static std::mutex mu;
+  static std::vector<Entry> cache;
+  int dev = 0;
+  MLPG_HIP_CHECK(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Entry &e : cache)
+      if (e.kern == kern && e.dev == dev) { *out = e.grid; return 0; }
+  }
+  int ncu = 0, per_cu = 0;
+  MLPG_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  MLPG_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  MLPG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
+  if (ncu < 1 || per_cu < 1) {
+    set_error("strip kernel: occupancy query returned %d workgroups per CU on %d CUs", per_cu, ncu);
+    return MLPG_HIP_ERUNTIME;
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  cache.push_back({kern, dev, ncu * per_cu});
+  *out = ncu * per_cu;
+  return 0;
+}
+
 template <typename TIN, typename TOUT, bool BWD>
 int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, int ndg, int dgw,
              bool zero_ctrl) {
@@ -1386,15 +1417,19 @@ int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_b
     for (int q = 0; q < 9; ++q) a.wc[w][q] = v[q];
   }
   const long nitems = (long)nsg * R;
-  a.nlists = nitems >= 512 ? kMaxLists : 1;  // a small launch may not put a workgroup on every XCD early: one list
-  if (zero_ctrl) MLPG_HIP_CHECK(hipMemsetAsync(a.ctrl, 0, ctrl_ints(nsg, R) * sizeof(int), st));
-  // persistent workgroups: as many as can be resident (two per CU), each draws items until the lists are empty
-  int dev = 0, ncu = 256;
-  MLPG_HIP_CHECK(hipGetDevice(&dev));
-  MLPG_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-  const long grid = nitems < 2L * ncu ? nitems : 2L * ncu;
   auto go = [&](auto kern) -> int {
-    MLPG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    // persistent workgroups: as many as can be RESIDENT (asked of the runtime for this kernel and its LDS, once per
+    // device), each draws items until the lists are empty
+    int resident = 0;
+    if (int rc = resident_grid((const void *)kern, kW * 64, kLdsBytes, &resident)) return rc;
+    // Co-residency the protocol relies on: a strip may wait for every strip of its utterance (route 0), and those
+    // are only ever held by workgroups that draw from the same list.  One list per XCD (system group g in list g % 8,
+    // locality) only while an utterance's strips fit twice into an XCD's share of the grid; otherwise one list, and
+    // then the whole grid must be able to hold an utterance twice over -- if not, the caller takes another kernel.
+    a.nlists = (nitems >= 512 && R <= resident / (2 * kMaxLists)) ? kMaxLists : 1;
+    if (nitems > resident && R > resident / 2) return kNotResident;
+    if (zero_ctrl) MLPG_HIP_CHECK(hipMemsetAsync(a.ctrl, 0, ctrl_ints(nsg, R) * sizeof(int), st));
+    const long grid = nitems < resident ? nitems : resident;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kW * 64), kLdsBytes, st, p, ws, a);
     MLPG_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL((verdict_kernel<TIN, TOUT, BWD>), dim3((unsigned)((nsg + 3) / 4)), dim3(256), 0, st, p, ws, a);

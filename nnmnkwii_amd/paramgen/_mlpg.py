@@ -152,12 +152,7 @@ def _mlpg_batch_host(means, variances, windows, lengths, algo, check, device):
                 v = 1.0 / (np.float32(1.0) / v).astype(np.float64)
             else:
                 m = m.astype(np.float64)
-    dev_index = 0
-    if device is not None:                                 # int, "cuda:1" or an object with .index
-        idx = getattr(device, "index", device)
-        if isinstance(idx, str):
-            idx = idx.split(":")[-1] if ":" in idx else 0
-        dev_index = 0 if idx is None else int(idx)
+    dev_index = _hip.current_device_index(device)          # default: the process's current GPU, not GPU 0
     out, status = _hip.forward_host(m, v, windows, lengths, algo=algo, device=dev_index)
     if check:
         st = status.ravel()

@@ -89,7 +89,7 @@ class DTWAligner(object):
         dist_kind, dist_scale = _resolve_dist(self.dist)
         dev = _hip.require_gpu()
         if X.nbytes + Y.nbytes >= self._HOST_ENTRY_BYTES:
-            out = _hip.fastdtw_host(X, Y, self.radius, dist_kind, dist_scale)      # alignment.py:46-50
+            out = _hip.fastdtw_host(X, Y, self.radius, dist_kind, dist_scale, device=dev.index)      # alignment.py:46-50
             return out + ((lambda is_x, path, plen, T_out, dtype: _gather(X if is_x else Y, path, plen, T_out, dtype)),)
         torch = _hip.torch_mod()
         Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)

@@ -100,8 +100,9 @@ def mlpg_batch_sharded(means, variances, windows, lengths=None, gather=True, gro
 
     ``local_shards=True``: every rank passes ONLY its own utterances (the way a multi-process data loader hands
     them out: no rank ever holds the whole batch); shard sizes may differ (even be zero).  ``gather=True``
-    concatenates the results in rank order on every rank; ``gather=False`` returns the local result and this
-    rank's ``(lo, hi)`` position in that order.
+    concatenates the results in rank order on every rank (ranks may have padded their shards to different ``Tmax``:
+    the results are grown to the global maximum before the gather; the static dimension must agree);
+    ``gather=False`` returns the local result and this rank's ``(lo, hi)`` position in that order.
 
     ``compute(means, variances, windows, lengths)`` overrides the per-shard
     kernel call (the CPU tests inject a checker there; the default is the HIP path).
@@ -135,6 +136,19 @@ def mlpg_batch_sharded(means, variances, windows, lengths=None, gather=True, gro
             sizes = _gather_sizes(int(yt.shape[0]), yt.device, group)
             start = sum(sizes[:rank])
             return y, (start, start + sizes[rank])
+        # ranks that padded their own shards may disagree on Tmax: pad every shard to the global maximum first
+        # (all_gather_into_tensor needs identical trailing shapes; the padding frames of an MLPG result are zero anyway)
+        if world > 1:
+            tmax = torch.tensor([yt.shape[1], yt.shape[2], -yt.shape[2]], dtype=torch.int64, device=yt.device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
+            t_glob, sd_max, sd_min = int(tmax[0]), int(tmax[1]), -int(tmax[2])
+            if sd_max != sd_min:
+                raise ValueError("mlpg_batch_sharded(local_shards=True): ranks disagree on the static dimension "
+                                 "(%d vs %d)" % (sd_min, sd_max))
+            if t_glob != yt.shape[1]:
+                grown = yt.new_zeros((yt.shape[0], t_glob, yt.shape[2]))
+                grown[:, : yt.shape[1]] = yt
+                yt = grown
         full = all_gather_varsize(yt, group)[0]
     else:
         full = all_gather_shards(yt, B, group)
@@ -173,9 +187,13 @@ def dtw_align_sharded(aligner, X, Y, group=None, transform=None, local_shards=Fa
     T_out = int(tlen.item())
 
     def pad(a):
-        out = np.zeros((a.shape[0], T_out, D), dtype=a.dtype)
-        out[:, : a.shape[1]] = a
-        return torch.from_numpy(out).to(dev)
+        # upload the shard as it is and grow it on the device: no host-side padded copy
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        if t.shape[1] == T_out:
+            return t
+        out = torch.zeros((a.shape[0], T_out, D), dtype=t.dtype, device=dev)
+        out[:, : a.shape[1]] = t
+        return out
 
     if local_shards:
         return all_gather_varsize(pad(Xa), group)[0].cpu().numpy(), all_gather_varsize(pad(Ya), group)[0].cpu().numpy()

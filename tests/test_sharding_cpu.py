@@ -90,6 +90,13 @@ def _worker(rank, world, port, B, q):
         Xf2, Yf2 = sharding.dtw_align_sharded(None, X[mine], Y[mine], transform=lambda xy: OD.dtw_align(xy[0], xy[1])[:2],
                                               local_shards=True)
         ok = ok and Xf2.shape == Xo.shape and np.array_equal(Xf2, Xo) and np.array_equal(Yf2, Yo)
+        # ... and each rank padded its own shard to its OWN Tmax (what a per-process data loader does): the shards'
+        # trailing shapes differ, the gather grows them to the global maximum first
+        own_T = max(int(lengths[mine].max()), 1) if mine.stop > mine.start else 1
+        full3 = sharding.mlpg_batch_sharded(M[mine, :own_T], V[mine, :own_T], windows, lengths[mine], gather=True,
+                                            compute=compute, local_shards=True)
+        t_glob = int(max(lengths[:cut].max(), lengths[cut:].max() if cut < B else 1))
+        ok = ok and full3.shape == (B, t_glob, sd) and np.array_equal(full3, ref[:, :t_glob])
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -358,3 +358,59 @@ def test_strip_kernel_inside_a_hip_graph():
             if k == 1:
                 assert int(st.reshape(B, sd)[2, 7]) == 301 and not y[2, :, 7].any()
                 v[2, 300, 7] = 0.5
+
+
+def test_strip_whole_utterance_route_many_groups_long_utterances():
+    """Round-2 advisor scenario: >= 8 system groups, T = 8000 (125 strips > the 64 workgroups of one XCD) and
+    variances whose dynamic features are 1e3 / 1e4 x tighter than the static ones, so that every strip takes the
+    whole-utterance route.  With one ticket list per XCD each XCD's workgroups would hold the first strips of their
+    own utterance and starve; the launcher must pick a single list there.  No time-out, same numbers as the
+    natural-order kernel."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, T, sd = 10, 8000, 60
+    m = torch.randn(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=g)
+    v = torch.rand(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=g) + 0.1
+    v[:, :, sd:2 * sd] *= 1e-3
+    v[:, :, 2 * sd:] *= 1e-4
+    out, status = _hip.forward(m, v, STD3, algo=_hip.ALGO_STRIP)
+    assert int(status.abs().max().item()) == 0           # -1 would be a timed-out inter-workgroup wait
+    gen, _ = _hip.forward(m, v, STD3, algo=_hip.ALGO_GENERIC)
+    scale = gen.abs().amax(dim=1, keepdim=True)
+    assert float(((out - gen).abs() / scale).max()) <= 1e-7
+    out2, _ = _hip.forward(m, v, STD3, algo=_hip.ALGO_STRIP)
+    assert torch.equal(out, out2)
+
+
+def test_strip_whole_utterance_route_while_another_stream_holds_cus():
+    """The whole-utterance route at the largest strip count the kernel accepts (T = 16 384) while a second stream keeps
+    the GPU busy with large elementwise kernels: the persistent grid is sized from the runtime's occupancy answer and
+    every wait is on strips that resident workgroups hold, so the result arrives (status 0) however the two kernels
+    share the CUs."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    g = torch.Generator(device="cuda").manual_seed(6)
+    B, T, sd = 4, 16384, 60
+    m = torch.randn(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=g)
+    v = torch.rand(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=g) + 0.1
+    v[:, :, sd:2 * sd] *= 1e-3
+    v[:, :, 2 * sd:] *= 1e-4
+    ref, _ = _hip.forward(m, v, STD3, algo=_hip.ALGO_GENERIC)
+    torch.cuda.synchronize()
+    hog = torch.randn(64 << 20, device="cuda")
+    side = torch.cuda.Stream()
+    outs = []
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                hog = torch.sin(hog) * 1.0001
+        o, st = _hip.forward(m, v, STD3, algo=_hip.ALGO_STRIP)
+        outs.append((o, st))
+    torch.cuda.synchronize()
+    scale = ref.abs().amax(dim=1, keepdim=True)
+    for o, st in outs:
+        assert int(st.abs().max().item()) == 0
+        assert float(((o - ref).abs() / scale).max()) <= 1e-7
