@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-check", action="store_true", help="profiling/ablation only: skip status and parity checks")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL all-gather of the outputs (reported separately)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` object (the other BASELINE configs and kernel variants, timed after the metric)")
+    ap.add_argument("--regions", type=int, default=9,
+                    help="extra timed regions of --steps launches after the official one; their median is reported beside it")
     return ap.parse_args()
 
 
@@ -171,6 +175,45 @@ def measured_traffic(B, T, sd, algo):
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def collect_secondary(rank, world, local_rank, copy_gbs):
+    """The other BASELINE configs and kernel variants, one entry per path: ms (HIP events on the launch stream, median),
+    the rate in the path's own unit, algorithmic bytes and their fraction of the 8 TB/s peak (`frac`) and of
+    the copy rate measured in this run (`frac_of_measured`).  N = 1: every path on rank 0.  N > 1: the per-GPU shares of
+    configs 4 and 5 on every rank, whole-job rates from the slowest rank."""
+    import torch
+    import torch.distributed as dist
+    from tools import bench_paths
+    lines = []
+    keys = "c2b,c2g,c3,c4,c5" if world == 1 else "c4q,c5q"
+    try:
+        bench_paths.run(only=keys, quick=False, sink=lines, device_index=local_rank)
+    except Exception as e:  # noqa: BLE001 -- the metric line must still be printed
+        lines.append({"path": "error", "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
+    out = {}
+    for ln in lines:
+        name = ln.pop("path")
+        if "roofline_frac" in ln:
+            ln["frac"] = ln.pop("roofline_frac")
+            if copy_gbs:
+                ln["frac_of_measured"] = ln["GBps"] / copy_gbs
+        out[name] = ln
+    if world > 1:
+        # whole-job figures: every rank ran the same per-GPU share; the job is as fast as its slowest rank
+        names = sorted(k for k in out if "ms" in out[k])
+        mine = torch.tensor([out[k]["ms"] for k in names], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        allms = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allms, mine)
+        worst = torch.stack(allms).max(dim=0).values.tolist()
+        for k, w in zip(names, worst):
+            e = out[k]
+            scale = e["ms"] / w
+            e["ms_slowest_rank"] = w
+            for f in ("frames_per_s", "pairs_per_s", "dp_cells_per_s", "GBps"):
+                if f in e and e[f] is not None:
+                    e[f + "_whole_job"] = e[f] * scale * world
+    return out if rank == 0 else None
 
 
 def _free_port():
@@ -348,6 +391,47 @@ def main():
     if rank == 0 and not dry:
         _, steady_ms, _, _ = timed(max(200, args.steps))
 
+    # the official region is short at the driver's --steps (a few ms): repeat it and report the spread beside it
+    regions = None
+    if not dry and args.regions > 0:
+        rs = []
+        for _ in range(args.regions):
+            barrier()
+            el, km, _, _ = timed(args.steps)
+            rs.append((el / args.steps * 1e3, km))
+        regions = {"k": len(rs), "ms_per_step_median": float(np.median([r[0] for r in rs])),
+                   "ms_per_step_min": float(min(r[0] for r in rs)), "ms_per_step_max": float(max(r[0] for r in rs)),
+                   "kernel_ms_median": float(np.median([r[1] for r in rs]))}
+
+    # what a plain copy kernel reaches on this box, in this run (the library's own streaming copy, 16 B per lane):
+    # the measured peak beside the nominal 8 TB/s
+    copy_gbs = None
+    if rank == 0 and not dry:
+        nb = 512 << 20
+        src = torch.empty(nb // 4, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            _hip.stream_copy(src, dst)
+        sync()
+        best = None
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                _hip.stream_copy(src, dst)
+            e1.record()
+            sync()
+            t = float(e0.elapsed_time(e1)) / 10
+            best = t if best is None else min(best, t)
+        assert torch.equal(src, dst)
+        copy_gbs = 2.0 * nb / (best * 1e-3) / 1e9
+        del src, dst
+
+    # the other BASELINE configs and kernel variants (after the metric; never part of `value`)
+    secondary = None
+    if not dry and not args.no_secondary:
+        secondary = collect_secondary(rank, world, local_rank, copy_gbs)
+
     if rank == 0:
         err = None
         if not dry:
@@ -380,6 +464,8 @@ def main():
                 "workload": "BASELINE configs[1]: %d utterances/GPU x T=%d x %d-dim mgc static+delta+delta-delta "
                             "(%d columns), float64, per-frame variances, std 3 windows; mlpg_hip_forward via C ABI"
                             % (B, T, sd, D),
+                "inputs": "means ~ N(0,1), variances ~ U(0.1, 1.1), generated in HBM by torch.Generator(seed 1234 + rank) "
+                          "(the distributions of SURVEY 8(d); not numpy RandomState(1234), which would mean a host copy)",
                 "batch_per_gpu": B, "frames": T, "static_dim": sd, "algo": args.algo,
                 "kernel": algo_names.get(args.algo, "?") + (" (= strip at this shape: mlpg::strip::strip_kernel)" if args.algo == 0 else ""),
                 "parallelism": "batch-sharded x%d, no data-path collective" % world,
@@ -390,8 +476,12 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                "peak_measured": copy_gbs,
+                "peak_measured_kernel": "mlpg_hip_stream_copy, 512 MiB -> 512 MiB, (read + written bytes) / best of 5 x 10 launches, same run",
+                "frac_of_measured": (achieved / copy_gbs) if (achieved and copy_gbs) else None,
                 "traffic": measured_traffic(B, T, sd, args.algo),
-                "traffic_unit": "bytes/launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/traffic.json)",
+                "traffic_unit": "bytes/launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE; taken from the committed rocprofv3 pass "
+                                "profiles/traffic.json of this command -- bench.py cannot run the PMC pass on itself)",
                 "kernel_ms": kern_ms,
                 "kernel_ms_steady": steady_ms,
                 "algorithmic_bytes": alg_bytes,
@@ -406,6 +496,10 @@ def main():
                                         "weak_scaling_efficiency": (frames / elapsed) / (world * solo)}
         if gather_ms is not None:
             res["allgather_ms"] = gather_ms
+        if regions is not None:
+            res["repeat_regions"] = regions
+        if secondary is not None:
+            res["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline and not dry:
             res["cpu_baseline"] = cpu_baseline(T, D, args.cpu_seconds)
         print(json.dumps(res), flush=True)

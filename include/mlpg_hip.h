@@ -66,6 +66,14 @@ int mlpg_hip_device_count(void);
 void mlpg_hip_shutdown(void);
 
 /*
+ * Measurement aid, not part of the reference's interface: a plain streaming copy of nbytes (a multiple of 16; both
+ * pointers 16-byte aligned device memory), 16 bytes per lane and access.  bench.py times it in the same run as the
+ * MLPG kernels to report the HBM rate a copy kernel reaches on the box ("fraction of both nominal and
+ * measured-copy peak").
+ */
+int mlpg_hip_stream_copy(int device, void *stream, const void *src, void *dst, size_t nbytes);
+
+/*
  * MLPG forward, batched.  Replaces paramgen.mlpg (paramgen/_mlpg.py:92-199)
  * and everything beneath it: build_win_mats (:13-50), build_poe (:53-89),
  * _bandmat/tensor.pyx dot_mv_plus_equals (:20-64) / dot_mm_plus_equals

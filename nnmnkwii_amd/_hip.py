@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 F32, F64 = 0, 1
-ABI_VERSION = 8               # mlpg_hip_abi_version() of the library this binding was written for
+ABI_VERSION = 9               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE, ALGO_STRIP = 0, 1, 2, 3
 
@@ -44,6 +44,7 @@ EXPORTS = (
     "mlpg_hip_fastdtw_l2",
     "mlpg_hip_gather_path",
     "mlpg_hip_gmm_convert",
+    "mlpg_hip_stream_copy",
 )
 
 
@@ -118,6 +119,8 @@ def lib():
         L.mlpg_hip_gmm_convert.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
         L.mlpg_hip_gather_path.restype = ci
         L.mlpg_hip_gather_path.argtypes = [ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+        L.mlpg_hip_stream_copy.restype = ci
+        L.mlpg_hip_stream_copy.argtypes = [ci, vp, vp, vp, ctypes.c_size_t]
         if L.mlpg_hip_abi_version() != ABI_VERSION:
             raise HipExtensionError("nnmnkwii_amd: %s has ABI version %d, this binding needs %d -- rebuild it with "
                                     "`python nnmnkwii_amd/csrc/build.py`" % (SO_PATH, L.mlpg_hip_abi_version(), ABI_VERSION))
@@ -550,6 +553,14 @@ def gather_path(src, path, path_len, Tout):
                                     _p(path_len), N, Tsrc, path.shape[1], D, Tout, _p(out))
     _check(rc, "mlpg_hip_gather_path")
     return out
+
+
+def stream_copy(src, dst):
+    """dst[...] = src[...] by the library's plain streaming-copy kernel (measurement aid: the HBM rate a copy reaches)."""
+    assert src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()
+    nbytes = src.numel() * src.element_size()
+    assert nbytes == dst.numel() * dst.element_size() and nbytes % 16 == 0
+    _check(lib().mlpg_hip_stream_copy(src.device.index, _stream(src.device), _p(src), _p(dst), nbytes), "mlpg_hip_stream_copy")
 
 
 def gmm_convert(x, posterior, mixture, mu_x, mu_y, A):

@@ -281,7 +281,7 @@ using namespace mlpg;
 
 extern "C" {
 
-__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 8; }
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 9; }
 
 __attribute__((visibility("default"))) const char *mlpg_hip_last_error(void) { return g_err; }
 
@@ -452,6 +452,21 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
     }
   if (int rc = join_side()) return rc;
   return 0;
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_stream_copy(int device, void *stream, const void *src, void *dst,
+                                                                size_t nbytes) {
+  if (nbytes == 0) return 0;
+  if (!src || !dst || (((uintptr_t)src | (uintptr_t)dst) & 15)) {
+    set_error("stream_copy: NULL or not 16-byte aligned pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  return launch_stream_copy((hipStream_t)stream, src, dst, nbytes);
 }
 
 __attribute__((visibility("default"))) int mlpg_hip_backward(int device, void *stream, int in_dtype, int out_dtype,

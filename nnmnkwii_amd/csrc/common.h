@@ -61,6 +61,7 @@ int launch_strip(hipStream_t s, int dtype, int out_dtype, bool backward, const P
                  int device);
 int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,
                      int ncols, void *dst, long ld_dst);
+int launch_stream_copy(hipStream_t s, const void *src, void *dst, size_t nbytes);
 int launch_modspec(hipStream_t s, int mode, const double *x, const double *ms, const double *ph, double *out,
                    double *out_ph, int B, int T, int D, int n, int ortho, int limit_bin, int log_domain);
 void host_api_shutdown();  // host_api.hip: streams, events, pinned and device staging buffers of the _host entry points

@@ -280,7 +280,31 @@ __global__ void copy_cols_kernel(const T *__restrict__ src, long ld_src, const i
   dst[(size_t)bt * ld_dst + c] = t < len ? src[(size_t)bt * ld_src + c] : (T)0;
 }
 
+// Plain streaming copy, 16 bytes per lane, ONE access per lane and a grid that covers the buffer: the yardstick for
+// "what a copy kernel reaches on this box" (bench.py roofline.peak_measured), nothing else.  Measured on MI355X
+// (tools/dbg/copy_sweep.hip, 512 MiB): this form 6.2 TB/s; persistent grid-stride loops of 1024 .. 16384 workgroups
+// 4.4 - 5.4 TB/s (nontemporal or not); hipMemcpyAsync 5.1 TB/s -- the dispatcher walking the buffer front to back keeps
+// the chip's accesses in a narrow moving window.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) stream_copy_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t n16) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+
 }  // namespace
+
+int launch_stream_copy(hipStream_t st, const void *src, void *dst, size_t nbytes) {
+  const size_t n16 = nbytes / 16;
+  if (n16 == 0) return 0;
+  const size_t blocks = (n16 + 255) / 256;
+  if (blocks > 0x7fffffffull) {
+    set_error("stream_copy: buffer too large");
+    return MLPG_HIP_EINVAL;
+  }
+  hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const f32x4 *)src, (f32x4 *)dst, n16);
+  MLPG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 
 int launch_copy_cols(hipStream_t st, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,
                      int ncols, void *dst, long ld_dst) {

@@ -48,10 +48,45 @@ def gpu_time(fn, steps=10, warmup=2):
 HBM_PEAK_GBS = 8000.0
 
 
+_SINK = None      # run(sink=[...]) collects the lines instead of printing them (bench.py's `secondary` object)
+
+
 def emit(**kw):
     if "GBps" in kw and kw["GBps"] is not None:
         kw["roofline_frac"] = kw["GBps"] / HBM_PEAK_GBS      # algorithmic bytes / time against the 8 TB/s HBM3E peak
-    print(json.dumps(kw), flush=True)
+    if _SINK is not None:
+        _SINK.append(kw)
+    else:
+        print(json.dumps(kw), flush=True)
+
+
+def fastdtw_window_cells(x, y, radius=1):
+    """DP cells fastdtw visits for one pair, over all levels of the halving pyramid (the kernel's work measure beside
+    bytes): the full matrix at the coarsest level, else the per-row intervals that upstream's __expand_window builds
+    from the coarser path (union of (2r+1)^2 neighbourhoods, each coarse cell = 2x2 fine cells, one run per row)."""
+    from oracle import dtw as OD
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    if len(x) < radius + 2 or len(y) < radius + 2:
+        return len(x) * len(y)
+    xs = (x[0:len(x) - len(x) % 2:2] + x[1:len(x):2][: len(x) // 2]) / 2
+    ys = (y[0:len(y) - len(y) % 2:2] + y[1:len(y):2][: len(y) // 2]) / 2
+    cells = fastdtw_window_cells(xs, ys, radius)
+    _, path = OD.fastdtw(xs, ys, radius)
+    lo = np.full(len(xs) + 2 * radius + 2, 1 << 30)
+    hi = np.full(len(xs) + 2 * radius + 2, -1)
+    for i, j in path:
+        for a in range(-radius, radius + 1):
+            r = i + a + radius
+            lo[r] = min(lo[r], j - radius)
+            hi[r] = max(hi[r], j + radius)
+    tot = 0
+    for i in range(len(x)):
+        r = i // 2 + radius
+        if hi[r] < 0:
+            continue
+        tot += min(2 * hi[r] + 1, len(y) - 1) - max(2 * lo[r], 0) + 1
+    return cells + tot
 
 
 def main():
@@ -59,6 +94,25 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
+    run(only=args.only, quick=args.quick)
+
+
+def run(only="", quick=False, sink=None, device_index=0):
+    """Run the selected paths (comma-separated keys, empty = all); with `sink` (a list) the result dicts are appended to
+    it instead of being printed."""
+    global _SINK
+    _SINK = sink
+    try:
+        _run(only, quick, device_index)
+    finally:
+        _SINK = None
+
+
+def _run(only, quick, device_index):
+    class _A(object):
+        pass
+    args = _A()
+    args.only, args.quick = only, quick
     import torch
     from nnmnkwii_amd import _hip
     from nnmnkwii_amd import autograd as AF
@@ -67,7 +121,7 @@ def main():
     from oracle import dtw as OD
     from oracle import mlpg as O
     O.build()
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", device_index)
     gen = torch.Generator(device=dev).manual_seed(1234)
     want = lambda k: not args.only or k in args.only.split(",")  # noqa: E731
 
@@ -254,8 +308,9 @@ def main():
              cpu_oracle_forward_only_frames_per_s=T / cpu_fwd,
              note="reference backward is O(T^2) dense solve_banded: 12.7 ms per static dim at T=500 (SURVEY 6)")
 
-    # ---- c4: DTW ----
-    if want("c4"):
+    # ---- c4: DTW (c4q: the kernel on one GPU's share only -- the per-rank leg of bench.py --gpus N) ----
+    if want("c4") or want("c4q"):
+        share_only = want("c4q") and not want("c4")
         N = 32 if args.quick else 128
         rng = np.random.RandomState(1234)
         Tx = Ty = 900
@@ -271,24 +326,27 @@ def main():
         pi, pj, pl, cost = _hip.fastdtw_l2(Xd, Yd, lenx, leny, 1)
         plen = pl.cpu().numpy()
         by = float(((lenx + leny).sum().item()) * 25 * 8 + 8 * plen.sum())
-        ncpu = 8 if args.quick else 32
+        ncpu = 2 if share_only else (8 if args.quick else 32)
         t0 = time.perf_counter()
         for n in range(ncpu):
             OD.fastdtw(X[n, :int(lenx[n])], Y[n, :int(leny[n])], 1)
         cpu_s = (time.perf_counter() - t0) / ncpu
-        ms_full = gpu_time(lambda: DTWAligner().transform((X, Y)), steps=3, warmup=1)
-        if not args.quick:
+        ms_full = None if share_only else gpu_time(lambda: DTWAligner().transform((X, Y)), steps=3, warmup=1)
+        # DP cells over all pyramid levels (mean of 8 pairs): the kernel is latency-bound, cells/s is its work rate
+        cells_per_pair = float(np.mean([fastdtw_window_cells(X[n, :int(lenx[n])], Y[n, :int(leny[n])], 1) for n in range(8)]))
+        if not args.quick and not share_only:
             # all 1024 pairs of config 4 on one GPU (the pairs repeated 8 times)
             X8, Y8 = Xd.repeat(8, 1, 1).contiguous(), Yd.repeat(8, 1, 1).contiguous()
             lx8, ly8 = lenx.repeat(8).contiguous(), leny.repeat(8).contiguous()
             ms8 = gpu_time(lambda: _hip.fastdtw_l2(X8, Y8, lx8, ly8, 1), steps=5)
             emit(path="c4-fastdtw-kernel-1024pairs", pairs=8 * N, ms=ms8, pairs_per_s=8 * N / ms8 * 1e3, alg_bytes=8 * by,
-                 GBps=8 * by / ms8 / 1e6)
+                 GBps=8 * by / ms8 / 1e6, dp_cells_per_pair=cells_per_pair, dp_cells_per_s=cells_per_pair * 8 * N / ms8 * 1e3)
             del X8, Y8
             # the same 1024 pairs from HOST memory through mlpg_hip_fastdtw_host (device-side trim, chunks of pairs
             # on two streams, PCIe-inclusive wall clock), pageable and pinned inputs
-            Xh, Yh = np.tile(X, (8, 1, 1)), np.tile(Y, (8, 1, 1))
-            for nm, (a_, b_) in (("pageable", (Xh, Yh)), ("pinned", (_hip.pinned_empty(Xh.shape), _hip.pinned_empty(Yh.shape)))):
+            host_legs = (not args.only) or "c4h" in args.only.split(",")
+            Xh, Yh = (np.tile(X, (8, 1, 1)), np.tile(Y, (8, 1, 1))) if host_legs else (None, None)
+            for nm, (a_, b_) in () if not host_legs else (("pageable", (Xh, Yh)), ("pinned", (_hip.pinned_empty(Xh.shape), _hip.pinned_empty(Yh.shape)))):
                 if nm == "pinned":
                     a_[...] = Xh
                     b_[...] = Yh
@@ -300,7 +358,9 @@ def main():
                 emit(path="c4h-fastdtw-host-1024pairs-" + nm, pairs=8 * N, ms=wall, pairs_per_s=8 * N / wall * 1e3,
                      host_bytes=float(Xh.nbytes + Yh.nbytes))
         emit(path="c4-fastdtw-kernel", pairs=N, ms=ms, pairs_per_s=N / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6,
-             cpu_oracle_c_pairs_per_s=1.0 / cpu_s, transform_numpy_to_numpy_ms=ms_full)
+             dp_cells_per_pair=cells_per_pair, dp_cells_per_s=cells_per_pair * N / ms * 1e3,
+             cpu_oracle_c_pairs_per_s=1.0 / cpu_s, transform_numpy_to_numpy_ms=ms_full,
+             note="paths bit-exact vs the oracle's restatement of third-party fastdtw (parity unpinned: the package is absent)")
 
     # ---- ms: modulation-spectrum smoothing of the config-2 output batch (the step after MLPG) ----
     if want("ms"):
@@ -334,11 +394,12 @@ def main():
              cpu_numpy_fft_frames_per_s=T / cpu3)
         del x
 
-    # ---- c5: Merlin-style multi-stream ----
-    if want("c5"):
+    # ---- c5: Merlin-style multi-stream (c5q: the one-call form only) ----
+    if want("c5") or want("c5q"):
         B, T = (128 if args.quick else 512), 2000
-        tot_ms, tot_by = 0.0, 0.0
-        for name, sd in (("mgc", 60), ("lf0", 1), ("bap", 5)):
+        tot_ms, tot_by = 0.0, sum(56.0 * sd_ * B * T for sd_ in (60, 1, 5))
+        tot_by0, tot_by = tot_by, 0.0
+        for name, sd in (("mgc", 60), ("lf0", 1), ("bap", 5)) if want("c5") else ():
             m = torch.randn(B, T, 3 * sd, dtype=torch.float64, device=dev, generator=gen)
             v = torch.rand(B, T, 3 * sd, dtype=torch.float64, device=dev, generator=gen) + 0.1
             ms = gpu_time(lambda: _hip.forward(m, v, WINDOWS, want_status=False), steps=5)
@@ -347,8 +408,10 @@ def main():
             tot_ms += ms
             tot_by += by
             del m, v
-        emit(path="c5-all-streams", batch=B, ms=tot_ms, frames_per_s=B * T / tot_ms * 1e3, alg_bytes=tot_by,
-             GBps=tot_by / tot_ms / 1e6)
+        if want("c5"):
+            emit(path="c5-all-streams", batch=B, ms=tot_ms, frames_per_s=B * T / tot_ms * 1e3, alg_bytes=tot_by,
+                 GBps=tot_by / tot_ms / 1e6)
+        tot_by = tot_by0
         # the same three streams consumed in place from ONE (B, T, 198) batch: mlpg_hip_forward_streams
         m = torch.randn(B, T, 198, dtype=torch.float64, device=dev, generator=gen)
         v = torch.rand(B, T, 198, dtype=torch.float64, device=dev, generator=gen) + 0.1
