@@ -58,6 +58,8 @@ extern "C" {
 #define MLPG_HIP_ALGO_GENERIC 1 /* thread-per-system, factor in HBM scratch       */
 #define MLPG_HIP_ALGO_WAVE 2    /* wave-per-system, factor in registers           */
 #define MLPG_HIP_ALGO_STRIP 3   /* lane-per-static-dim, wavefront per 16-frame chunk, any T */
+#define MLPG_HIP_ALGO_PIPE 4    /* the strip scheme software-pipelined: 3 chunk wavefronts + 1 chain wavefront per CU,
+                                   level 1 of item s+1 runs under the level-2/3 latency chain of item s (3 windows) */
 
 int mlpg_hip_abi_version(void);
 const char *mlpg_hip_last_error(void);

@@ -171,7 +171,7 @@ int check_common(int B, int Tmax, int D, int nw) {
 // ones, generic kernel for window extents > 1 or utterances longer than either supports.
 int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool backward, const Problem &p,
                    const WinSet &ws, int device) {
-  if (algo < MLPG_HIP_ALGO_AUTO || algo > MLPG_HIP_ALGO_STRIP) {
+  if (algo < MLPG_HIP_ALGO_AUTO || algo > MLPG_HIP_ALGO_PIPE) {
     set_error("unknown algo %d", algo);
     return MLPG_HIP_EINVAL;
   }
@@ -183,10 +183,20 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     set_error("MLPG_HIP_ALGO_STRIP does not support this problem (T=%d, half-bandwidth %d)", p.Tmax, ws.q);
     return MLPG_HIP_EINVAL;
   }
+  if (algo == MLPG_HIP_ALGO_PIPE && !pipe_supported(p, ws)) {
+    // the pipelined kernel is the strip scheme for the usual three windows; other window sets of extent <= 1 run on
+    // the strip kernel itself
+    if (!strip_supported(p, ws)) {
+      set_error("MLPG_HIP_ALGO_PIPE does not support this problem (T=%d, %d windows, half-bandwidth %d)", p.Tmax, ws.nw, ws.q);
+      return MLPG_HIP_EINVAL;
+    }
+    algo = MLPG_HIP_ALGO_STRIP;
+  }
   if (algo == MLPG_HIP_ALGO_AUTO) {
     if (strip_preferred(p, ws, backward, in_dtype) || (strip_supported(p, ws) && !wave_supported(p, ws))) algo = MLPG_HIP_ALGO_STRIP;
     else algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
   }
+  if (algo == MLPG_HIP_ALGO_PIPE) return launch_pipe(st, in_dtype, out_dtype, backward, p, ws, device);
   if (algo == MLPG_HIP_ALGO_STRIP) return launch_strip(st, in_dtype, out_dtype, backward, p, ws, device);
   if (algo == MLPG_HIP_ALGO_WAVE) return launch_wave(st, in_dtype, out_dtype, backward, p, ws, device);
   return launch_generic(st, in_dtype, out_dtype, backward, p, ws, device);

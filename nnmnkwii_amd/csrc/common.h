@@ -59,6 +59,8 @@ bool strip_supported(const Problem &p, const WinSet &w);
 bool strip_preferred(const Problem &p, const WinSet &w, bool backward, int in_dtype);
 int launch_strip(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
                  int device);
+bool pipe_supported(const Problem &p, const WinSet &w);
+int launch_pipe(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
 int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,
                      int ncols, void *dst, long ld_dst);
 int launch_stream_copy(hipStream_t s, const void *src, void *dst, size_t nbytes);

@@ -1,0 +1,8 @@
+// pipelined strip MLPG kernel: forward, double
+#include "mlpg_pipe_impl.h"
+namespace mlpg {
+int launch_pipe_fwd_f64(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl) {
+  (void)out_dtype;
+  return pipe::launch_t<double, double, false>(st, p, ws, scratch, R, ndg, dgw, zero_ctrl);
+}
+}  // namespace mlpg

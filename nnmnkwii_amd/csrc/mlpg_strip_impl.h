@@ -86,6 +86,12 @@ constexpr int kCtrlLine = 32;
 #ifndef MLPG_STRIP_RING_F32
 #define MLPG_STRIP_RING_F32 6
 #endif
+#ifndef MLPG_STRIP_SCHED_RELAX
+#define MLPG_STRIP_SCHED_RELAX 0
+#endif
+#ifndef MLPG_STRIP_RING_F64
+#define MLPG_STRIP_RING_F64 6
+#endif
 #ifndef MLPG_STRIP_ROUTE1_TOL
 #define MLPG_STRIP_ROUTE1_TOL 0.0  // own transfer factor below which a 3-strip window is tried first (0: never)
 #endif
@@ -469,7 +475,7 @@ __device__ __forceinline__ bool eliminate(double (&Pd)[kM], double (&P1)[kM], do
 // reached yet hold nothing, so the ring and the accumulators never peak together: this is what lets the loads
 // stream without spilling.  Arithmetic per entry: the same sums in a different order (frame-major).
 template <typename TIN>
-struct RingDepth { static constexpr int value = 6; };   // frames of loads in flight per wavefront (float64: 36 loads, 18 KB)
+struct RingDepth { static constexpr int value = MLPG_STRIP_RING_F64; };   // frames of loads in flight per wavefront (float64: 36 loads, 18 KB)
 template <>
 struct RingDepth<float> { static constexpr int value = MLPG_STRIP_RING_F32; };  // float32 values take half the registers
 template <typename TIN, bool BWD, int VM, bool EDGE, int NW>
@@ -508,8 +514,14 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
       int t = f0 + i;
       if (EDGE) t = t < cl[w] ? cl[w] : (t >= ch[w] ? ch[w] - 1 : t);
       const unsigned soff = (unsigned)t * ldi_bytes + (unsigned)w * win_bytes;
+#ifdef MLPG_STRIP_FAKE_LOADS  // timing experiment only: no memory traffic, opaque per-lane values instead
+      (void)soff;
+      if (VM == MLPG_HIP_VAR_FRAME) { TIN x = (TIN)1.5; asm volatile("" : "+v"(x)); v[w] = x; }
+      if (!BWD) { TIN x = (TIN)0.25; asm volatile("" : "+v"(x)); m[w] = x; }
+#else
       if (VM == MLPG_HIP_VAR_FRAME) v[w] = ld_row<TIN>(vrs, soff, loff);
       if (!BWD) m[w] = ld_row<TIN>(mrs, soff, loff);
+#endif
     }
   };
   auto accumulate_frame = [&](const TIN (&v)[NW], const TIN (&m)[NW], const int i) __attribute__((always_inline)) {
@@ -617,17 +629,22 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
   }
   __builtin_amdgcn_sched_barrier(0);
   // step S handles frame I = S - 1 in ring slot S % 6: accumulate, refill with frame I + 6, eliminate row I - 1
+  // MLPG_STRIP_SCHED_RELAX (A/B switch): bit 0 drops the barrier after the accumulation, bit 1 the one after the
+  // refill, bit 2 the one after the elimination step (one wavefront per SIMD wants the scheduler to interleave the
+  // elimination's dependent chain with the next frame's accumulation; two per SIMD did not care)
+#define STRIP_SB(bit) do { if (!((MLPG_STRIP_SCHED_RELAX) & (bit))) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define STRIP_STEP(S)                                                                   \
   accumulate_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1);                            \
-  __builtin_amdgcn_sched_barrier(0);                                                    \
+  STRIP_SB(1);                                                                          \
   if ((S) + kRing < kM + 2) { load_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1 + kRing); } \
-  __builtin_amdgcn_sched_barrier(0);                                                    \
+  STRIP_SB(2);                                                                          \
   if ((S)-2 >= 0 && (S)-2 < kN) { elim_row((S)-2); }                                    \
-  __builtin_amdgcn_sched_barrier(0);
+  STRIP_SB(4);
   STRIP_STEP(0) STRIP_STEP(1) STRIP_STEP(2) STRIP_STEP(3) STRIP_STEP(4) STRIP_STEP(5)
   STRIP_STEP(6) STRIP_STEP(7) STRIP_STEP(8) STRIP_STEP(9) STRIP_STEP(10) STRIP_STEP(11)
   STRIP_STEP(12) STRIP_STEP(13) STRIP_STEP(14) STRIP_STEP(15) STRIP_STEP(16) STRIP_STEP(17)
 #undef STRIP_STEP
+#undef STRIP_SB
   if (EDGE) {
     fix_row(kN);
     fix_row(kN + 1);
