@@ -37,6 +37,17 @@
 #define PIPE_TICK(k) do {} while (0)
 #endif
 
+#ifdef MLPG_PIPE_TRACE
+// realtime stamps (100 MHz, comparable across CUs) per item into the status array: workgroups 0 .. 31, 24 items, 10 stamps
+#define PIPE_STAMP(item, k)                                                                                     \
+  do {                                                                                                          \
+    if (lane == 0 && p.status && blockIdx.x < 32 && (item) < 24)                                                \
+      p.status[(blockIdx.x * 24 + (item)) * 10 + (k)] = (int)((long long)__builtin_amdgcn_s_memrealtime() & 0x3fffffff); \
+  } while (0)
+#else
+#define PIPE_STAMP(item, k) do {} while (0)
+#endif
+
 namespace mlpg {
 namespace pipe {
 
@@ -70,7 +81,8 @@ constexpr size_t oOwn = oRec + 2 * kC * kRecBytes1;                    // [2][kR
 constexpr size_t oFac = oOwn + 2 * kRecBytes1;                         // [2][kC-1][kFac][64]
 constexpr size_t oU = oFac + 2 * (size_t)(kC - 1) * kFac * 64 * 8;     // [2][kC+1][2][64]   separator solutions
 constexpr size_t oStage = oU + 2 * (size_t)(kC + 1) * 2 * 64 * 8;      // [kStage][kRec][64] level-3 staging (chain wavefront)
-constexpr size_t oCtl = oStage + (size_t)kStage * kRecBytes1;          // ints
+constexpr size_t oY = oStage + (size_t)kStage * kRecBytes1;            // [2][kC][kY=5][64]  right-hand sums, by item parity and consumer
+constexpr size_t oCtl = oY + (2 * (size_t)kC + 2) * 5 * 64 * 8;        // ints   (+ a write-only slot and a slot of zeros)
 constexpr size_t kLdsBytes = oCtl + 64 * sizeof(int);
 static_assert(kLdsBytes <= 160 * 1024, "LDS");
 
@@ -81,6 +93,7 @@ enum {
   cSeqRec = 5,    // [kC] level-1 records written by chunk wavefront w
   cSeqU = 8,      // items whose separator solutions have been posted
   cTimedOut = 9,  // [2] by item parity: a wait of this item timed out
+  cSeqY = 12,     // [kC] hand-overs written by chunk wavefront w (to wavefront w-1)
 };
 
 __device__ __forceinline__ int lds_ld(const int *p) {
@@ -114,6 +127,305 @@ __device__ __forceinline__ Item decode(const Problem &p, const Args &a, int id) 
   return it;
 }
 
+
+// ---- level 1 of the pipelined kernel ----------------------------------------------------------------
+// One chunk wavefront owns the ROWS f0 .. f0+M-1 of its system (lane = static dim) and loads the FRAMES f0-1 .. f0+M-2:
+// frame t feeds rows t-1, t, t+1, so the only contributions the wavefront cannot form itself are those of frames
+// f0+M-1 and f0+M to its last two rows (its separator).  Those frames are the first two frames of the NEXT chunk
+// wavefront of the strip, which hands the five sums over (Y: LDS, one sequence word per producer) as soon as it has
+// seen them -- at the START of its stream, while the consumer needs them at the END of its own: nobody waits.  Only
+// the strip's last chunk wavefront loads its two right-hand frames itself (they belong to another workgroup).  A
+// strip of 48 frames is read as 50 frames; the strip kernel read 54 (18 per wavefront).
+// The stream is uniform code for all wavefronts: a wavefront that gets its right-hand sums from LDS still issues the
+// two loads (of its own last frame: a cache hit, no HBM traffic) and weighs them with 0.
+//
+// The stream is split into a PROLOGUE (the first kRing frames' loads: no arithmetic, needs nothing but the ticket)
+// and the BODY, so that the prologue of item s+1 is in flight while the wavefront back-substitutes and stores item s-1.
+#ifndef MLPG_PIPE_RING_F64
+#define MLPG_PIPE_RING_F64 6
+#endif
+#ifndef MLPG_PIPE_RING_F32
+#define MLPG_PIPE_RING_F32 8
+#endif
+template <typename TIN> struct PipeRing { static constexpr int value = MLPG_PIPE_RING_F64; };
+template <> struct PipeRing<float> { static constexpr int value = MLPG_PIPE_RING_F32; };
+constexpr int kY = 5;  // doubles per lane handed to the previous chunk wavefront: Pd[M-2], P1[M-2], rhs[M-2], Pd[M-1], rhs[M-1]
+
+template <typename TIN>
+struct L1Args {  // wave-uniform description of one chunk (everything the stream needs besides the ring)
+  __amdgpu_buffer_rsrc_t mrs, vrs, grs;
+  const TIN *vglob;
+  unsigned loff, ldi_bytes, win_bytes, ldg_bytes;
+  int f0, T, mw;
+  int last;      // this wavefront loads its two right-hand frames itself (last chunk of the strip)
+  int lo[3], hi[3], cl[3], ch[3];  // live frames [lo, hi) of each window, load clamp [cl, ch)
+};
+template <typename TIN>
+__device__ __forceinline__ void l1_windows(L1Args<TIN> &A) {
+  const int T = A.T, mw = A.mw;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    A.lo[w] = w ? mw : 0;
+    A.hi[w] = w ? (mw != 0 && T - mw > mw ? T - mw : mw) : T;
+    A.cl[w] = A.lo[w] < T ? A.lo[w] : T - 1;   // a window without live frames still loads (frame cl) and weighs 0
+    A.ch[w] = A.hi[w] > A.cl[w] ? A.hi[w] : A.cl[w] + 1;
+  }
+}
+// frame i (relative to f0) of window w -> the row it is loaded from
+template <typename TIN, bool CLAMP>
+__device__ __forceinline__ unsigned l1_soff(const L1Args<TIN> &A, const int i, const int w) {
+  int t = A.f0 + i;
+  if (i >= kM - 1) t = A.last ? t : A.f0 + kM - 2;  // right-hand frames of a wavefront that gets their sums from LDS
+  if (CLAMP) t = t < A.cl[w] ? A.cl[w] : (t >= A.ch[w] ? A.ch[w] - 1 : t);
+  return (unsigned)t * A.ldi_bytes + (unsigned)w * A.win_bytes;
+}
+template <typename TIN, bool BWD, int VM, bool CLAMP>
+__device__ __forceinline__ void l1_load_frame(const L1Args<TIN> &A, TIN (&v)[3], TIN (&m)[3], const int i) {
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const unsigned soff = l1_soff<TIN, CLAMP>(A, i, w);
+    if (VM == MLPG_HIP_VAR_FRAME) v[w] = ld_row<TIN>(A.vrs, soff, A.loff);
+    if (!BWD) m[w] = ld_row<TIN>(A.mrs, soff, A.loff);
+  }
+}
+template <typename TIN, bool BWD, int VM, int RING>
+__device__ __forceinline__ void l1_prologue(const L1Args<TIN> &A, TIN (&rv)[RING][3], TIN (&rm)[RING][3]) {
+#pragma unroll
+  for (int sl = 0; sl < RING; ++sl) l1_load_frame<TIN, BWD, VM, true>(A, rv[sl], rm[sl], sl - 1);
+}
+
+// The body: accumulate frame by frame, refill the ring, eliminate row i as soon as frame i+1 is in (as
+// strip::assemble_eliminate).  y_out / y_in: this lane's slots of the LDS hand-over (producer: predecessor's slot).
+template <typename TIN, bool BWD, int VM, bool EDGE, int RING>
+__device__ __forceinline__ bool l1_body(const L1Args<TIN> &A, TIN (&rv)[RING][3], TIN (&rm)[RING][3], const double (*wc)[9],
+                                        const double one, double *y_out, int *y_out_seq, const double *y_in,
+                                        const int *y_in_seq, const int seq, const int lane, double (&Pd)[kM], double (&P1)[kM],
+                                        double (&P2)[kM], double (&rhs)[kM], double &ca, double &cb, double &cc,
+                                        double (&rec)[kRec]) {
+  const int f0 = A.f0, T = A.T;
+  WinCoef k[3];
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    k[w] = win_coef<TIN, VM>(wc, w, A.vglob, (int)(A.win_bytes / sizeof(TIN)));
+    if (VM == MLPG_HIP_VAR_UNIT) {  // the unit precision as an opaque per-lane value (see strip::assemble_eliminate)
+      double t1 = one;
+      asm volatile("" : "+v"(t1));
+      k[w].tau_glob = t1;
+    }
+  }
+  const double wR = A.last ? 1.0 : 0.0;  // weight of the two right-hand frames
+  double y[kY];
+  auto accumulate_frame = [&](const TIN (&v)[3], const TIN (&m)[3], const int i) __attribute__((always_inline)) {
+    const int t = f0 + i;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      double tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[w]) : k[w].tau_glob;
+      if (EDGE) tau *= (t >= A.lo[w] && t < A.hi[w]) ? 1.0 : 0.0;  // wave-uniform weight
+      if (i >= kM - 1) tau *= wR;
+      double tm = 0.0;
+      if (!BWD) tm = tau * (double)m[w];
+      const bool first = w == 0;  // first contribution to: Pd, rhs of row t+1; P1 of row t; P2 of row t-1
+      if (i >= 0 && i < kM) {  // row t
+        Pd[i] += k[w].c00 * tau;
+        if (i < kM - 1) P1[i] = first ? k[w].cp0 * tau : P1[i] + k[w].cp0 * tau;
+        if (!BWD) rhs[i] += k[w].c0 * tm;
+      }
+      if (i + 1 >= 0 && i + 1 < kM) {  // row t+1
+        Pd[i + 1] = first ? k[w].cpp * tau : Pd[i + 1] + k[w].cpp * tau;
+        if (!BWD) rhs[i + 1] = first ? k[w].cp * tm : rhs[i + 1] + k[w].cp * tm;
+      }
+      if (i - 1 >= 0 && i - 1 < kM) {  // row t-1
+        Pd[i - 1] += k[w].cmm * tau;
+        if (i - 1 < kM - 1) P1[i - 1] += k[w].c0m * tau;
+        if (i - 1 < kM - 2) P2[i - 1] = first ? k[w].cpm * tau : P2[i - 1] + k[w].cpm * tau;
+        if (!BWD) rhs[i - 1] += k[w].cm * tm;
+      }
+      // coupling of the chunk's first two rows to the previous chunk's separator:
+      // ca = P[f0, f0-2], cb = P[f0, f0-1], cc = P[f0+1, f0-1]
+      if (i == -1) {
+        ca = first ? k[w].cpm * tau : ca + k[w].cpm * tau;
+        cb = first ? k[w].cp0 * tau : cb + k[w].cp0 * tau;
+        // ... and what this frame adds to the PREVIOUS chunk's rows M-2 (t-1) and M-1 (t)
+        y[0] = first ? k[w].cmm * tau : y[0] + k[w].cmm * tau;
+        y[1] = first ? k[w].c0m * tau : y[1] + k[w].c0m * tau;
+        y[3] = first ? k[w].c00 * tau : y[3] + k[w].c00 * tau;
+        if (!BWD) {
+          y[2] = first ? k[w].cm * tm : y[2] + k[w].cm * tm;
+          y[4] = first ? k[w].c0 * tm : y[4] + k[w].c0 * tm;
+        }
+      }
+      if (i == 0) {
+        cb += k[w].c0m * tau;
+        cc = first ? k[w].cpm * tau : cc + k[w].cpm * tau;
+        y[3] += k[w].cmm * tau;  // the previous chunk's row M-1 is this frame's row t-1
+        if (!BWD) y[4] += k[w].cm * tm;
+      }
+    }
+  };
+  auto fix_row = [&](const int i) __attribute__((always_inline)) {
+    const int f = f0 + i;
+    const double live = f < T ? 1.0 : 0.0, live1 = f + 1 < T ? 1.0 : 0.0, live2 = f + 2 < T ? 1.0 : 0.0;
+    Pd[i] = Pd[i] * live + (1.0 - live);
+    if (i < kM - 1) P1[i] *= live1;
+    if (i < kM - 2) P2[i] *= live2;
+    rhs[i] *= live;
+  };
+  bool bad = false;
+  double t00 = 0.0, t01 = 0.0, t11 = 0.0, h0 = 0.0, h1 = 0.0;
+  double g1 = 0.0, g2 = 0.0, va1 = 0.0, va2 = 0.0, vb1 = 0.0, vb2 = 0.0;
+  double l1p = 0.0, l2p = 0.0, l2pp = 0.0;
+  auto elim_row = [&](const int i) __attribute__((always_inline)) {
+    if (EDGE) {
+      fix_row(i);
+      if (i == 0) {
+        const double keep = (f0 == 0 || f0 >= T) ? 0.0 : 1.0, keepc = f0 + 1 >= T ? 0.0 : 1.0;
+        ca *= keep;
+        cb *= keep;
+        cc *= keep * keepc;
+      }
+    }
+    const double dd = Pd[i];
+    bad |= !(dd > 0.0);
+    const double dinv = fast_rcp(dd);
+    const double e1 = P1[i], e2 = P2[i];
+    const double l1 = e1 * dinv, l2 = e2 * dinv;
+    Pd[i + 1] -= l1 * e1;
+    P1[i + 1] -= l2 * e1;
+    Pd[i + 2] -= l2 * e2;
+    const double gi = rhs[i] - l1p * g1 - l2pp * g2;
+    const double ba = (i == 0) ? ca : 0.0;
+    const double bb = (i == 0) ? cb : ((i == 1) ? cc : 0.0);
+    const double va = ba - l1p * va1 - l2pp * va2;
+    const double vb = bb - l1p * vb1 - l2pp * vb2;
+    const double wa = va * dinv, wb = vb * dinv;
+    t00 += wa * va;
+    t01 += wa * vb;
+    t11 += wb * vb;
+    h0 += wa * gi;
+    h1 += wb * gi;
+    Pd[i] = dinv;
+    P1[i] = l1;
+    P2[i] = l2;
+    rhs[i] = gi;
+    g2 = g1; g1 = gi;
+    va2 = va1; va1 = va;
+    vb2 = vb1; vb1 = vb;
+    l2pp = l2p; l2p = l2; l1p = l1;
+  };
+
+  static_assert(RING >= 2 && RING <= kM + 2, "ring depth");
+  if (BWD) {
+#pragma unroll
+    for (int i = 0; i < kM; ++i) {
+      int t = f0 + i;
+      t = t >= T ? T - 1 : t;
+      rhs[i] = (double)ld_row<TIN>(A.grs, (unsigned)t * A.ldg_bytes, A.loff);  // rows >= T are reset by fix_row
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // step S handles frame I = S - 1 in ring slot S % RING: accumulate, refill with frame I + RING, eliminate row I - 1
+#define PIPE_STEP(S)                                                                                   \
+  accumulate_frame(rv[(S) % RING], rm[(S) % RING], (S)-1);                                             \
+  __builtin_amdgcn_sched_barrier(0);                                                                   \
+  if ((S) + RING < kM + 2) { l1_load_frame<TIN, BWD, VM, EDGE>(A, rv[(S) % RING], rm[(S) % RING], (S)-1 + RING); } \
+  __builtin_amdgcn_sched_barrier(0);                                                                   \
+  if ((S) == 1) {                                                                                      \
+    /* frames f0-1 and f0 are in: hand their sums to the previous chunk wavefront (the strip's first */ \
+    /* wavefront writes into a slot nobody reads: no branch in the stream) */                          \
+    _Pragma("unroll")                                                                                  \
+    for (int q = 0; q < kY; ++q) y_out[q * 64] = (BWD && (q == 2 || q == 4)) ? 0.0 : y[q];             \
+    lds_order();                                                                                       \
+    if (lane == 0) lds_st(y_out_seq, seq + 1);                                                         \
+  }                                                                                                    \
+  if ((S)-2 >= 0 && (S)-2 < kN) { elim_row((S)-2); }                                                   \
+  __builtin_amdgcn_sched_barrier(0);
+  PIPE_STEP(0) PIPE_STEP(1) PIPE_STEP(2) PIPE_STEP(3) PIPE_STEP(4) PIPE_STEP(5)
+  PIPE_STEP(6) PIPE_STEP(7) PIPE_STEP(8) PIPE_STEP(9) PIPE_STEP(10) PIPE_STEP(11)
+  PIPE_STEP(12) PIPE_STEP(13) PIPE_STEP(14) PIPE_STEP(15) PIPE_STEP(16) PIPE_STEP(17)
+#undef PIPE_STEP
+  static_assert(kM == 16, "the stream above is written out for 16-frame chunks");
+  {
+    // the right-hand sums come from the next chunk wavefront (it wrote them at the start of its own stream); the
+    // strip's last wavefront formed them itself: it looks at its own sequence word and adds a slot of zeros
+    while (lds_ld(y_in_seq) <= seq) __builtin_amdgcn_s_sleep(1);
+    lds_order();
+    Pd[kM - 2] += y_in[0 * 64];
+    P1[kM - 2] += y_in[1 * 64];
+    Pd[kM - 1] += y_in[3 * 64];
+    if (!BWD) {
+      rhs[kM - 2] += y_in[2 * 64];
+      rhs[kM - 1] += y_in[4 * 64];
+    }
+  }
+  if (EDGE) {
+    fix_row(kN);
+    fix_row(kN + 1);
+  }
+  rec[rT00] = t00; rec[rT01] = t01; rec[rT11] = t11; rec[rH0] = h0; rec[rH1] = h1;
+  rec[rD11] = Pd[kN]; rec[rD12] = P1[kN]; rec[rD22] = Pd[kN + 1];
+  rec[rF1] = rhs[kN] - (l1p * g1 + l2pp * g2);
+  rec[rF2] = rhs[kN + 1] - l2p * g1;
+  rec[rL11] = -(l1p * va1 + l2pp * va2);
+  rec[rL12] = -(l1p * vb1 + l2pp * vb2);
+  rec[rL21] = -(l2p * va1);
+  rec[rL22] = -(l2p * vb1);
+  return bad;
+}
+
+
+// ---- explicit parking in accumulation registers ------------------------------------------------------
+// One wavefront per SIMD owns 512 registers per lane, of which only 256 (the architectural VGPRs) can be operands.
+// The factor of the item that waits for its separators is parked in the other 256 (AGPRs) BY HAND: values of
+// register class "a" that the allocator cannot mistake for something worth keeping in a VGPR.  (Left to itself
+// -- plain double arrays live across the loop -- it shuffled 800 accvgpr moves per item and still spilled to scratch.)
+struct Parked { unsigned lo, hi; };
+__device__ __forceinline__ Parked park(const double x) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned l = (unsigned)u, h = (unsigned)(u >> 32);
+  Parked r;
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(r.lo) : "v"(l));
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(r.hi) : "v"(h));
+  return r;
+}
+__device__ __forceinline__ double unpark(const Parked &q) {
+  unsigned l, h;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(q.lo));
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(q.hi));
+  return __longlong_as_double((long long)(((unsigned long long)h << 32) | l));
+}
+struct ParkedFactor {  // rows 0 .. kN-1 of 1/d, l1, l2, g and the three couplings
+  Parked d[kN], l1[kN], l2[kN], g[kN], ca, cb, cc;
+};
+
+// back-substitution of one chunk straight from the parked factor (strip::backsub): x[0..kM) on return
+__device__ __forceinline__ void backsub_parked(const ParkedFactor &F, double (&x)[kM], const V2 ul, const V2 u) {
+  {
+    const double ca = unpark(F.ca), cb = unpark(F.cb), cc = unpark(F.cc);
+    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+#pragma unroll
+    for (int i = 0; i < kN; ++i) {
+      const double ba = (i == 0) ? ca : 0.0;
+      const double bb = (i == 0) ? cb : ((i == 1) ? cc : 0.0);
+      const double va = ba - q1 * a1 - q3 * a2;
+      const double vb = bb - q1 * b1 - q3 * b2;
+      x[i] = unpark(F.g[i]) - (va * ul.x + vb * ul.y);
+      a2 = a1; a1 = va;
+      b2 = b1; b1 = vb;
+      q3 = q2; q2 = unpark(F.l2[i]); q1 = unpark(F.l1[i]);
+    }
+  }
+  double x1 = u.x, x2 = u.y;
+#pragma unroll
+  for (int i = kN - 1; i >= 0; --i) {
+    const double xi = x[i] * unpark(F.d[i]) - unpark(F.l1[i]) * x1 - unpark(F.l2[i]) * x2;
+    x[i] = xi;
+    x2 = x1;
+    x1 = xi;
+  }
+  x[kN] = u.x;
+  x[kN + 1] = u.y;
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------
 template <typename TIN, typename TOUT, bool BWD, int VM>
 __global__ __launch_bounds__(kThreads, 1) void pipe_kernel(Problem p, WinSet ws, Args a) {
@@ -123,6 +435,7 @@ __global__ __launch_bounds__(kThreads, 1) void pipe_kernel(Problem p, WinSet ws,
   double *lds_fac = (double *)(smem + oFac);
   double *lds_u = (double *)(smem + oU);
   double *lds_stage = (double *)(smem + oStage);
+  double *lds_y = (double *)(smem + oY);
   int *ctl = (int *)(smem + oCtl);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -132,37 +445,76 @@ __global__ __launch_bounds__(kThreads, 1) void pipe_kernel(Problem p, WinSet ws,
   const long ldi = p.ld_in, ldg = p.ld_gout, ldo = p.ld_out;
 
   if (tid < 64) ctl[tid] = 0;
+  for (int q = tid; q < kY * 64; q += kThreads) lds_y[(size_t)(2 * kC + 1) * kY * 64 + q] = 0.0;  // the slot of zeros
   __syncthreads();
 
   if (wv < kC) {
     // =============================== chunk wavefront ===============================
-    double Fd[kM], F1[kM], F2[kM], Fr[kM], Fa = 0.0, Fb = 0.0, Fc = 0.0;  // factor of the item awaiting its separators
+    constexpr int kRing = PipeRing<TIN>::value;
+    const unsigned ldi_bytes = (unsigned)ldi * (unsigned)sizeof(TIN), win_bytes = (unsigned)sd * (unsigned)sizeof(TIN);
+    // wave-uniform description of a chunk of item `it` for this wavefront
+    auto make_args = [&](const Item &it) __attribute__((always_inline)) {
+      L1Args<TIN> A;
+      const bool lane_ok = lane < it.nd;
+      const int d = it.d0 + (lane_ok ? lane : it.nd - 1);  // idle lanes shadow the group's last dim (never stored)
+      A.loff = (unsigned)(d - it.d0) * (unsigned)sizeof(TIN);
+      A.mrs = make_rsrc(BWD ? (const TIN *)p.out : (const TIN *)p.mean + (size_t)it.b * Tmax * ldi + it.d0);
+      A.vrs = make_rsrc(VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)it.b * Tmax * ldi + it.d0 : (const TIN *)p.out);
+      A.grs = make_rsrc(BWD ? (const TIN *)p.grad_out + (size_t)it.b * Tmax * ldg + it.d0 : (const TIN *)p.out);
+      A.vglob = VM == MLPG_HIP_VAR_GLOBAL ? (const TIN *)p.var + d : nullptr;
+      A.ldi_bytes = ldi_bytes;
+      A.win_bytes = win_bytes;
+      A.ldg_bytes = (unsigned)ldg * (unsigned)sizeof(TIN);
+      A.f0 = (it.r * kC + wv) * kM;
+      A.T = it.T;
+      A.mw = mw;
+      A.last = wv == kC - 1;
+      l1_windows(A);
+      return A;
+    };
+    auto fetch_ticket = [&](const int q) __attribute__((always_inline)) {  // ticket number q -> item id (-1: no more items)
+      while (lds_ld(ctl + cSeqTk) <= q) __builtin_amdgcn_s_sleep(2);
+      lds_order();
+      return __builtin_amdgcn_readfirstlane(lds_ld(ctl + cTk + (q & 3)));
+    };
+
+    ParkedFactor F;  // factor of the item awaiting its separators (in AGPRs)
+    {
+      const Parked z = park(0.0);
 #pragma unroll
-    for (int i = 0; i < kM; ++i) Fd[i] = F1[i] = F2[i] = Fr[i] = 0.0;
-    int old_id = -1;
+      for (int i = 0; i < kN; ++i) F.d[i] = F.l1[i] = F.l2[i] = F.g[i] = z;
+      F.ca = F.cb = F.cc = z;
+    }
+    TIN rv[kRing][3], rm[kRing][3];  // the ring of frames in flight
+    bool have_old = false;
     Item old_it = {};
 #ifdef MLPG_PIPE_TIMING
     long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long t_prev = (long long)__builtin_readcyclecounter();
     int n_items = 0;
 #endif
+    // the first item: ticket and prologue
+    int id = fetch_ticket(0);
+    Item cur = {};
+    if (id >= 0) {
+      cur = decode(p, a, id);
+      if (!cur.pad) l1_prologue<TIN, BWD, VM, kRing>(make_args(cur), rv, rm);
+    }
     for (int s = 0;; ++s) {
-      // ---- ticket s ----
-      while (lds_ld(ctl + cSeqTk) <= s) __builtin_amdgcn_s_sleep(2);
-      lds_order();
       PIPE_TICK(0);
-      const int id = __builtin_amdgcn_readfirstlane(lds_ld(ctl + cTk + (s & 3)));
+      if (wv == 0 && id >= 0) PIPE_STAMP(s, 0);  // body start
+      // ---- level 1 of item s (its first frames are already in flight) ----
       double Pd[kM], P1[kM], P2[kM], rhs[kM], ca = 0.0, cb = 0.0, cc = 0.0;
-      Item new_it = {};
+      int nid = -1;
+      Item nxt = {};
       if (id >= 0) {
-        const Item it = decode(p, a, id);
-        new_it = it;
-        const int f0 = (it.r * kC + wv) * kM;
+        const Item &it = cur;
         const bool lane_ok = lane < it.nd;
-        const int d = it.d0 + (lane_ok ? lane : it.nd - 1);  // idle lanes shadow the group's last dim (never stored)
-        TOUT *out_b = (TOUT *)p.out + (size_t)it.b * Tmax * ldo;
         if (it.pad) {
           // nothing but padding frames in this strip: zero-fill this chunk's rows (no record, no chain work)
+          const int f0 = (it.r * kC + wv) * kM;
+          const int d = it.d0 + (lane_ok ? lane : it.nd - 1);
+          TOUT *out_b = (TOUT *)p.out + (size_t)it.b * Tmax * ldo;
           if (lane_ok) {
             for (int i = 0; i < kM; ++i) {
               const int t = f0 + i;
@@ -178,32 +530,21 @@ __global__ __launch_bounds__(kThreads, 1) void pipe_kernel(Problem p, WinSet ws,
 #pragma unroll
           for (int i = 0; i < kM; ++i) { Pd[i] = 1.0; P1[i] = P2[i] = rhs[i] = 0.0; }
         } else {
+          const L1Args<TIN> A = make_args(it);
           double rec[kRec];
-          bool bad = false;
-          if (f0 < it.T) {
-            const unsigned loff = (unsigned)(d - it.d0) * (unsigned)sizeof(TIN);
-            const __amdgpu_buffer_rsrc_t mrs =
-                make_rsrc(BWD ? (const TIN *)p.out : (const TIN *)p.mean + (size_t)it.b * Tmax * ldi + it.d0);
-            const __amdgpu_buffer_rsrc_t vrs = make_rsrc(
-                VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)it.b * Tmax * ldi + it.d0 : (const TIN *)p.out);
-            const TIN *vglob = VM == MLPG_HIP_VAR_GLOBAL ? (const TIN *)p.var + d : nullptr;
-            const __amdgpu_buffer_rsrc_t grs =
-                make_rsrc(BWD ? (const TIN *)p.grad_out + (size_t)it.b * Tmax * ldg + it.d0 : (const TIN *)p.out);
-            const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < it.T - mw;
-            if (interior)
-              bad = assemble_eliminate<TIN, BWD, VM, false, 3>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, it.T, mw, a.wc,
-                                                               a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
-            else
-              bad = assemble_eliminate<TIN, BWD, VM, true, 3>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, it.T, mw, a.wc,
-                                                              a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
-          } else {
-            // a chunk of identity rows behind the utterance's end (keeps the strip's separator chain regular)
-#pragma unroll
-            for (int i = 0; i < kM; ++i) { Pd[i] = 1.0; P1[i] = P2[i] = rhs[i] = 0.0; }
-#pragma unroll
-            for (int k = 0; k < kRec; ++k) rec[k] = 0.0;
-            rec[rD11] = rec[rD22] = 1.0;
-          }
+          // hand-over slots: this wavefront produces for wavefront wv-1 and consumes what wavefront wv+1 produced
+          double *y_out = lds_y + ((size_t)(wv > 0 ? (s & 1) * kC + (wv - 1) : 2 * kC) * kY) * 64 + lane;
+          const double *y_in = lds_y + ((size_t)(wv + 1 < kC ? (s & 1) * kC + wv : 2 * kC + 1) * kY) * 64 + lane;
+          int *y_out_seq = ctl + cSeqY + wv;
+          const int *y_in_seq = ctl + cSeqY + (wv + 1 < kC ? wv + 1 : wv);
+          const bool interior = mw != 0 && A.f0 - 1 >= mw && A.f0 + kM < it.T - mw;
+          bool bad;
+          if (interior)
+            bad = l1_body<TIN, BWD, VM, false, kRing>(A, rv, rm, a.wc, a.one, y_out, y_out_seq, y_in, y_in_seq, s, lane, Pd, P1,
+                                                      P2, rhs, ca, cb, cc, rec);
+          else
+            bad = l1_body<TIN, BWD, VM, true, kRing>(A, rv, rm, a.wc, a.one, y_out, y_out_seq, y_in, y_in_seq, s, lane, Pd, P1,
+                                                     P2, rhs, ca, cb, cc, rec);
           if (bad) rec[rD11] = __builtin_nan("");  // poisons every later level: the system is reported, not solved
           double *rp = lds_rec + ((size_t)((s & 1) * kC + wv) * kRec) * 64 + lane;
 #pragma unroll
@@ -214,124 +555,136 @@ __global__ __launch_bounds__(kThreads, 1) void pipe_kernel(Problem p, WinSet ws,
 #ifdef MLPG_PIPE_TIMING
         ++n_items;
 #endif
+        PIPE_TICK(1);
+        if (wv == 0) PIPE_STAMP(s, 1);  // body end, records written
+        // ---- the next ticket, and its first frames into the ring (in flight during what follows) ----
+        nid = fetch_ticket(s + 1);
+        if (wv == 0) PIPE_STAMP(s, 2);  // next ticket known
+        if (nid >= 0) {
+          nxt = decode(p, a, nid);
+          if (!nxt.pad) l1_prologue<TIN, BWD, VM, kRing>(make_args(nxt), rv, rm);
+        }
+        PIPE_TICK(4);
       }
-      PIPE_TICK(1);
 
-      // ---- back-substitution and stores of item s-1 ----
-      if (old_id >= 0) {
-        const Item it = old_it;
-        const int so = s - 1;
-        while (lds_ld(ctl + cSeqU) < s) __builtin_amdgcn_s_sleep(2);
+      // ---- back-substitution and stores of item s-1 (one more turn of the loop after the last item) ----
+      auto finish_item = [&](const Item &it, const int so) __attribute__((always_inline)) {
+        while (lds_ld(ctl + cSeqU) <= so) __builtin_amdgcn_s_sleep(2);
         lds_order();
         PIPE_TICK(2);
-        if (!it.pad) {
-          const int f0 = (it.r * kC + wv) * kM;
-          const bool lane_ok = lane < it.nd;
-          const int d = it.d0 + (lane_ok ? lane : it.nd - 1);
-          TOUT *out_b = (TOUT *)p.out + (size_t)it.b * Tmax * ldo;
-          const double *up = lds_u + (size_t)(so & 1) * (kC + 1) * 2 * 64 + lane;
-          const V2 ul = {up[(wv * 2) * 64], up[(wv * 2 + 1) * 64]};
-          const V2 uo = {up[((wv + 1) * 2) * 64], up[((wv + 1) * 2 + 1) * 64]};
-          const double sx = up[(kC * 2) * 64];
-          const int timed_out = __builtin_amdgcn_readfirstlane(lds_ld(ctl + cTimedOut + (so & 1)));
-          const bool sys_bad = !(sx == sx) || !(uo.x == uo.x) || !(ul.x == ul.x);  // NaN: some pivot of this system failed
-          backsub(Fd, F1, F2, Fr, Fa, Fb, Fc, ul, uo);
-          // Verdict marks (see strip_kernel): a strip that met a failing pivot or a time-out marks its lanes in the
-          // utterance's mask; verdict_kernel turns the marks into the reference's status and zero columns.
-          if (wv == 0) {
-            const unsigned long long m = timed_out ? ~0ull : __ballot(sys_bad && lane_ok);
-            if (m != 0ull && lane == 0) {
-              int *line = a.ctrl + (1 + kMaxLists + it.g) * kCtrlLine;
-              __hip_atomic_fetch_or(line + 2, (int)(unsigned)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_fetch_or(line + 3, (int)(unsigned)(m >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (timed_out) __hip_atomic_store(line + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (it.r == 0 && lane_ok && p.status) p.status[(size_t)it.b * p.ld_status + d] = 0;
+        if (wv == 0) PIPE_STAMP(so, 3);  // separators arrived
+        if (it.pad) return;
+        const int f0 = (it.r * kC + wv) * kM;
+        const bool lane_ok = lane < it.nd;
+        const int d = it.d0 + (lane_ok ? lane : it.nd - 1);
+        TOUT *out_b = (TOUT *)p.out + (size_t)it.b * Tmax * ldo;
+        const double *up = lds_u + (size_t)(so & 1) * (kC + 1) * 2 * 64 + lane;
+        const V2 ul = {up[(wv * 2) * 64], up[(wv * 2 + 1) * 64]};
+        const V2 uo = {up[((wv + 1) * 2) * 64], up[((wv + 1) * 2 + 1) * 64]};
+        const double sx = up[(kC * 2) * 64];
+        const int timed_out = __builtin_amdgcn_readfirstlane(lds_ld(ctl + cTimedOut + (so & 1)));
+        const bool sys_bad = !(sx == sx) || !(uo.x == uo.x) || !(ul.x == ul.x);  // NaN: some pivot of this system failed
+        double Xr[kM];
+        backsub_parked(F, Xr, ul, uo);
+        // Verdict marks (see strip_kernel): a strip that met a failing pivot or a time-out marks its lanes in the
+        // utterance's mask; verdict_kernel turns the marks into the reference's status and zero columns.
+        if (wv == 0) {
+          const unsigned long long m = timed_out ? ~0ull : __ballot(sys_bad && lane_ok);
+          if (m != 0ull && lane == 0) {
+            int *line = a.ctrl + (1 + kMaxLists + it.g) * kCtrlLine;
+            __hip_atomic_fetch_or(line + 2, (int)(unsigned)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_or(line + 3, (int)(unsigned)(m >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (timed_out) __hip_atomic_store(line + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          const bool zero_out = sys_bad || timed_out;
-          if (lane_ok) {
-            if (!BWD) {
+          if (it.r == 0 && lane_ok && p.status) p.status[(size_t)it.b * p.ld_status + d] = 0;
+        }
+        const bool zero_out = sys_bad || timed_out;
+        if (!lane_ok) return;
+        if (!BWD) {
 #pragma unroll
-              for (int i = 0; i < kM; ++i) {
-                const int t = f0 + i;
-                if (t < Tmax) out_b[(size_t)t * ldo + d] = (t < it.T && !zero_out) ? (TOUT)Fr[i] : (TOUT)0;
+          for (int i = 0; i < kM; ++i) {
+            const int t = f0 + i;
+            if (t < Tmax) out_b[(size_t)t * ldo + d] = (t < it.T && !zero_out) ? (TOUT)Xr[i] : (TOUT)0;
+          }
+        } else {
+          // grad[t, w*sd+d] = tau_w[t] * (cm x[t-1] + c0 x[t] + cp x[t+1]): see strip_kernel's epilogue
+          const unsigned loff = (unsigned)(d - it.d0) * (unsigned)sizeof(TIN);
+          const __amdgpu_buffer_rsrc_t vrs = make_rsrc(
+              VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)it.b * Tmax * ldi + it.d0 : (const TIN *)p.out);
+          const TIN *vglob = VM == MLPG_HIP_VAR_GLOBAL ? (const TIN *)p.var + d : nullptr;
+          const int T = it.T;
+          auto load_w = [&](TIN (&v)[kM + 1], const int w) __attribute__((always_inline)) {
+            if (VM != MLPG_HIP_VAR_FRAME) return;
+#pragma unroll
+            for (int i = -1; i < kM; ++i) {
+              int t = f0 + i;
+              t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+              v[i + 1] = ld_row<TIN>(vrs, (unsigned)t * ldi_bytes + (unsigned)w * win_bytes, loff);
+            }
+          };
+          auto emit_w = [&](const TIN (&v)[kM + 1], const int w) __attribute__((always_inline)) {
+            const double cm = a.wc[w][0], c0 = a.wc[w][1], cp = a.wc[w][2];
+            double tau_glob = 1.0;
+            if (VM == MLPG_HIP_VAR_GLOBAL) tau_glob = tau_of<TIN>(vglob[w * sd]);
+            TOUT *ow = out_b + (size_t)w * sd + d;
+#pragma unroll
+            for (int i = -1; i < kM; ++i) {
+              const int t = f0 + i;
+              if (t < 0 || t >= Tmax) continue;
+              if (t >= T) {
+                if (i >= 0) ow[(size_t)t * ldo] = (TOUT)0;
+                continue;
               }
-            } else {
-              // grad[t, w*sd+d] = tau_w[t] * (cm x[t-1] + c0 x[t] + cp x[t+1]): see strip_kernel's epilogue
-              const unsigned loff = (unsigned)(d - it.d0) * (unsigned)sizeof(TIN);
-              const __amdgpu_buffer_rsrc_t vrs = make_rsrc(
-                  VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)it.b * Tmax * ldi + it.d0 : (const TIN *)p.out);
-              const TIN *vglob = VM == MLPG_HIP_VAR_GLOBAL ? (const TIN *)p.var + d : nullptr;
-              const unsigned ldi_bytes = (unsigned)ldi * (unsigned)sizeof(TIN), win_bytes = (unsigned)sd * (unsigned)sizeof(TIN);
-              const int T = it.T;
-              auto load_w = [&](TIN (&v)[kM + 1], const int w) __attribute__((always_inline)) {
-                if (VM != MLPG_HIP_VAR_FRAME) return;
-#pragma unroll
-                for (int i = -1; i < kM; ++i) {
-                  int t = f0 + i;
-                  t = t < 0 ? 0 : (t >= T ? T - 1 : t);
-                  v[i + 1] = ld_row<TIN>(vrs, (unsigned)t * ldi_bytes + (unsigned)w * win_bytes, loff);
-                }
-              };
-              auto emit_w = [&](const TIN (&v)[kM + 1], const int w) __attribute__((always_inline)) {
-                const double cm = a.wc[w][0], c0 = a.wc[w][1], cp = a.wc[w][2];
-                double tau_glob = 1.0;
-                if (VM == MLPG_HIP_VAR_GLOBAL) tau_glob = tau_of<TIN>(vglob[w * sd]);
-                TOUT *ow = out_b + (size_t)w * sd + d;
-#pragma unroll
-                for (int i = -1; i < kM; ++i) {
-                  const int t = f0 + i;
-                  if (t < 0 || t >= Tmax) continue;
-                  if (t >= T) {
-                    if (i >= 0) ow[(size_t)t * ldo] = (TOUT)0;
-                    continue;
-                  }
-                  if (i == -1 && f0 >= T) continue;
-                  if (i == kM - 1 && t != T - 1) continue;  // the next chunk writes it
-                  const bool lv = w ? (mw != 0 && t >= mw && t < T - mw) : true;
-                  double tau = 0.0;
-                  if (lv) tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[i + 1]) : tau_glob;
-                  const double xm = (i == -1) ? ul.x : ((i == 0) ? ul.y : Fr[i > 0 ? i - 1 : 0]);
-                  const double x0 = (i == -1) ? ul.y : Fr[i >= 0 ? i : 0];
-                  const double xp = (i == kM - 1) ? 0.0 : Fr[i + 1];
-                  const double gval = tau * (cm * xm + c0 * x0 + cp * xp);
-                  ow[(size_t)t * ldo] = zero_out ? (TOUT)0 : (TOUT)gval;
-                }
-              };
-              TIN tvA[kM + 1], tvB[kM + 1];
-              load_w(tvA, 0);
-              for (int w = 0; w < nw; w += 2) {
-                if (w + 1 < nw) load_w(tvB, w + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                emit_w(tvA, w);
-                __builtin_amdgcn_sched_barrier(0);
-                if (w + 1 < nw) {
-                  if (w + 2 < nw) load_w(tvA, w + 2);
-                  __builtin_amdgcn_sched_barrier(0);
-                  emit_w(tvB, w + 1);
-                  __builtin_amdgcn_sched_barrier(0);
-                }
-              }
+              if (i == -1 && f0 >= T) continue;
+              if (i == kM - 1 && t != T - 1) continue;  // the next chunk writes it
+              const bool lv = w ? (mw != 0 && t >= mw && t < T - mw) : true;
+              double tau = 0.0;
+              if (lv) tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[i + 1]) : tau_glob;
+              const double xm = (i == -1) ? ul.x : ((i == 0) ? ul.y : Xr[i > 0 ? i - 1 : 0]);
+              const double x0 = (i == -1) ? ul.y : Xr[i >= 0 ? i : 0];
+              const double xp = (i == kM - 1) ? 0.0 : Xr[i + 1];
+              const double gval = tau * (cm * xm + c0 * x0 + cp * xp);
+              ow[(size_t)t * ldo] = zero_out ? (TOUT)0 : (TOUT)gval;
+            }
+          };
+          TIN tvA[kM + 1], tvB[kM + 1];
+          load_w(tvA, 0);
+          for (int w = 0; w < nw; w += 2) {
+            if (w + 1 < nw) load_w(tvB, w + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            emit_w(tvA, w);
+            __builtin_amdgcn_sched_barrier(0);
+            if (w + 1 < nw) {
+              if (w + 2 < nw) load_w(tvA, w + 2);
+              __builtin_amdgcn_sched_barrier(0);
+              emit_w(tvB, w + 1);
+              __builtin_amdgcn_sched_barrier(0);
             }
           }
         }
-      }
+      };
+      if (have_old) finish_item(old_it, s - 1);
+      if (wv == 0 && have_old) PIPE_STAMP(s - 1, 4);  // back-substitution and stores issued
 #ifdef MLPG_PIPE_TIMING
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
       PIPE_TICK(3);
       if (id < 0) break;
 #pragma unroll
-      for (int i = 0; i < kM; ++i) { Fd[i] = Pd[i]; F1[i] = P1[i]; F2[i] = P2[i]; Fr[i] = rhs[i]; }
-      Fa = ca; Fb = cb; Fc = cc;
-      old_id = id;
-      old_it = new_it;
+      for (int i = 0; i < kN; ++i) { F.d[i] = park(Pd[i]); F.l1[i] = park(P1[i]); F.l2[i] = park(P2[i]); F.g[i] = park(rhs[i]); }
+      F.ca = park(ca); F.cb = park(cb); F.cc = park(cc);
+      have_old = true;
+      old_it = cur;
+      cur = nxt;
+      id = nid;
     }
 #ifdef MLPG_PIPE_TIMING
-    // profiling build: mean cycles per item of (ticket wait, level 1, wait for the separators, back-substitution + stores)
-    if (lane == 0 && p.status && blockIdx.x < 64)
-      for (int k = 0; k < 4; ++k) p.status[(blockIdx.x * 4 + wv) * 8 + k] = (int)(tq[k] / (n_items > 0 ? n_items : 1));
-    if (lane == 0 && p.status && blockIdx.x < 64) p.status[(blockIdx.x * 4 + wv) * 8 + 7] = n_items;
+    // profiling build: mean cycles per item of (rotation, level-1 body, wait for the separators, back-substitution + stores,
+    // next ticket + prologue)
+    if (lane == 0 && p.status && blockIdx.x < 64) {
+      for (int k = 0; k < 5; ++k) p.status[(blockIdx.x * 4 + wv) * 8 + k] = (int)(tq[k] / (n_items > 0 ? n_items : 1));
+      p.status[(blockIdx.x * 4 + wv) * 8 + 7] = n_items;
+    }
 #endif
     return;
   }
@@ -474,7 +827,9 @@ __global__ __launch_bounds__(kThreads, 1) void pipe_kernel(Problem p, WinSet ws,
     }
     st_route[par] = route;
     st_state[par] = route ? sWaitWindow : sWaitFull;
+#ifndef MLPG_PIPE_FAKE_CHAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     int *cnt = a.ctrl + (1 + kMaxLists + it.g) * kCtrlLine;
     int *flags = a.ctrl + (1 + kMaxLists + a.nsg) * kCtrlLine + (size_t)it.g * flag_pitch(R);
     if (lane == 0) {
@@ -485,6 +840,9 @@ __global__ __launch_bounds__(kThreads, 1) void pipe_kernel(Problem p, WinSet ws,
 
   // ---- one look at what item (parity par) is waiting for ----
   auto arrived = [&](const int par) -> bool {
+#ifdef MLPG_PIPE_FAKE_CHAIN  // timing experiment only: what if the protocol's round trips cost nothing
+    return true;
+#endif
     const Item it = par ? st_it1 : st_it0;
     int *cnt = a.ctrl + (1 + kMaxLists + it.g) * kCtrlLine;
     int *flags = a.ctrl + (1 + kMaxLists + a.nsg) * kCtrlLine + (size_t)it.g * flag_pitch(R);
@@ -565,8 +923,14 @@ __global__ __launch_bounds__(kThreads, 1) void pipe_kernel(Problem p, WinSet ws,
         for (int q = 0; q < kLoad; ++q) {
           const int pos = p0 + (q < kn ? q : kn - 1);
           const double *rp = a.rec + ((size_t)g * R + row_of(o, pos)) * (kRec * 64) + lane;
+#if defined(MLPG_PIPE_FAKE_CHAIN) && MLPG_PIPE_FAKE_CHAIN == 1
+          (void)rp;
+#pragma unroll
+          for (int k = 0; k < kRec; ++k) sv[q][k] = lds_own[((size_t)par * kRec + k) * 64 + lane];
+#else
 #pragma unroll
           for (int k = 0; k < kRec; ++k) sv[q][k] = ld_agent(rp + k * 64);
+#endif
         }
       };
       auto stage_store = [&]() __attribute__((always_inline)) {
@@ -650,7 +1014,11 @@ __global__ __launch_bounds__(kThreads, 1) void pipe_kernel(Problem p, WinSet ws,
       if (!full) {
         const bool full_range = w.lo == 0 && !w.edge;
         const bool lane_fine = !lane_ok || full_range || (damp < kDampTol && sig.x == sig.x);
+#ifndef MLPG_PIPE_FAKE_CHAIN
         if (__ballot(!lane_fine) != 0ull) return false;  // the whole utterance is needed
+#else
+        (void)lane_fine;
+#endif
       }
     }
     // level-2 back-substitution -> the separator solutions of the strip
@@ -685,6 +1053,7 @@ __global__ __launch_bounds__(kThreads, 1) void pipe_kernel(Problem p, WinSet ws,
         const bool arr_ = arrived(par);
         PIPE_TICK(1);  // polls
         if (arr_) {
+          PIPE_STAMP(n_fin, 7);  // neighbours arrived
           ready = true;
         } else if (++st_spins[par] > kSpinLimit) {
           ready = true;
@@ -707,10 +1076,12 @@ __global__ __launch_bounds__(kThreads, 1) void pipe_kernel(Problem p, WinSet ws,
         // window -- the new item could sit unpublished behind an item that waits for the whole utterance, the new
         // item's own strip included.
         PIPE_TICK(2);  // level 3 + level-2 back-substitution
+        PIPE_STAMP(n_fin, 8);  // level 3 done
         post_ticket();
         lds_order();
         if (lane == 0) lds_st(ctl + cSeqU, n_fin + 1);
         PIPE_TICK(0);  // ticket
+        PIPE_STAMP(n_fin, 9);  // ticket + separators posted
         st_state[par] = sNone;
         ++n_fin;
         progress = true;
@@ -724,7 +1095,9 @@ __global__ __launch_bounds__(kThreads, 1) void pipe_kernel(Problem p, WinSet ws,
       if (all && n_l2 - n_fin < 2) {
         lds_order();
         PIPE_TICK(4);
+        PIPE_STAMP(n_l2, 5);  // records seen
         level2_publish(n_l2);
+        PIPE_STAMP(n_l2, 6);  // published
         ++n_l2;
         progress = true;
         PIPE_TICK(3);  // level 2 + publish

@@ -13,9 +13,9 @@ for _ in range(3):
     out, st = _hip.forward(m, v, WINDOWS, algo=_hip.ALGO_PIPE)
 torch.cuda.synchronize()
 s = st.cpu().numpy()[:64 * 4 * 8].reshape(64, 4, 8)
-print("chunk wavefronts (ticket wait, level 1, wait u, backsub+stores) cycles/item; items:")
+print("chunk wavefronts (rotate, level-1 body, wait u, backsub+stores, next ticket+prologue) cycles/item; items:")
 for w in range(3):
-    print("  wave", w, s[:, w, :4].mean(0).astype(int), "sum", int(s[:, w, :4].mean(0).sum()), "items", s[:, w, 7].mean())
+    print("  wave", w, s[:, w, :5].mean(0).astype(int), "sum", int(s[:, w, :5].mean(0).sum()), "items", s[:, w, 7].mean())
 print("chain wavefront (ticket, polls, level3+l2back, level2+publish, idle) cycles/item:", s[:, 3, :5].mean(0).astype(int), "sum", int(s[:, 3, :5].mean(0).sum()), "items", s[:, 3, 7].mean())
 x = st.cpu().numpy()[64 * 4 * 8: 64 * 4 * 8 + 64 * 4].reshape(64, 4)
 print("  finish detail (issue staging loads, loads landed + LDS writes, sweep) cycles/item:", x[:, :3].mean(0).astype(int), "(the rest of level3+l2back = decode + level-2 back-substitution)")
