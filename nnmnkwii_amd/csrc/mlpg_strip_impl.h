@@ -86,6 +86,9 @@ constexpr int kCtrlLine = 32;
 #ifndef MLPG_STRIP_RING_F32
 #define MLPG_STRIP_RING_F32 6
 #endif
+#ifndef MLPG_STRIP_NT_STORES
+#define MLPG_STRIP_NT_STORES 0  // trajectory rows with the nontemporal hint (written once, never read by this kernel)
+#endif
 #ifndef MLPG_STRIP_SCHED_RELAX
 #define MLPG_STRIP_SCHED_RELAX 0
 #endif
@@ -96,7 +99,9 @@ constexpr int kCtrlLine = 32;
 #define MLPG_STRIP_ROUTE1_TOL 0.0  // own transfer factor below which a 3-strip window is tried first (0: never)
 #endif
 #ifndef MLPG_STRIP_STREAM
-#define MLPG_STRIP_STREAM 1  // 0: window-major assembly, then elimination, also for three windows (A/B measurements)
+#define MLPG_STRIP_STREAM 1  // 1: streamed level 1, every wavefront loads its own 18 frames (shipped); 2: the halo handed over
+                             // through LDS, 66 instead of 72 frames per strip (round 3: parity green, 2-3 % SLOWER -- the kernel is
+                             // bound by its latency chain, not by bytes; kept as a switch); 0: window-major assembly (A/B)
 #endif
 #ifndef MLPG_STRIP_PHASES
 #define MLPG_STRIP_PHASES 1
@@ -660,6 +665,214 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
   return bad;
 }
 
+// The same stream with the HALO handed over inside the workgroup (round 3): a wavefront loads the frames f0-1 .. f0+M-2
+// of its chunk; what the frames f0+M-1 and f0+M add to its last two rows comes from the next wavefront of the strip,
+// which forms those five sums from its own first two frames (step 1 of its stream) and leaves them in LDS; level 2
+// (wavefront 0, behind the barrier that follows level 1 anyway) adds them to the separator entries of the records.  Only the strip's last wavefront
+// (`last`) loads its two right-hand frames itself; the others repeat their own last frame there (a cache hit) with
+// weight 0, so that the stream stays the same straight-line code for everybody.  66 instead of 72 frames per strip.
+template <typename TIN, bool BWD, int VM, bool EDGE, int NW>
+__device__ __forceinline__ bool assemble_eliminate_halo(const int last, double *lds_yb, const int slot_out, const int lane,
+                                                        __amdgpu_buffer_rsrc_t mrs, __amdgpu_buffer_rsrc_t vrs,
+                                                   __amdgpu_buffer_rsrc_t grs, const TIN *__restrict__ vglob,
+                                                   unsigned loff, long ldi, long ldg, int sd, int f0, int T, int mw,
+                                                   const double (*wc)[9], const double one, double (&Pd)[kM], double (&P1)[kM],
+                                                   double (&P2)[kM], double (&rhs)[kM], double &ca, double &cb,
+                                                   double &cc, double (&rec)[kRec]) {
+  // No zero-fill: every accumulator is ASSIGNED by the first contribution that reaches it (window 0 of the frame
+  // noted below), so that a row costs no register before its first frame arrives.
+  const unsigned ldi_bytes = (unsigned)ldi * (unsigned)sizeof(TIN), win_bytes = (unsigned)sd * (unsigned)sizeof(TIN);
+  // live frames of a window: [0, T) for the static window, [mw, T - mw) for the dynamic ones (none if mw == 0)
+  int lo[NW], hi[NW], cl[NW], ch[NW];
+  WinCoef k[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    lo[w] = w ? mw : 0;
+    hi[w] = w ? (mw != 0 && T - mw > mw ? T - mw : mw) : T;
+    cl[w] = lo[w] < T ? lo[w] : T - 1;            // a window without live frames still loads (frame cl) and weighs 0
+    ch[w] = hi[w] > cl[w] ? hi[w] : cl[w] + 1;
+    k[w] = win_coef<TIN, VM>(wc, w, vglob, sd);
+    // unit variances: the precision 1.0 as an opaque per-lane run-time value.  As a literal (or any wave-uniform value)
+    // the whole matrix becomes uniform arithmetic that the compiler hoists above the stream and spills (544-880 B/lane).
+    if (VM == MLPG_HIP_VAR_UNIT) {
+      double t1 = one;
+      asm volatile("" : "+v"(t1));  // a per-lane value as far as the compiler can tell
+      k[w].tau_glob = t1;
+    }
+  }
+  constexpr int kRing = RingDepth<TIN>::value;
+  TIN rv[kRing][NW], rm[kRing][NW];
+  auto load_frame = [&](TIN (&v)[NW], TIN (&m)[NW], const int i) __attribute__((always_inline)) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      int t = f0 + i;
+      if (i >= kM - 1) t = last ? t : f0 + kM - 2;
+      if (EDGE) t = t < cl[w] ? cl[w] : (t >= ch[w] ? ch[w] - 1 : t);
+      const unsigned soff = (unsigned)t * ldi_bytes + (unsigned)w * win_bytes;
+#ifdef MLPG_STRIP_FAKE_LOADS  // timing experiment only: no memory traffic, opaque per-lane values instead
+      (void)soff;
+      if (VM == MLPG_HIP_VAR_FRAME) { TIN x = (TIN)1.5; asm volatile("" : "+v"(x)); v[w] = x; }
+      if (!BWD) { TIN x = (TIN)0.25; asm volatile("" : "+v"(x)); m[w] = x; }
+#else
+      if (VM == MLPG_HIP_VAR_FRAME) v[w] = ld_row<TIN>(vrs, soff, loff);
+      if (!BWD) m[w] = ld_row<TIN>(mrs, soff, loff);
+#endif
+    }
+  };
+  const double wR = last ? 1.0 : 0.0;  // weight of the two right-hand frames
+  double y[5];
+  auto accumulate_frame = [&](const TIN (&v)[NW], const TIN (&m)[NW], const int i) __attribute__((always_inline)) {
+    const int t = f0 + i;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      double tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[w]) : k[w].tau_glob;
+      if (EDGE) tau *= (t >= lo[w] && t < hi[w]) ? 1.0 : 0.0;  // wave-uniform weight
+      if (i >= kM - 1) tau *= wR;
+      double tm = 0.0;
+      if (!BWD) tm = tau * (double)m[w];
+      const bool first = w == 0;  // first contribution to: Pd, rhs of row t+1; P1 of row t; P2 of row t-1
+      if (i >= 0 && i < kM) {  // row t
+        Pd[i] += k[w].c00 * tau;
+        P1[i] = first ? k[w].cp0 * tau : P1[i] + k[w].cp0 * tau;
+        if (!BWD) rhs[i] += k[w].c0 * tm;
+      }
+      if (i + 1 >= 0 && i + 1 < kM) {  // row t+1
+        Pd[i + 1] = first ? k[w].cpp * tau : Pd[i + 1] + k[w].cpp * tau;
+        if (!BWD) rhs[i + 1] = first ? k[w].cp * tm : rhs[i + 1] + k[w].cp * tm;
+      }
+      if (i - 1 >= 0 && i - 1 < kM) {  // row t-1
+        Pd[i - 1] += k[w].cmm * tau;
+        P1[i - 1] += k[w].c0m * tau;
+        P2[i - 1] = first ? k[w].cpm * tau : P2[i - 1] + k[w].cpm * tau;
+        if (!BWD) rhs[i - 1] += k[w].cm * tm;
+      }
+      // coupling of the chunk's first two rows to the previous chunk's separator:
+      // ca = P[f0, f0-2], cb = P[f0, f0-1], cc = P[f0+1, f0-1]
+      if (i == -1) {
+        ca = first ? k[w].cpm * tau : ca + k[w].cpm * tau;
+        cb = first ? k[w].cp0 * tau : cb + k[w].cp0 * tau;
+        // what this frame adds to the PREVIOUS chunk's rows M-2 (t-1) and M-1 (t)
+        y[0] = first ? k[w].cmm * tau : y[0] + k[w].cmm * tau;
+        y[1] = first ? k[w].c0m * tau : y[1] + k[w].c0m * tau;
+        y[3] = first ? k[w].c00 * tau : y[3] + k[w].c00 * tau;
+        if (!BWD) {
+          y[2] = first ? k[w].cm * tm : y[2] + k[w].cm * tm;
+          y[4] = first ? k[w].c0 * tm : y[4] + k[w].c0 * tm;
+        }
+      }
+      if (i == 0) {
+        cb += k[w].c0m * tau;
+        cc = first ? k[w].cpm * tau : cc + k[w].cpm * tau;
+        y[3] += k[w].cmm * tau;
+        if (!BWD) y[4] += k[w].cm * tm;
+      }
+    }
+  };
+  // matrix edges (EDGE): rows >= T are identity rows, entries that would leave the T x T matrix vanish.  Wave-uniform
+  // 0/1 factors instead of branches (x * 1 and x * 1 + 0 are exact; dead frames enter with weight 0, so nothing
+  // that is multiplied by 0 here can be Inf or NaN unless the input is): straight-line code for the allocator.
+  auto fix_row = [&](const int i) __attribute__((always_inline)) {
+    const int f = f0 + i;
+    const double live = f < T ? 1.0 : 0.0, live1 = f + 1 < T ? 1.0 : 0.0, live2 = f + 2 < T ? 1.0 : 0.0;
+    Pd[i] = Pd[i] * live + (1.0 - live);
+    P1[i] *= live1;
+    P2[i] *= live2;
+    rhs[i] *= live;
+  };
+  // elimination state (see `eliminate`)
+  bool bad = false;
+  double t00 = 0.0, t01 = 0.0, t11 = 0.0, h0 = 0.0, h1 = 0.0;
+  double g1 = 0.0, g2 = 0.0, va1 = 0.0, va2 = 0.0, vb1 = 0.0, vb2 = 0.0;
+  double l1p = 0.0, l2p = 0.0, l2pp = 0.0;
+  auto elim_row = [&](const int i) __attribute__((always_inline)) {
+    if (EDGE) {
+      fix_row(i);
+      if (i == 0) {
+        const double keep = (f0 == 0 || f0 >= T) ? 0.0 : 1.0, keepc = f0 + 1 >= T ? 0.0 : 1.0;
+        ca *= keep;
+        cb *= keep;
+        cc *= keep * keepc;
+      }
+    }
+    const double dd = Pd[i];
+    bad |= !(dd > 0.0);
+    const double dinv = fast_rcp(dd);
+    const double e1 = P1[i], e2 = P2[i];
+    const double l1 = e1 * dinv, l2 = e2 * dinv;
+    Pd[i + 1] -= l1 * e1;
+    P1[i + 1] -= l2 * e1;
+    Pd[i + 2] -= l2 * e2;
+    const double gi = rhs[i] - l1p * g1 - l2pp * g2;
+    const double ba = (i == 0) ? ca : 0.0;
+    const double bb = (i == 0) ? cb : ((i == 1) ? cc : 0.0);
+    const double va = ba - l1p * va1 - l2pp * va2;
+    const double vb = bb - l1p * vb1 - l2pp * vb2;
+    const double wa = va * dinv, wb = vb * dinv;
+    t00 += wa * va;
+    t01 += wa * vb;
+    t11 += wb * vb;
+    h0 += wa * gi;
+    h1 += wb * gi;
+    Pd[i] = dinv;
+    P1[i] = l1;
+    P2[i] = l2;
+    rhs[i] = gi;
+    g2 = g1; g1 = gi;
+    va2 = va1; va1 = va;
+    vb2 = vb1; vb1 = vb;
+    l2pp = l2p; l2p = l2; l1p = l1;
+  };
+
+  // prologue: the first kRing frames (f0-1 ..) in flight
+#pragma unroll
+  for (int sl = 0; sl < kRing; ++sl) load_frame(rv[sl], rm[sl], sl - 1);
+  static_assert(kRing >= 2 && kRing <= kM + 2, "ring depth");
+  if (BWD) {
+#pragma unroll
+    for (int i = 0; i < kM; ++i) {
+      int t = f0 + i;
+      if (EDGE) t = t >= T ? T - 1 : t;
+      rhs[i] = (double)ld_row<TIN>(grs, (unsigned)t * (unsigned)ldg * (unsigned)sizeof(TIN), loff);  // rows >= T are reset by fix_row
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // step S handles frame I = S - 1 in ring slot S % 6: accumulate, refill with frame I + 6, eliminate row I - 1
+  // MLPG_STRIP_SCHED_RELAX (A/B switch): bit 0 drops the barrier after the accumulation, bit 1 the one after the
+  // refill, bit 2 the one after the elimination step (one wavefront per SIMD wants the scheduler to interleave the
+  // elimination's dependent chain with the next frame's accumulation; two per SIMD did not care)
+#define STRIP_SB(bit) do { if (!((MLPG_STRIP_SCHED_RELAX) & (bit))) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STRIP_STEP(S)                                                                   \
+  accumulate_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1);                            \
+  STRIP_SB(1);                                                                          \
+  if ((S) + kRing < kM + 2) { load_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1 + kRing); } \
+  STRIP_SB(2);                                                                          \
+  if ((S) == 1) {                                                                       \
+    _Pragma("unroll")                                                                   \
+    for (int q = 0; q < 5; ++q) lds_yb[(slot_out * 5 + q) * 64 + lane] = (BWD && (q == 2 || q == 4)) ? 0.0 : y[q]; \
+  }                                                                                     \
+  if ((S)-2 >= 0 && (S)-2 < kN) { elim_row((S)-2); }                                    \
+  STRIP_SB(4);
+  STRIP_STEP(0) STRIP_STEP(1) STRIP_STEP(2) STRIP_STEP(3) STRIP_STEP(4) STRIP_STEP(5)
+  STRIP_STEP(6) STRIP_STEP(7) STRIP_STEP(8) STRIP_STEP(9) STRIP_STEP(10) STRIP_STEP(11)
+  STRIP_STEP(12) STRIP_STEP(13) STRIP_STEP(14) STRIP_STEP(15) STRIP_STEP(16) STRIP_STEP(17)
+#undef STRIP_STEP
+#undef STRIP_SB
+  if (EDGE) {
+    fix_row(kN);
+    fix_row(kN + 1);
+  }
+  rec[rT00] = t00; rec[rT01] = t01; rec[rT11] = t11; rec[rH0] = h0; rec[rH1] = h1;
+  rec[rD11] = Pd[kN]; rec[rD12] = P1[kN]; rec[rD22] = Pd[kN + 1];
+  rec[rF1] = rhs[kN] - (l1p * g1 + l2pp * g2);
+  rec[rF2] = rhs[kN + 1] - l2p * g1;
+  rec[rL11] = -(l1p * va1 + l2pp * va2);
+  rec[rL12] = -(l1p * vb1 + l2pp * vb2);
+  rec[rL21] = -(l2p * va1);
+  rec[rL22] = -(l2p * vb1);
+  return bad;
+}
+
+
 // ---- level 1: back-substitution; on return x[0..kM) is the chunk's solution -------------------
 __device__ __forceinline__ void backsub(const double (&Pd)[kM], const double (&P1)[kM], const double (&P2)[kM],
                                         double (&rhs)[kM], double ca, double cb, double cc, V2 ul, V2 u) {
@@ -771,9 +984,22 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
   double Pd[kM], P1[kM], P2[kM], rhs[kM], ca, cb, cc;
   double rec[kRec];
   bool bad = false;
+  if (MLPG_STRIP_STREAM == 2 && nw == 3 && MLPG_STRIP_ABLATE < 2) {
+    // three windows: the streamed level 1 with the halo handed over through LDS.  Every chunk of an active strip runs
+    // it, also one behind the utterance's end (all weights 0, identity rows): its predecessor expects its hand-over.
+    // Slots in the tail of the staging area (free until level 3): slot w = what wavefront w consumes; wavefront 0
+    // produces into slot kW-1, which nobody reads (the last wavefront takes zeros instead).
+    double *lds_yb = lds_stage + (size_t)kW * kRec * 64;
+    const int slot_out = wv > 0 ? wv - 1 : kW - 1;
+    const int lastw = wv == kW - 1;
+    const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < T - mw;
+    if (interior) bad = assemble_eliminate_halo<TIN, BWD, VM, false, 3>(lastw, lds_yb, slot_out, lane, mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
+    else bad = assemble_eliminate_halo<TIN, BWD, VM, true, 3>(lastw, lds_yb, slot_out, lane, mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
+    STRIP_TICK(1);
+  } else
   if (f0 < T) {
     const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < T - mw;
-    if (MLPG_STRIP_STREAM && nw == 3 && MLPG_STRIP_ABLATE < 2) {
+    if (MLPG_STRIP_STREAM == 1 && nw == 3 && MLPG_STRIP_ABLATE < 2) {
       // the usual three windows: assembly and elimination streamed in frame order
       if (interior) bad = assemble_eliminate<TIN, BWD, VM, false, 3>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
       else bad = assemble_eliminate<TIN, BWD, VM, true, 3>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
@@ -826,7 +1052,21 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
     }
     S2 E_s = {1.0, 0.0, 1.0};
     V2 g_s = {0.0, 0.0};
-    auto R_ = [&](int j, int k) { return lds_rec[(j * kRec + k) * 64 + lane]; };
+    // level-1 records; with the handed-over halo (MLPG_STRIP_STREAM == 2) the separator entries D11, D12, D22, F1, F2
+    // of chunks 0 .. kW-2 still lack what the next chunk's first two frames add to them: slot j of the hand-over area
+    // (rows behind the utterance's end are identity rows: their sums vanish)
+    const bool halo = MLPG_STRIP_STREAM == 2 && nw == 3 && MLPG_STRIP_ABLATE < 2;
+    const double *lds_yr = lds_stage + (size_t)kW * kRec * 64 + lane;
+    auto R_ = [&](int j, int k) __attribute__((always_inline)) {
+      double v = lds_rec[(j * kRec + k) * 64 + lane];
+      if (halo && j < kW - 1 && (k == rD11 || k == rD12 || k == rD22 || k == rF1 || k == rF2)) {
+        const int q = k == rD11 ? 0 : k == rD12 ? 1 : k == rF1 ? 2 : k == rD22 ? 3 : 4;
+        const int fj = (r * kW + j) * kM;  // first frame of chunk j
+        const double live = (q == 0 || q == 2) ? (fj + kN < T ? 1.0 : 0.0) : (fj + kN + 1 < T ? 1.0 : 0.0);
+        if (!(BWD && (q == 2 || q == 4))) v += live * lds_yr[(j * 5 + q) * 64];
+      }
+      return v;
+    };
     S2 E = {R_(0, rD11), R_(0, rD12), R_(0, rD22)};
     V2 gg = {R_(0, rF1), R_(0, rF2)};
     M2 V = {R_(0, rL11), R_(0, rL12), R_(0, rL21), R_(0, rL22)};
@@ -1227,7 +1467,11 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
 #pragma unroll
     for (int i = 0; i < kM; ++i) {
       const int t = f0 + i;
+#if MLPG_STRIP_NT_STORES
+      if (t < Tmax) __builtin_nontemporal_store((t < T && !zero_out) ? (TOUT)rhs[i] : (TOUT)0, &out_b[(size_t)t * ldo + d]);
+#else
       if (t < Tmax) out_b[(size_t)t * ldo + d] = (t < T && !zero_out) ? (TOUT)rhs[i] : (TOUT)0;
+#endif
     }
   } else {
     // grad[t, w*sd+d] = tau_w[t] * (cm x[t-1] + c0 x[t] + cp x[t+1])  (paramgen/_mlpg.py:202-281).  The row whose
