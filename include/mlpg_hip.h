@@ -68,6 +68,28 @@ int mlpg_hip_device_count(void);
 void mlpg_hip_shutdown(void);
 
 /*
+ * One training step of unit-variance MLPG under a mean-squared-error loss, fused: what the reference's
+ * perf/autograd_mlpg_perf.py:56-86 loop does per batch with autograd.unit_variance_mlpg (autograd/_impl/mlpg.py:70-172:
+ * dense R @ means forward, R^T @ grad backward) around torch.nn.MSELoss --
+ *     y = MLPG(mean) with unit variances;  loss = sum_{live frames} (y - target)^2 / n_elems;
+ *     grad_mean = d loss / d mean
+ * in ONE kernel launch (wave-per-system scheme: both solves of a system share the launch, the trajectory stays in
+ * registers between them).  mean (B, Tmax, D), target (B, Tmax, D/nw), grad_mean (B, Tmax, D) of `dtype`; y_out
+ * (B, Tmax, D/nw) or NULL; loss: one float64 on the device; n_elems: the divisor of the mean (B * Tmax * D/nw for
+ * nn.MSELoss over a padded batch).  Window extents <= 1, Tmax <= 1024.  The loss is summed in a fixed order
+ * (bitwise repeatable).  status as for mlpg_hip_forward (may be NULL).
+ * workspace: caller-owned device memory, 128-byte aligned, >= mlpg_hip_unit_mse_workspace_bytes(B, D, nw) bytes,
+ * zeroed ONCE by the caller before its first use (the kernel leaves its arrival counter zero); one workspace per stream
+ * that may run the call concurrently.  The call allocates nothing and is capturable into a HIP graph.
+ */
+int mlpg_hip_unit_mse_step(int device, void *stream, int dtype, const void *mean, const void *target,
+                           const int32_t *lengths, int B, int Tmax, int D, int num_windows,
+                           const int32_t *win_l_h, const int32_t *win_u_h, const double *win_coef_h,
+                           double n_elems, void *y_out, void *grad_mean, double *loss, int32_t *status,
+                           void *workspace, size_t workspace_bytes);
+size_t mlpg_hip_unit_mse_workspace_bytes(int B, int D, int num_windows);
+
+/*
  * Measurement aid, not part of the reference's interface: a plain streaming copy of nbytes (a multiple of 16; both
  * pointers 16-byte aligned device memory), 16 bytes per lane and access.  bench.py times it in the same run as the
  * MLPG kernels to report the HBM rate a copy kernel reaches on the box ("fraction of both nominal and

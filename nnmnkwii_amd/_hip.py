@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 F32, F64 = 0, 1
-ABI_VERSION = 9               # mlpg_hip_abi_version() of the library this binding was written for
+ABI_VERSION = 10               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE, ALGO_STRIP, ALGO_PIPE = 0, 1, 2, 3, 4
 
@@ -45,6 +45,8 @@ EXPORTS = (
     "mlpg_hip_gather_path",
     "mlpg_hip_gmm_convert",
     "mlpg_hip_stream_copy",
+    "mlpg_hip_unit_mse_step",
+    "mlpg_hip_unit_mse_workspace_bytes",
 )
 
 
@@ -119,6 +121,11 @@ def lib():
         L.mlpg_hip_gmm_convert.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
         L.mlpg_hip_gather_path.restype = ci
         L.mlpg_hip_gather_path.argtypes = [ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+        L.mlpg_hip_unit_mse_step.restype = ci
+        L.mlpg_hip_unit_mse_step.argtypes = [ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, cd, vp, vp, vp, vp, vp,
+                                             ctypes.c_size_t]
+        L.mlpg_hip_unit_mse_workspace_bytes.restype = ctypes.c_size_t
+        L.mlpg_hip_unit_mse_workspace_bytes.argtypes = [ci, ci, ci]
         L.mlpg_hip_stream_copy.restype = ci
         L.mlpg_hip_stream_copy.argtypes = [ci, vp, vp, vp, ctypes.c_size_t]
         if L.mlpg_hip_abi_version() != ABI_VERSION:
@@ -553,6 +560,43 @@ def gather_path(src, path, path_len, Tout):
                                     _p(path_len), N, Tsrc, path.shape[1], D, Tout, _p(out))
     _check(rc, "mlpg_hip_gather_path")
     return out
+
+
+_MSE_WORKSPACE = {}
+
+
+def unit_mse_step(mean, target, windows, lengths=None, n_elems=None, want_y=False, want_status=False):
+    """Fused unit-variance MLPG + MSE training step on device tensors (mlpg_hip_unit_mse_step): mean (B, T, D), target
+    (B, T, D / nw), float32 or float64.  Returns (loss float64 0-dim tensor, grad_mean (B, T, D), y or None, status or None)."""
+    torch = torch_mod()
+    assert mean.is_cuda and mean.dim() == 3 and mean.is_contiguous() and target.is_contiguous()
+    B, T, D = mean.shape
+    nw = _nw(windows)
+    sd = D // nw
+    assert target.shape == (B, T, sd) and target.dtype == mean.dtype and target.device == mean.device
+    wl, wu, wc = pack_windows(windows)
+    if lengths is not None:
+        assert lengths.dtype == torch.int32 and lengths.shape == (B,) and lengths.device == mean.device
+    if n_elems is None:
+        n_elems = float(B * T * sd)
+    grad = torch.empty_like(mean)
+    y = torch.empty_like(target) if want_y else None
+    loss = torch.empty((), dtype=torch.float64, device=mean.device)
+    status = torch.empty((B * sd,), dtype=torch.int32, device=mean.device) if want_status else None
+    need = int(lib().mlpg_hip_unit_mse_workspace_bytes(B, D, nw))
+    stream = torch.cuda.current_stream(mean.device)
+    key = (mean.device.index, stream.cuda_stream)
+    ws = _MSE_WORKSPACE.get(key)
+    if ws is None or ws.numel() < need:
+        # zeroed once; the kernel leaves its arrival counter zero.  One per (device, stream): concurrent streams do not share
+        # it; allocated on first use outside any capture (warm up a step before capturing it into a graph).
+        ws = torch.zeros((need + 4095) // 4096 * 4096, dtype=torch.uint8, device=mean.device)
+        _MSE_WORKSPACE[key] = ws
+    rc = lib().mlpg_hip_unit_mse_step(mean.device.index, _stream(mean.device), _dt(mean), _p(mean), _p(target), _p(lengths),
+                                      B, T, D, nw, _np(wl), _np(wu), _np(wc), float(n_elems), _p(y), _p(grad), _p(loss),
+                                      _p(status), _p(ws), ws.numel())
+    _check(rc, "mlpg_hip_unit_mse_step")
+    return loss, grad, y, status
 
 
 def stream_copy(src, dst):

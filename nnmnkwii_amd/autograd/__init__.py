@@ -1,2 +1,3 @@
-from ._mlpg import MLPG, UnitVarianceMLPG, mlpg, unit_variance_mlpg  # noqa: F401
+from ._mlpg import (MLPG, UnitVarianceMLPG, UnitVarianceMLPGMSELoss, mlpg, unit_variance_mlpg,  # noqa: F401
+                    unit_variance_mlpg_mse_loss)
 from ._modspec import ModSpec, modspec  # noqa: F401

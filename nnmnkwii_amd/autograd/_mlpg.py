@@ -213,3 +213,55 @@ def unit_variance_mlpg(R, means):
     """Unit-variance MLPG; note the argument order ``(R, means)``
     (autograd/_impl/mlpg.py:202-217)."""
     return UnitVarianceMLPG.apply(means, R)
+
+
+class UnitVarianceMLPGMSELoss(Function):
+    """``MSELoss(unit_variance_mlpg(R, means), target)`` as ONE autograd node and one kernel launch.
+
+    Not in the reference: there the step is ``unit_variance_mlpg`` followed by ``torch.nn.MSELoss`` (its own training
+    benchmark, perf/autograd_mlpg_perf.py:56-86) -- a dense ``R @ means``, a dozen small framework kernels for the
+    loss, a dense ``R^T @ grad``.  On the GPU the two banded solves take 30 microseconds each and everything around
+    them is launch overhead; ``mlpg_hip_unit_mse_step`` runs both solves of a system in the same wavefront (same
+    matrix: unit variances), keeps the trajectory in registers in between, sums the loss in a fixed order and writes
+    ``d loss / d means`` in the forward pass already.  ``backward`` only scales that gradient by the incoming one.
+
+    ``means`` ``(B, T, D)`` or ``(T, D)`` frame-major (not the reshaped ``(T*nw, static_dim)`` form), ``target``
+    ``(B, T, static_dim)`` / ``(T, static_dim)``; float32 or float64.  Same value and gradient as the two-node form
+    (tests/test_autograd_gpu.py).
+    """
+
+    @staticmethod
+    def forward(ctx, means, target, windows):
+        dev = _hip.require_gpu(means.device if means.is_cuda else None)
+        m = _to_gpu(means, dev)
+        if m.dtype not in (torch.float32, torch.float64):
+            m = m.to(torch.float32)
+        t = _to_gpu(target, dev).to(m.dtype)
+        if m.dim() == 2:
+            m, t = m[None], t[None]
+        loss, grad, _, _ = _hip.unit_mse_step(m, t, windows)
+        ctx.save_for_backward(grad)
+        ctx.shape = means.shape
+        ctx.like = means
+        return loss.to(means.dtype) if means.dtype.is_floating_point else loss.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (grad,) = ctx.saved_tensors
+        g = grad * grad_loss.to(grad.dtype)
+        return _back(g.reshape(ctx.shape), ctx.like), None, None
+
+
+def unit_variance_mlpg_mse_loss(R_or_windows, means, target):
+    """``torch.nn.functional.mse_loss(unit_variance_mlpg(R, means), target)`` in one fused launch
+    (:class:`UnitVarianceMLPGMSELoss`).  The first argument is either the matrix ``R`` from
+    :func:`nnmnkwii_amd.paramgen.unit_variance_mlpg_matrix` (recognised by content, as in
+    :func:`unit_variance_mlpg`) or the window list itself.  A foreign ``R`` falls back to the two-node form."""
+    if torch.is_tensor(R_or_windows):
+        ident = _identify_R(R_or_windows)
+        if ident is None or means.shape[-2] != R_or_windows.shape[0]:
+            return torch.nn.functional.mse_loss(unit_variance_mlpg(R_or_windows, means), target)
+        windows = ident[0]
+    else:
+        windows = R_or_windows
+    return UnitVarianceMLPGMSELoss.apply(means, target, windows)

@@ -291,7 +291,7 @@ using namespace mlpg;
 
 extern "C" {
 
-__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 9; }
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 10; }
 
 __attribute__((visibility("default"))) const char *mlpg_hip_last_error(void) { return g_err; }
 
@@ -462,6 +462,75 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
     }
   if (int rc = join_side()) return rc;
   return 0;
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_unit_mse_step(int device, void *stream, int dtype, const void *mean,
+                                                                  const void *target, const int32_t *lengths, int B,
+                                                                  int Tmax, int D, int num_windows,
+                                                                  const int32_t *win_l_h, const int32_t *win_u_h,
+                                                                  const double *win_coef_h, double n_elems, void *y_out,
+                                                                  void *grad_mean, double *loss, int32_t *status,
+                                                                  void *workspace, size_t workspace_bytes) {
+  if (int rc = check_common(B, Tmax, D, num_windows)) return rc;
+  if (dtype != MLPG_HIP_F32 && dtype != MLPG_HIP_F64) {
+    set_error("dtype must be MLPG_HIP_F32 or MLPG_HIP_F64");
+    return MLPG_HIP_EINVAL;
+  }
+  if (!(n_elems > 0.0)) {
+    set_error("unit_mse_step: n_elems must be positive");
+    return MLPG_HIP_EINVAL;
+  }
+  WinSet ws;
+  if (int rc = pack_windows(num_windows, win_l_h, win_u_h, win_coef_h, &ws)) return rc;
+  if (!loss) {
+    set_error("unit_mse_step: NULL loss pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  if (!unit_mse_supported(Tmax > 0 ? Tmax : 1, ws)) {
+    set_error("unit_mse_step: needs window extents <= 1 and T <= 1024 (T=%d, half-bandwidth %d)", Tmax, ws.q);
+    return MLPG_HIP_EINVAL;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0 || Tmax == 0 || D == 0) {
+    MLPG_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(double), st));
+    return 0;
+  }
+  if (!mean || !target || !grad_mean) {
+    set_error("NULL data pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  if (!workspace || workspace_bytes < unit_mse_workspace_bytes(B, D / num_windows) || ((uintptr_t)workspace & 127)) {
+    set_error("unit_mse_step: workspace of %zu bytes (128-byte aligned) needed, see mlpg_hip_unit_mse_workspace_bytes",
+              unit_mse_workspace_bytes(B, D / num_windows));
+    return MLPG_HIP_EINVAL;
+  }
+  Problem p;
+  p.mean = mean;
+  p.var = nullptr;
+  p.grad_out = nullptr;
+  p.lengths = lengths;
+  p.out = grad_mean;
+  p.status = status;
+  p.var_mode = MLPG_HIP_VAR_UNIT;
+  p.B = B;
+  p.Tmax = Tmax;
+  p.D = D;
+  p.sd = D / num_windows;
+  p.ld_in = D;
+  p.ld_gout = 0;
+  p.ld_out = D;
+  p.ld_status = D / num_windows;
+  return launch_unit_mse(st, dtype, p, ws, target, y_out, n_elems, loss, workspace);
+}
+
+__attribute__((visibility("default"))) size_t mlpg_hip_unit_mse_workspace_bytes(int B, int D, int num_windows) {
+  if (B < 0 || D < 0 || num_windows < 1) return 0;
+  return unit_mse_workspace_bytes(B, D / num_windows);
 }
 
 __attribute__((visibility("default"))) int mlpg_hip_stream_copy(int device, void *stream, const void *src, void *dst,

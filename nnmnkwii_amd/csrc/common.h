@@ -59,6 +59,10 @@ bool strip_supported(const Problem &p, const WinSet &w);
 bool strip_preferred(const Problem &p, const WinSet &w, bool backward, int in_dtype);
 int launch_strip(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
                  int device);
+bool unit_mse_supported(int Tmax, const WinSet &w);
+size_t unit_mse_workspace_bytes(int B, int sd);
+int launch_unit_mse(hipStream_t s, int dtype, const Problem &p, const WinSet &w, const void *target, void *y_out,
+                    double n_elems, double *loss, void *workspace);
 bool pipe_supported(const Problem &p, const WinSet &w);
 int launch_pipe(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
 int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,

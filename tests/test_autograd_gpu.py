@@ -145,3 +145,42 @@ def test_foreign_R_is_multiplied_densely():
     means = torch.rand(B, T, nw * sd, device="cuda")
     dense = torch.matmul(Rg, means.view(B, T, nw, sd).transpose(1, 2).reshape(B, nw * T, sd))
     assert torch.allclose(AF.unit_variance_mlpg(Rg, means), dense, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+@pytest.mark.parametrize("shape", [(64, 500, 60), (5, 37, 7), (3, 1000, 4), (2, 200, 25)])
+def test_fused_unit_variance_mse_step_equals_two_node_form(shape, dt):
+    """autograd.unit_variance_mlpg_mse_loss (one fused launch: mlpg_hip_unit_mse_step) against
+    mse_loss(unit_variance_mlpg(R, means), target): same loss, same gradient; config-3 size included.  The float64 case
+    is also checked against the dense float64 definition y = R mu."""
+    import torch
+    from nnmnkwii_amd import autograd as AF
+    from nnmnkwii_amd import paramgen as G
+    B, T, sd = shape
+    dtype = getattr(torch, dt)
+    windows = WINDOW_SETS["std3"]
+    torch.manual_seed(B * T)
+    means = torch.rand(B, T, 3 * sd, dtype=dtype, device="cuda", requires_grad=True)
+    target = torch.rand(B, T, sd, dtype=dtype, device="cuda")
+    R = torch.from_numpy(G.unit_variance_mlpg_matrix(windows, T)).cuda()
+    loss_a = torch.nn.functional.mse_loss(AF.unit_variance_mlpg(R, means), target)
+    loss_a.backward()
+    ga = means.grad.clone()
+    means.grad = None
+    loss_b = AF.unit_variance_mlpg_mse_loss(R, means, target)
+    loss_b.backward()
+    gb = means.grad.clone()
+    tol = 2e-6 if dt == "float32" else 1e-12
+    assert abs(float(loss_a) - float(loss_b)) <= tol * abs(float(loss_a))
+    assert float((ga - gb).abs().max()) <= tol * float(ga.abs().max()) + 1e-30
+    # the window list instead of R, a scaled loss, repeatability
+    means.grad = None
+    (3.0 * AF.unit_variance_mlpg_mse_loss(windows, means, target)).backward()
+    assert float((means.grad - 3.0 * gb).abs().max()) <= 1e-6 * float(gb.abs().max()) + 1e-30
+    l2 = AF.unit_variance_mlpg_mse_loss(R, means, target)
+    assert float(l2) == float(loss_b)
+    if dt == "float64" and T <= 500:
+        Rd = R.double().view(T, 3, T)
+        y = torch.einsum("tws,bswd->btd", Rd, means.detach().view(B, T, 3, sd))
+        ref = ((y - target) ** 2).mean()
+        assert abs(float(ref) - float(loss_b)) <= 1e-6 * float(ref)     # R itself is a float32 matrix

@@ -29,7 +29,7 @@ def test_exports_match_header(L):
     assert declared == set(_hip.EXPORTS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.mlpg_hip_abi_version() == _hip.ABI_VERSION == 9
+    assert L.mlpg_hip_abi_version() == _hip.ABI_VERSION == 10
 
 
 def test_argument_validation_without_gpu(L):

@@ -210,3 +210,24 @@ def test_modspec_oracle_matches_reference_goldens():
         np.testing.assert_allclose(grad, g[case + "/grad"], rtol=0, atol=2e-5 * np.abs(g[case + "/grad"]).max())   # float32 goldens
         seen += 1
     assert seen > 30
+
+
+def test_dtw_oracle_matches_64_reference_pairs_with_numpy_norm():
+    """Round 3: 64 BASELINE config-4 sized pairs (T in [700, 900], 25-dim) through the reference's unmodified
+    DTWAligner with its own ``dist = lambda x, y: norm(x - y)`` (numpy BLAS order), paths recorded by
+    tests/golden/make_golden3.py.  The C oracle sums the local cost sequentially; on these ~110 000 path cells (about a
+    million window cells) the two orders never lead the DP to a different decision, and the distances agree to rounding.
+    (fastdtw itself is bound to the literal restatement there: parity unpinned, as oracle/dtw.py says.)"""
+    import os
+    from cases import c4_pairs
+    from oracle import dtw as OD
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dtw_paths64.npz"))
+    X, Y = c4_pairs(64, seed=64)
+    assert len(g["plen"]) == 64
+    for n in range(64):
+        x, y = OD.trim_zeros_frames(X[n]), OD.trim_zeros_frames(Y[n])
+        assert (len(x), len(y)) == (int(g["lenx"][n]), int(g["leny"][n]))
+        d, path = OD.fastdtw(x, y, 1)
+        k = int(g["plen"][n])
+        assert len(path) == k and np.array_equal(path, g["paths"][n, :k].astype(np.int32)), n
+        assert abs(d - g["dist"][n]) <= 1e-12 * g["dist"][n]

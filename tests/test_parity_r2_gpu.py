@@ -300,3 +300,30 @@ def test_shutdown_releases_everything_and_the_library_keeps_working():
     c = run()
     for u, v, w in zip(a, b, c):
         assert np.array_equal(u, v) and np.array_equal(u, w)
+
+
+def test_config4_64_pairs_paths_vs_reference_with_numpy_norm():
+    """64 config-4 pairs: the HIP fastdtw paths against the paths the reference's DTWAligner took with its own
+    ``norm(x - y)`` dist (tests/golden/dtw_paths64.npz, make_golden3.py), index for index, and the aligned arrays the
+    aligner returns against ``X[path_i]`` / ``Y[path_j]`` built from those paths."""
+    import torch
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    g = np.load(os.path.join(HERE, "golden", "dtw_paths64.npz"))
+    X, Y = c4_pairs(64, seed=64)
+    Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+    lenx, leny = _hip.trim_lengths(Xd), _hip.trim_lengths(Yd)
+    assert np.array_equal(lenx.cpu().numpy(), g["lenx"]) and np.array_equal(leny.cpu().numpy(), g["leny"])
+    pi, pj, pl, cost = _hip.fastdtw_l2(Xd, Yd, lenx, leny, 1)
+    pi, pj, pl, cost = pi.cpu().numpy(), pj.cpu().numpy(), pl.cpu().numpy(), cost.cpu().numpy()
+    assert np.array_equal(pl, g["plen"])
+    for n in range(64):
+        k = int(pl[n])
+        assert np.array_equal(pi[n, :k], g["paths"][n, :k, 0]) and np.array_equal(pj[n, :k], g["paths"][n, :k, 1]), n
+    assert np.abs(cost - g["dist"]).max() <= 1e-12 * g["dist"].max()
+    Xa, Ya = DTWAligner().transform((X, Y))
+    assert Xa.shape[1] == int(g["T_out"][0])
+    for n in (0, 17, 63):
+        k = int(pl[n])
+        assert np.array_equal(Xa[n, :k], X[n][g["paths"][n, :k, 0]]) and np.array_equal(Ya[n, :k], Y[n][g["paths"][n, :k, 1]])
+        assert not Xa[n, k:].any() and not Ya[n, k:].any()

@@ -282,6 +282,35 @@ def _run(only, quick, device_index):
             rm = mc.view(B, T, 3, -1).transpose(1, 2).contiguous().view(B, -1, D // 3)
             loss_fn(torch.matmul(Rc, rm), tc).backward()
         cpu_s = (time.perf_counter() - t0) / nrep
+        # the same step as ONE fused launch (autograd.unit_variance_mlpg_mse_loss -> mlpg_hip_unit_mse_step)
+        def step_fused():
+            means.grad = None
+            AF.unit_variance_mlpg_mse_loss(R, means, target).backward()
+
+        ms_fused = gpu_time(step_fused, steps=20)
+        ms_fused_kernel = gpu_time(lambda: _hip.unit_mse_step(md, target, WINDOWS), steps=20)
+        ms_fused_graph = None
+        try:
+            torch.cuda.synchronize()
+            g2 = torch.cuda.CUDAGraph()
+            means.grad = None
+            side2 = torch.cuda.Stream()
+            side2.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side2):
+                for _ in range(3):
+                    step_fused()
+            torch.cuda.current_stream().wait_stream(side2)
+            torch.cuda.synchronize()
+            means.grad = None
+            with torch.cuda.graph(g2):
+                AF.unit_variance_mlpg_mse_loss(R, means, target).backward()
+            ms_fused_graph = gpu_time(g2.replay, steps=20)
+        except Exception as e:  # noqa: BLE001
+            ms_fused_graph = "capture failed: %s" % str(e)[:120]
+        emit(path="c3-fused-unit-mse-step", ms=ms_fused_kernel, ms_autograd_eager=ms_fused, ms_hip_graph_replay=ms_fused_graph,
+             frames_per_s=B * T / ms_fused_kernel * 1e3, alg_bytes=by + 4.0 * 60 * B * T, GBps=(by + 4.0 * 60 * B * T) / ms_fused_kernel / 1e6,
+             note="ms = one mlpg_hip_unit_mse_step call (one kernel, nothing allocated): forward + MSE loss + backward of config 3; "
+                  "ms_autograd_eager / ms_hip_graph_replay = the same through autograd.unit_variance_mlpg_mse_loss(...).backward()")
         emit(path="c3-unit-variance-autograd-fwd+bwd", ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by,
              GBps=by / ms / 1e6, ms_hip_graph_replay=ms_graph,
              GBps_hip_graph_replay=(by / ms_graph / 1e6 if isinstance(ms_graph, float) else None),
