@@ -291,6 +291,10 @@ int mlpg_hip_trim_lengths(int device, void *stream, int dtype, const void *X,
 #define MLPG_HIP_DIST_SCALED_L2_NP 1 /* dist_scale * sqrt(((x-y)*(x-y)).sum()) with the sum in numpy's pairwise
                                         order (D <= 128): metrics.melcd(x, y) for two frames
                                         (metrics/__init__.py:27-59) with dist_scale = 10/ln(10)*sqrt(2) */
+#define MLPG_HIP_DIST_SCALED_L1_NP 2 /* dist_scale * np.abs(x-y).sum(): city-block distance, numpy's pairwise order */
+#define MLPG_HIP_DIST_SCALED_SQL2_NP 3 /* dist_scale * ((x-y)**2).sum(): squared Euclidean, numpy's pairwise order
+                                        (what DTWAligner(dist=...) callables of those forms resolve to; the reference
+                                        accepts any Python callable, alignment.py:35 -- the kernel evaluates the cost) */
 int mlpg_hip_fastdtw(int device, void *stream, const double *X,
                      const double *Y, const int32_t *lenx,
                      const int32_t *leny, int N, int Tx, int Ty, int D,

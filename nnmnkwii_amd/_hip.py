@@ -492,7 +492,7 @@ def trim_lengths(X, eps=1e-7):
     return lengths
 
 
-DIST_L2, DIST_SCALED_L2_NP = 0, 1
+DIST_L2, DIST_SCALED_L2_NP, DIST_SCALED_L1_NP, DIST_SCALED_SQL2_NP = 0, 1, 2, 3
 
 
 def fastdtw_l2(X, Y, lenx, leny, radius=1, dist_kind=DIST_L2, dist_scale=1.0):

@@ -106,36 +106,33 @@ __device__ __forceinline__ double l2_cost(const double *__restrict__ a, const do
 // partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail): what
 // `scale * math.sqrt(((x - y) * (x - y)).sum(-1))` evaluates to, i.e. the reference's metrics.melcd(x, y) for two
 // frames (metrics/__init__.py:27-59) with scale = 10 / ln 10 * sqrt 2.
-__device__ __forceinline__ double np_l2_cost(const double *__restrict__ a, const double *__restrict__ b, int D, double scale) {
+template <int F>
+__device__ __forceinline__ double np_term(double diff) {
+  return F == 1 ? __builtin_fabs(diff) : __dmul_rn(diff, diff);
+}
+// F = 0: scale * sqrt(sum (a-b)^2)   1: scale * sum |a-b|   2: scale * sum (a-b)^2
+template <int F>
+__device__ __forceinline__ double np_cost(const double *__restrict__ a, const double *__restrict__ b, int D, double scale) {
   double res;
   if (D < 8) {
     res = 0.0;
-    for (int k = 0; k < D; ++k) {
-      const double diff = __dsub_rn(a[k], b[k]);
-      res = __dadd_rn(res, __dmul_rn(diff, diff));
-    }
+    for (int k = 0; k < D; ++k) res = __dadd_rn(res, np_term<F>(__dsub_rn(a[k], b[k])));
   } else {
     double r[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const double diff = __dsub_rn(a[q], b[q]);
-      r[q] = __dmul_rn(diff, diff);
-    }
+    for (int q = 0; q < 8; ++q) r[q] = np_term<F>(__dsub_rn(a[q], b[q]));
     int k = 8;
     for (; k < D - (D % 8); k += 8) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const double diff = __dsub_rn(a[k + q], b[k + q]);
-        r[q] = __dadd_rn(r[q], __dmul_rn(diff, diff));
-      }
+      for (int q = 0; q < 8; ++q) r[q] = __dadd_rn(r[q], np_term<F>(__dsub_rn(a[k + q], b[k + q])));
     }
     res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])), __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
-    for (; k < D; ++k) {
-      const double diff = __dsub_rn(a[k], b[k]);
-      res = __dadd_rn(res, __dmul_rn(diff, diff));
-    }
+    for (; k < D; ++k) res = __dadd_rn(res, np_term<F>(__dsub_rn(a[k], b[k])));
   }
-  return __dmul_rn(scale, __dsqrt_rn(res));
+  return __dmul_rn(scale, F == 0 ? __dsqrt_rn(res) : res);
+}
+__device__ __forceinline__ double np_l2_cost(const double *__restrict__ a, const double *__restrict__ b, int D, double scale) {
+  return np_cost<0>(a, b, D, scale);
 }
 
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total) {
@@ -390,8 +387,11 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         }
         const int row = i0 + a;
         const int j = (int)lo[row] + cc - (off[row] - base);
-        dst[cc + 2 * a + 1] = p.dist_kind == MLPG_HIP_DIST_L2 ? l2_cost(xk + (size_t)row * D, yk + (size_t)j * D, D)
-                                                              : np_l2_cost(xk + (size_t)row * D, yk + (size_t)j * D, D, p.dist_scale);
+        const double *xr = xk + (size_t)row * D, *yr = yk + (size_t)j * D;
+        dst[cc + 2 * a + 1] = p.dist_kind == MLPG_HIP_DIST_L2             ? l2_cost(xr, yr, D)
+                              : p.dist_kind == MLPG_HIP_DIST_SCALED_L2_NP ? np_cost<0>(xr, yr, D, p.dist_scale)
+                              : p.dist_kind == MLPG_HIP_DIST_SCALED_L1_NP ? np_cost<1>(xr, yr, D, p.dist_scale)
+                                                                          : np_cost<2>(xr, yr, D, p.dist_scale);
       }
       for (int a = tid - t0; a < R; a += nthr) {  // the +INF frame of every row
         dst[off[i0 + a] - base + 2 * a] = INFINITY;
@@ -726,12 +726,12 @@ size_t lds_bytes(int Tx, int Ty, int D, const DtwParams &p) {
 int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, const int32_t *lenx,
                    const int32_t *leny, int N, int Tx, int Ty, int D, int radius, int dist_kind, double dist_scale,
                    int32_t *path_i, int32_t *path_j, int32_t *path_len, double *cost) {
-  if (dist_kind != MLPG_HIP_DIST_L2 && dist_kind != MLPG_HIP_DIST_SCALED_L2_NP) {
+  if (dist_kind < MLPG_HIP_DIST_L2 || dist_kind > MLPG_HIP_DIST_SCALED_SQL2_NP) {
     set_error("fastdtw: unknown local distance %d", dist_kind);
     return MLPG_HIP_EINVAL;
   }
-  if (dist_kind == MLPG_HIP_DIST_SCALED_L2_NP && D > 128) {
-    set_error("fastdtw: MLPG_HIP_DIST_SCALED_L2_NP reproduces numpy's summation order up to 128 feature dims (got %d)", D);
+  if (dist_kind != MLPG_HIP_DIST_L2 && D > 128) {
+    set_error("fastdtw: the MLPG_HIP_DIST_*_NP distances reproduce numpy's summation order up to 128 feature dims (got %d)", D);
     return MLPG_HIP_EINVAL;
   }
   if (Tx > 65000 || Ty > 65000) {

@@ -23,6 +23,9 @@ def _resolve_dist(dist):
     * the default (``norm(x - y)``) and any callable that IS the Euclidean distance -> MLPG_HIP_DIST_L2;
     * ``metrics.melcd`` (this package's or the reference's) and any callable that is a positive multiple of the
       Euclidean distance -> MLPG_HIP_DIST_SCALED_L2_NP (numpy summation order, the multiple as measured);
+    * a positive multiple of the city-block distance ``np.abs(x - y).sum()`` (``norm(x - y, 1)``,
+      ``scipy.spatial.distance.cityblock``) or of the squared Euclidean distance ``((x - y) ** 2).sum()``
+      (``sqeuclidean``) -> MLPG_HIP_DIST_SCALED_L1_NP / MLPG_HIP_DIST_SCALED_SQL2_NP;
     * anything else cannot run on the GPU (there is no CPU fallback): NotImplementedError.
     The callable is only probed on a few random frame pairs, never called per DP cell.
     """
@@ -33,25 +36,29 @@ def _resolve_dist(dist):
         return _hip.DIST_SCALED_L2_NP, float(metrics._logdb_const)
     if not callable(dist):
         raise TypeError("dist must be callable")
+    # candidate forms, each evaluated by the kernel in numpy's summation order: Euclidean, city-block, squared Euclidean
+    forms = (
+        (_hip.DIST_SCALED_L2_NP, lambda x, y: float(norm(x - y))),
+        (_hip.DIST_SCALED_L1_NP, lambda x, y: float(np.abs(x - y).sum())),
+        (_hip.DIST_SCALED_SQL2_NP, lambda x, y: float(((x - y) ** 2).sum())),
+    )
     rng = np.random.RandomState(12345)
-    ratios = []
+    probes = [(rng.randn(D), rng.randn(D)) for D in (1, 5, 25) for _ in range(3)]
     try:
-        for D in (1, 5, 25):
-            for _ in range(3):
-                x, y = rng.randn(D), rng.randn(D)
-                ratios.append(float(dist(x, y)) / float(norm(x - y)))
+        vals = np.asarray([float(dist(x, y)) for x, y in probes])
     except Exception as e:   # a callable that does not take two frames
         raise NotImplementedError("DTWAligner: cannot evaluate `dist` on two frames (%s)" % e)
-    ratios = np.asarray(ratios)
-    c = float(np.median(ratios))
-    if not (c > 0 and np.all(np.abs(ratios - c) <= 1e-9 * c)):
-        raise NotImplementedError(
-            "nnmnkwii_amd.DTWAligner evaluates the local cost on the GPU: the default Euclidean distance, "
-            "metrics.melcd, or a callable that is a positive multiple of the Euclidean distance; an arbitrary "
-            "Python `dist` cannot run there (and there is no CPU fallback)")
-    if abs(c - 1.0) <= 1e-12:
-        return _hip.DIST_L2, 1.0
-    return _hip.DIST_SCALED_L2_NP, c
+    for kind, form in forms:
+        ratios = vals / np.asarray([form(x, y) for x, y in probes])
+        c = float(np.median(ratios))
+        if c > 0 and np.all(np.abs(ratios - c) <= 1e-9 * c):
+            if kind == _hip.DIST_SCALED_L2_NP and abs(c - 1.0) <= 1e-12:
+                return _hip.DIST_L2, 1.0
+            return kind, c
+    raise NotImplementedError(
+        "nnmnkwii_amd.DTWAligner evaluates the local cost on the GPU: the default Euclidean distance, metrics.melcd, or a "
+        "callable that is a positive multiple of the Euclidean, the city-block (np.abs(x - y).sum()) or the squared Euclidean "
+        "distance; an arbitrary Python `dist` cannot run there (and there is no CPU fallback)")
 
 
 class DTWAligner(object):

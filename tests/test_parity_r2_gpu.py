@@ -162,8 +162,12 @@ def test_dtw_aligner_dist_resolution():
     assert k == _hip.DIST_SCALED_L2_NP and abs(c - 10.0 / np.log(10.0) * np.sqrt(2.0)) < 1e-15
     k, c = _resolve_dist(lambda x, y: 3.0 * norm(x - y))
     assert k == _hip.DIST_SCALED_L2_NP and abs(c - 3.0) < 1e-12
+    k, c = _resolve_dist(lambda x, y: np.abs(x - y).sum())
+    assert k == _hip.DIST_SCALED_L1_NP and abs(c - 1.0) < 1e-12
+    k, c = _resolve_dist(lambda x, y: 0.5 * ((x - y) ** 2).sum())
+    assert k == _hip.DIST_SCALED_SQL2_NP and abs(c - 0.5) < 1e-12
     with pytest.raises(NotImplementedError):
-        _resolve_dist(lambda x, y: np.abs(x - y).sum())
+        _resolve_dist(lambda x, y: np.abs(x - y).max())
     X, Y = c4_pairs(1, seed=5)
     a = DTWAligner(dist=lambda x, y: norm(x - y)).transform((X, Y))
     b = DTWAligner().transform((X, Y))
@@ -327,3 +331,23 @@ def test_config4_64_pairs_paths_vs_reference_with_numpy_norm():
         k = int(pl[n])
         assert np.array_equal(Xa[n, :k], X[n][g["paths"][n, :k, 0]]) and np.array_equal(Ya[n, :k], Y[n][g["paths"][n, :k, 1]])
         assert not Xa[n, k:].any() and not Ya[n, k:].any()
+
+
+@pytest.mark.parametrize("form", ["l1", "sql2"])
+def test_dtw_aligner_cityblock_and_squared_euclidean_callables(form):
+    """dist callables of the city-block and squared-Euclidean forms run on the device (MLPG_HIP_DIST_SCALED_L1_NP /
+    _SQL2_NP, numpy's summation order): paths and aligned arrays against the literal restatement of fastdtw driven by
+    the very same Python callable (oracle/dtw.py::fastdtw_py; small pairs, it calls the callable per DP cell)."""
+    from cases import align_batch
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    from oracle import dtw as OD
+    dist = (lambda x, y: np.abs(x - y).sum()) if form == "l1" else (lambda x, y: ((x - y) ** 2).sum())
+    for X, Y in (align_batch("grow"), c4_pairs(2, seed=7)):     # 4-dim (sequential sum) and 25-dim (pairwise sum) frames
+        Xa, Ya = DTWAligner(dist=dist).transform((X, Y))
+        for n in range(X.shape[0]):
+            x, y = OD.trim_zeros_frames(X[n]), OD.trim_zeros_frames(Y[n])
+            _, path = OD.fastdtw_py(x, y, radius=1, dist=dist)
+            path = np.asarray(path)
+            k = len(path)
+            assert np.array_equal(Xa[n, :k], x[path[:, 0]]) and np.array_equal(Ya[n, :k], y[path[:, 1]]), (form, n)
+            assert not Xa[n, k:].any() and not Ya[n, k:].any()
