@@ -86,6 +86,10 @@ constexpr int kCtrlLine = 32;
 #ifndef MLPG_STRIP_RING_F32
 #define MLPG_STRIP_RING_F32 6
 #endif
+#ifndef MLPG_STRIP_PREFETCH
+#define MLPG_STRIP_PREFETCH 0  // frames of the NEXT item's chunk touched (LDS-DMA loads into a dummy LDS line: no register is
+                                // written) while this item back-substitutes: its first ring then comes out of L2 (0: off)
+#endif
 #ifndef MLPG_STRIP_NT_STORES
 #define MLPG_STRIP_NT_STORES 0  // trajectory rows with the nontemporal hint (written once, never read by this kernel)
 #endif
@@ -164,7 +168,7 @@ constexpr size_t kLdsStage = (size_t)kStage * kRec * 64 * 8;     // level-3 stag
 constexpr size_t kLdsPark = (size_t)kPark * 64 * 8;
 constexpr size_t kLdsFac = (size_t)(kW - 1) * kFac * 64 * 8;
 constexpr size_t kLdsU = (size_t)(kW + 1) * 2 * 64 * 8;
-constexpr size_t kLdsMisc = 64;
+constexpr size_t kLdsMisc = 64 + kW * 256;  // control words + a throw-away line per wavefront (MLPG_STRIP_PREFETCH)
 constexpr size_t kLdsBytes = kLdsStage + kLdsPark + kLdsFac + kLdsU + kLdsMisc;
 static_assert(kW * kRec <= kStage * kRec, "level-1 records must fit the staging area");
 static_assert(kLdsBytes <= 80 * 1024, "two workgroups per CU");
@@ -272,6 +276,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
   const unsigned long long u = (unsigned long long)base;
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
   return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+
+// A load whose result nobody wants (MLPG_STRIP_PREFETCH): it brings the row's lines into L2.  An LDS-DMA load into a
+// throw-away LDS line, so that no register is written (a register destination would have to stay reserved until the
+// data lands -- as inline assembly with a dead destination it silently overwrote whatever the allocator put there
+// next; as a builtin load it costs the registers this kernel does not have).  One dword per lane at this lane's
+// 8-byte (4-byte for float32) stride touches every line of the row.
+__device__ __forceinline__ void touch_row(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff, void *lds_dummy) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_dummy, 4, (int)loff, (int)soff, 0, 0);
 }
 
 // EDGE: a dead frame of the window (outside [lo, hi)) is loaded from the nearest live frame instead -- a finite
@@ -915,6 +928,8 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < 16) lds_misc[tid] = 0;
+  __syncthreads();
 
 #ifdef MLPG_STRIP_TIMING
   // claim, assemble, eliminate, barrier, level 2, publish, poll, barrier, level-3 staging, level-3 sweep, level-2 backsub, barrier, backsub, store
@@ -928,6 +943,8 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
   const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;  // hwreg(HW_REG_XCC_ID, 0, 4)
   const int R = a.R;
   const int phase = (MLPG_STRIP_PHASES > 1 && a.nlists > 1 && blockIdx.x >= gridDim.x / 2) ? 1 : 0;
+  int cur_lst = 0, cur_lim = 0;   // the work list this workgroup is drawing from (MLPG_STRIP_PREFETCH draws inside the body)
+  int *cur_ticket = nullptr;
   auto body = [&](const int g, const int r) __attribute__((always_inline)) {
   const int b = g / a.ndg, dg = g - b * a.ndg;
   const int sd = p.sd, Tmax = p.Tmax;
@@ -1344,6 +1361,14 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       if (bad3) sig.x = __builtin_nan("");
     }
 
+    if (MLPG_STRIP_PREFETCH && lane == 0) {
+      // Nothing this item still needs comes from another workgroup: the next ticket may be drawn (not earlier -- a
+      // ticket held unpublished while this strip waits for its utterance could be the very strip it waits for).
+      int tkn = cur_lim;
+      if (__hip_atomic_load(cur_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cur_lim) tkn = atomicAdd(cur_ticket, 1);
+      lds_misc[5] = tkn;
+      lds_misc[6] = 1;
+    }
     // ---- back-substitution of level 2 ----
     double *up = lds_u + lane;
     up[0] = sprev.x; up[64] = sprev.y;
@@ -1438,6 +1463,43 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
   const V2 uo = {lds_u[((wv + 1) * 2) * 64 + lane], lds_u[((wv + 1) * 2 + 1) * 64 + lane]};
   const double sx = lds_u[(kW * 2) * 64 + lane];
   const bool sys_bad = !(sx == sx) || !(uo.x == uo.x) || !(ul.x == ul.x);  // NaN: some pivot of this system failed
+  const int ntk = MLPG_STRIP_PREFETCH ? __builtin_amdgcn_readfirstlane(lds_misc[5]) : 0;
+  asm volatile("" ::: "memory");
+  if (MLPG_STRIP_PREFETCH) {
+    // the next item of this workgroup is known: touch the first frames of this wavefront's chunk of it, so that they
+    // travel from HBM while this item back-substitutes and stores
+    // (issued AFTER this item's last LDS reads: the compiler orders every LDS access behind outstanding LDS-DMA loads)
+    if (ntk < cur_lim) {
+      const int g2 = (ntk / R) * a.nlists + cur_lst, r2 = ntk % R;
+      const int b2 = g2 / a.ndg, dg2 = g2 - b2 * a.ndg;
+      int T2 = p.lengths ? p.lengths[b2] : Tmax;
+      T2 = T2 < 0 ? 0 : (T2 > Tmax ? Tmax : T2);
+      const int fn = (r2 * kW + wv) * kM;
+      if (fn < T2) {
+        const int dn0 = dg2 * a.dgw;
+        const int nd2 = sd - dn0 < a.dgw ? sd - dn0 : a.dgw;
+        const unsigned loff2 = (unsigned)(lane < nd2 ? lane : nd2 - 1) * (unsigned)sizeof(TIN);
+        const __amdgpu_buffer_rsrc_t mr = make_rsrc(BWD ? (const TIN *)p.out : (const TIN *)p.mean + (size_t)b2 * Tmax * ldi + dn0);
+        const __amdgpu_buffer_rsrc_t vr =
+            make_rsrc(VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)b2 * Tmax * ldi + dn0 : (const TIN *)p.out);
+        const unsigned lb = (unsigned)ldi * (unsigned)sizeof(TIN), wb = (unsigned)sd * (unsigned)sizeof(TIN);
+        void *dummy = (void *)(lds_misc + 16 + wv * 64);
+#pragma unroll
+        for (int q = 0; q < (MLPG_STRIP_PREFETCH > 100 ? 0 : MLPG_STRIP_PREFETCH); ++q) {
+          int t = fn - 1 + q;
+          t = t < 0 ? 0 : (t >= T2 ? T2 - 1 : t);
+#pragma unroll
+          for (int w = 0; w < 3; ++w) {
+            if (w < nw) {
+              const unsigned so = (unsigned)t * lb + (unsigned)w * wb;
+              if (VM == MLPG_HIP_VAR_FRAME) touch_row(vr, so, loff2, dummy);
+              if (!BWD) touch_row(mr, so, loff2, dummy);
+            }
+          }
+        }
+      }
+    }
+  }
   if (MLPG_STRIP_ABLATE < 2) backsub(Pd, P1, P2, rhs, ca, cb, cc, ul, uo);
   STRIP_TICK(12);
 
@@ -1563,11 +1625,20 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
     const int lst = (xcd + phase * 8 + k) % a.nlists;
     const int lim = ((a.nsg - lst + a.nlists - 1) / a.nlists) * R;  // items of this list
     int *ticket = a.ctrl + (1 + lst) * kCtrlLine;
+    cur_lst = lst;
+    cur_lim = lim;
+    cur_ticket = ticket;
     for (;;) {
       if (tid == 0) {
         int tk = lim;  // a plain look first: an exhausted list costs no read-modify-write
-        if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lim) tk = atomicAdd(ticket, 1);
+        if (MLPG_STRIP_PREFETCH && lds_misc[6]) {
+          tk = lds_misc[5];  // drawn inside the previous item (from this same list)
+        } else if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lim) {
+          tk = atomicAdd(ticket, 1);
+        }
         lds_misc[0] = tk;
+        lds_misc[5] = lim;
+        lds_misc[6] = 0;
       }
       __syncthreads();
       const int tk = __builtin_amdgcn_readfirstlane(lds_misc[0]);
