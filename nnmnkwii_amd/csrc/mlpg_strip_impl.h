@@ -86,6 +86,9 @@ constexpr int kCtrlLine = 32;
 #ifndef MLPG_STRIP_RING_F32
 #define MLPG_STRIP_RING_F32 6
 #endif
+#ifndef MLPG_STRIP_BWD_FRAME_MAJOR
+#define MLPG_STRIP_BWD_FRAME_MAJOR 1  // backward epilogue frame by frame (three adjacent row stores, ring of variance loads)
+#endif
 #ifndef MLPG_STRIP_PREFETCH
 #define MLPG_STRIP_PREFETCH 0  // frames of the NEXT item's chunk touched (LDS-DMA loads into a dummy LDS line: no register is
                                 // written) while this item back-substitutes: its first ring then comes out of L2 (0: off)
@@ -1578,21 +1581,85 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
         ow[(size_t)t * ldo] = zero_out ? (TOUT)0 : (TOUT)gval;
       }
     };
+    if (MLPG_STRIP_BWD_FRAME_MAJOR && nw == 3) {
+      // Frame-major epilogue (round 3): per frame three reciprocals and THREE ADJACENT 480-byte stores -- the wavefront writes its 17 gradient rows as one contiguous 24 KB run in
+      // address order (window-major, the three blocks of a row were written 16 rows of stores apart).
+      // All 51 variance loads are issued before the first store: loads and stores share one in-order counter on this
+      // chip, so a load queued behind stores waits for the stores' acknowledgements (a ring of loads refilled between
+      // the stores ran at one store latency per six frames: 19 k cycles for this epilogue, as long as level 1).
+      constexpr int kEpi = kM + 1;
+      TIN tv[kEpi][3];
+      auto ldf = [&](TIN (&v)[3], const int i) __attribute__((always_inline)) {
+        if (VM != MLPG_HIP_VAR_FRAME) return;
+        int t = f0 + i;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);  // in bounds; a row that is not live is not used
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v[w] = ld_row<TIN>(vrs, (unsigned)t * ldi_bytes + (unsigned)w * win_bytes, loff);
+      };
+      double tg[3] = {1.0, 1.0, 1.0};
+      if (VM == MLPG_HIP_VAR_GLOBAL) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) tg[w] = tau_of<TIN>(vglob[w * sd]);
+      }
+      auto emitf = [&](const TIN (&v)[3], const int i) __attribute__((always_inline)) {
+        const int t = f0 + i;
+        if (t < 0 || t >= Tmax) return;
+        TOUT *orow = out_b + (size_t)t * ldo + d;
+        auto put = [&](const int w, const TOUT val) __attribute__((always_inline)) {
+#ifdef MLPG_STRIP_BWD_NOSTORE  // timing experiment only
+          if (val == (TOUT)123.456) orow[(size_t)w * sd] = val;
+          return;
+#endif
+#if MLPG_STRIP_NT_STORES
+          __builtin_nontemporal_store(val, orow + (size_t)w * sd);
+#else
+          orow[(size_t)w * sd] = val;
+#endif
+        };
+        if (t >= T) {
+          if (i >= 0) { put(0, (TOUT)0); put(1, (TOUT)0); put(2, (TOUT)0); }
+          return;
+        }
+        if (i == -1 && f0 >= T) return;
+        if (i == kM - 1 && t != T - 1) return;  // the next chunk writes it
+        const double xm = (i == -1) ? ul.x : ((i == 0) ? ul.y : rhs[i > 0 ? i - 1 : 0]);
+        const double x0 = (i == -1) ? ul.y : rhs[i >= 0 ? i : 0];
+        const double xp = (i == kM - 1) ? 0.0 : rhs[i + 1];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const bool lv = w ? (mw != 0 && t >= mw && t < T - mw) : true;
+          double tau = 0.0;
+          if (lv) tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[w]) : tg[w];
+          const double gval = tau * (a.wc[w][0] * xm + a.wc[w][1] * x0 + a.wc[w][2] * xp);
+          put(w, zero_out ? (TOUT)0 : (TOUT)gval);
+        }
+      };
+#pragma unroll
+      for (int sl = 0; sl < kEpi; ++sl) ldf(tv[sl], sl - 1);
+      __builtin_amdgcn_sched_barrier(0);
+#define STRIP_EPI(S)                                                        \
+      emitf(tv[(S)], (S)-1);                                                  \
+      __builtin_amdgcn_sched_barrier(0);
+      STRIP_EPI(0) STRIP_EPI(1) STRIP_EPI(2) STRIP_EPI(3) STRIP_EPI(4) STRIP_EPI(5) STRIP_EPI(6) STRIP_EPI(7) STRIP_EPI(8)
+      STRIP_EPI(9) STRIP_EPI(10) STRIP_EPI(11) STRIP_EPI(12) STRIP_EPI(13) STRIP_EPI(14) STRIP_EPI(15) STRIP_EPI(16)
+#undef STRIP_EPI
+    } else {
     TIN tvA[kM + 1], tvB[kM + 1];
-    load_w(tvA, 0);
-    for (int w = 0; w < nw; w += 2) {
-      if (w + 1 < nw) load_w(tvB, w + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      emit_w(tvA, w);
-      __builtin_amdgcn_sched_barrier(0);
-      if (w + 1 < nw) {
-        if (w + 2 < nw) load_w(tvA, w + 2);
+      load_w(tvA, 0);
+      for (int w = 0; w < nw; w += 2) {
+        if (w + 1 < nw) load_w(tvB, w + 1);
         __builtin_amdgcn_sched_barrier(0);
-        emit_w(tvB, w + 1);
+        emit_w(tvA, w);
         __builtin_amdgcn_sched_barrier(0);
+        if (w + 1 < nw) {
+          if (w + 2 < nw) load_w(tvA, w + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          emit_w(tvB, w + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
-  }
+    }
 #ifdef MLPG_STRIP_TIMING
   // profiling build only: phase cycle counts of wavefront 0 of strips 0..15 of utterances 0..7 overwrite the head of
   // the status array (run bench.py --no-check with MLPG_DUMP_STATUS=1)
