@@ -8,6 +8,7 @@
 // threads (a single-threaded memcpy is slower than PCIe Gen5); memory that is already pinned (mlpg_hip_host_alloc,
 // hipHostMalloc, hipHostRegister) is transferred in place.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -185,7 +186,8 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_host(int device, int
   const size_t utt_in = (size_t)Tmax * D * esz, utt_out = (size_t)Tmax * sd * esz;
   const bool fvar = var_mode == MLPG_HIP_VAR_FRAME;
   // ~64 MB of input per chunk, at least 4 chunks when the batch allows (so that transfers and kernels overlap)
-  long cb = (long)((64u << 20) / (utt_in * (fvar ? 2 : 1)));
+  static const long chunk_mb = [] { const char *e = getenv("MLPG_HIP_HOST_CHUNK_MB"); const long v = e ? atol(e) : 0; return v > 0 ? v : 64; }();
+  long cb = (long)(((size_t)chunk_mb << 20) / (utt_in * (fvar ? 2 : 1)));
   cb = std::max<long>(1, std::min<long>(cb, (B + 3) / 4));
   const size_t in_bytes = (size_t)cb * utt_in * (fvar ? 2 : 1);
   const size_t out_bytes = up256((size_t)cb * utt_out) + (size_t)cb * sd * sizeof(int32_t);
