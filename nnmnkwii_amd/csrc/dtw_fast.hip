@@ -65,6 +65,7 @@ struct DtwParams {
   double *pyr;        // N * pyr_stride doubles: x levels >= 1, then y levels >= 1
   size_t pyr_stride;  // (Tx + Ty) * D
   int cellcap;        // window cells per level (bound)
+  int hwcap;          // back-pointer halfwords per level (bound)
   int chunkcap;       // cost cells per DP chunk
   int dist_kind;      // MLPG_HIP_DIST_*
   double dist_scale;  // factor of MLPG_HIP_DIST_SCALED_L2_NP
@@ -72,7 +73,10 @@ struct DtwParams {
 
 constexpr int kMaxLevels = 20;
 constexpr int kRows = 63;  // rows per chunk: lanes 1..63 of the sweeping wavefront (lane 0 feeds the row above)
-constexpr int kSeg = 16;    // rows per back-trace segment
+constexpr int kSegMin = 4, kSegMax = 16;  // rows per back-trace segment: chosen per level (see the back-trace)
+constexpr int kSlack = 8;        // +INF cells on both sides of a handed-over row (one block of 8 steps may overhang)
+constexpr int kHandDummy = 72;   // 64 lanes x 8 steps of throw-away writes, overlapping
+constexpr int kHandExtra = 2 * kSlack + kHandDummy;
 constexpr int kThreads = 512;  // 8 wavefronts per pair: wavefront 0 sweeps, all of them halve, compute local costs and back-trace
 
 __device__ __forceinline__ double l2_cost(const double *__restrict__ a, const double *__restrict__ b, int D) {
@@ -160,21 +164,30 @@ __device__ __forceinline__ int clamp_idx(int c, int hi) {  // median(c, -1, hi),
   return r;
 }
 
+// Back-pointer codes are packed two bits per step of the sweep (see the sweep below): the upper bit says "the diagonal
+// beats left", the lower one "the better of the two beats up".  rinfo[row] >> 32 is the row's cell-index base: cell (row, j) lives at
+// bit pair (base + j - lo) of the halfword stream, most significant pair first within a halfword.
+__device__ __forceinline__ unsigned bp_code(const unsigned short *__restrict__ bp16, int cidx) {
+  const unsigned hw = bp16[cidx >> 3];
+  const unsigned pair = (hw >> (14 - 2 * (cidx & 7))) & 3u;
+  return (pair & 1u) ? 1u + (pair >> 1) : 0u;  // 0 up, 1 left, 2 diagonal
+}
+
 // One back-trace walk from cell (bi, bj) up to (excluding) row `top`: follows the back-pointer
-// bytes, WRITE: stores the visited cells at positions wpos-1, wpos-2, ...  Returns the column
+// codes, WRITE: stores the visited cells at positions wpos-1, wpos-2, ...  Returns the column
 // reached in row top-1 (-2 if the walk leaves the window); *ncells = cells visited.
 template <bool WRITE>
-__device__ __forceinline__ int dtw_walk(const unsigned long long *__restrict__ rinfo, const unsigned char *__restrict__ bp,
+__device__ __forceinline__ int dtw_walk(const unsigned long long *__restrict__ rinfo, const unsigned short *__restrict__ bp16,
                                         unsigned short *__restrict__ pth_i, unsigned short *__restrict__ pth_j, int bi,
                                         int bj, int top, int wpos, int *ncells) {
   unsigned long long ri = rinfo[bi];
   unsigned long long rnext = bi > 0 ? rinfo[bi - 1] : 0ull;  // the row above is fetched one row ahead
   int rl = (int)(ri & 0xffffu);
-  const unsigned char *row = bp + (int)(ri >> 32) - rl;      // row[bj] = back-pointer of (bi, bj)
+  int cb = (int)(ri >> 32) - rl;  // cb + bj = cell index of (bi, bj)
   int cnt = 0;
   while (true) {
     ++cnt;
-    const unsigned code = row[bj];
+    const unsigned code = bp_code(bp16, cb + bj);
     if (WRITE) {
       --wpos;
       pth_i[wpos] = (unsigned short)bi;
@@ -190,11 +203,29 @@ __device__ __forceinline__ int dtw_walk(const unsigned long long *__restrict__ r
     ri = rnext;
     rnext = bi > 0 ? rinfo[bi - 1] : 0ull;
     rl = (int)(ri & 0xffffu);
-    row = bp + (int)(ri >> 32) - rl;
+    cb = (int)(ri >> 32) - rl;
     if (bj < rl || bj > (int)((ri >> 16) & 0xffffu)) { bj = -2; break; }
   }
   *ncells = cnt;
   return bj;
+}
+
+// (acc << 1) | (a < b): the compare lands in VCC and is shifted in by an add-with-carry
+__device__ __forceinline__ unsigned shift_in_lt(unsigned acc, double a, double b) {
+  unsigned r;
+  asm("v_cmp_lt_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %3, vcc" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
+  return r;
+}
+// IEEE minNum as one instruction (the sweep's values are never NaN unless the inputs are)
+__device__ __forceinline__ double vmin_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
 }
 
 __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
@@ -208,16 +239,20 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
   // ---- LDS carve (doubles / 64-bit words, ints, shorts) ----
   // local costs of a chunk's window cells, two buffers; every row is framed by one +INF cell on each side
   // (a lane that is outside its window then computes +INF without any select)
-  const int dstride = p.chunkcap + 2 * kRows + 2;
+  const int dstride = p.chunkcap + 4 * kRows + 4;  // every row is framed by TWO +INF cells per side (costs are read in pairs)
   double *dchunk = (double *)smem;
-  double *dprevA = dchunk + 2 * dstride;           // last row of the previous chunk, framed the same way (ping)
-  double *dprevB = dprevA + Ty + 72;               //                                  (pong); + 64 dummy slots each
-  unsigned long long *rinfo = (unsigned long long *)(dprevB + Ty + 72);  // per row: lo | hi << 16 | off << 32
+  // last row of the previous chunk (ping / pong): kSlack cells, the row's window, kSlack cells, then kHandDummy
+  // throw-away slots (lane l writes slots l .. l + 7)
+  double *dprevA = dchunk + 2 * dstride;
+  double *dprevB = dprevA + Ty + kHandExtra;
+  // per row: lo | hi << 16 | B << 32; B = first halfword of the row's back-pointer codes until its chunk is swept,
+  // then the row's cell-index base (see bp_code)
+  unsigned long long *rinfo = (unsigned long long *)(dprevB + Ty + kHandExtra);
   int *off = (int *)(rinfo + Tx);                  // cell offset of each row (prefix sum of widths)
   int *lvl_x = off + (Tx + 1);
   int *lvl_y = lvl_x + kMaxLevels;
   int *bcast = lvl_y + kMaxLevels;  // [8]
-  const int segcap = Tx / kSeg + 3;
+  const int segcap = Tx / kSegMin + 3;
   int *segoff = bcast + 8;          // candidate-table offset of each back-trace segment
   int *segent = segoff + segcap;    // entry column (relative to the bottom row's window) chosen by the stitch
   int *segend = segent + segcap;    // end (exclusive) of the segment's piece in the path arrays
@@ -227,8 +262,10 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
   unsigned short *clast = cfirst + (Tx / 2 + 2);
   unsigned short *pth_i = clast + (Tx / 2 + 2);
   unsigned short *pth_j = pth_i + pcap;
-  unsigned char *bp = (unsigned char *)(pth_j + pcap);  // back-pointer of every window cell, then a dummy row for the feeder
-  const int bp_dummy = p.cellcap;
+  // back-pointer codes: 2 bits per sweep step, a halfword per 8 steps; per row the halfwords its window touches
+  // (<= ((width + 6) >> 3) + 1) and one guard halfword, one more guard in front; then one throw-away halfword per lane
+  unsigned short *bp16 = (unsigned short *)(pth_j + pcap);
+  const int bp_dummy = p.hwcap;
 
   const int tx = p.lenx[n], ty = p.leny[n];
   int32_t *out_i = p.path_i + (size_t)n * pcap;
@@ -325,21 +362,31 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       const int rpl = (ltx + 63) / 64;
       const int b0 = lane * rpl < ltx ? lane * rpl : ltx;
       const int b1 = b0 + rpl < ltx ? b0 + rpl : ltx;
-      int sum = 0;
-      for (int i = b0; i < b1; ++i) sum += (int)hi[i] - (int)lo[i] + 1;
-      int total;
-      int run = wave_excl_scan(sum, lane, &total);
+      int sum = 0, sumhw = 0;
       for (int i = b0; i < b1; ++i) {
+        const int w_ = (int)hi[i] - (int)lo[i] + 1;
+        sum += w_;
+        sumhw += ((w_ + 6) >> 3) + 2;
+      }
+      int total, totalhw;
+      int run = wave_excl_scan(sum, lane, &total);
+      int runhw = 1 + wave_excl_scan(sumhw, lane, &totalhw);  // halfword 0 is the guard in front of row 0
+      for (int i = b0; i < b1; ++i) {
+        const int w_ = (int)hi[i] - (int)lo[i] + 1;
         off[i] = run;
-        rinfo[i] = (unsigned long long)lo[i] | ((unsigned long long)hi[i] << 16) | ((unsigned long long)(unsigned)run << 32);
-        run += (int)hi[i] - (int)lo[i] + 1;
+        rinfo[i] = (unsigned long long)lo[i] | ((unsigned long long)hi[i] << 16) | ((unsigned long long)(unsigned)runhw << 32);
+        run += w_;
+        runhw += ((w_ + 6) >> 3) + 2;
       }
       if (lane == 0) {
         off[ltx] = total;
-        bcast[3] = (total > p.cellcap) ? 1 : 0;
-        dprevA[0] = INFINITY;  // virtual row -1 of the level: D[-1][-1] = 0, nothing else
-        dprevA[1] = 0.0;
-        dprevA[2] = INFINITY;
+        bcast[3] = (total > p.cellcap || 1 + totalhw > p.hwcap) ? 1 : 0;
+        // virtual row -1 of the level: D[-1][-1] = 0, nothing else
+        dprevA[kSlack - 2] = INFINITY;
+        dprevA[kSlack - 1] = INFINITY;
+        dprevA[kSlack] = 0.0;
+        dprevA[kSlack + 1] = INFINITY;
+        dprevA[kSlack + 2] = INFINITY;
       }
     }
     __syncthreads();
@@ -388,14 +435,17 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         const int row = i0 + a;
         const int j = (int)lo[row] + cc - (off[row] - base);
         const double *xr = xk + (size_t)row * D, *yr = yk + (size_t)j * D;
-        dst[cc + 2 * a + 1] = p.dist_kind == MLPG_HIP_DIST_L2             ? l2_cost(xr, yr, D)
+        dst[cc + 4 * a + 2] = p.dist_kind == MLPG_HIP_DIST_L2             ? l2_cost(xr, yr, D)
                               : p.dist_kind == MLPG_HIP_DIST_SCALED_L2_NP ? np_cost<0>(xr, yr, D, p.dist_scale)
                               : p.dist_kind == MLPG_HIP_DIST_SCALED_L1_NP ? np_cost<1>(xr, yr, D, p.dist_scale)
                                                                           : np_cost<2>(xr, yr, D, p.dist_scale);
       }
       for (int a = tid - t0; a < R; a += nthr) {  // the +INF frame of every row
-        dst[off[i0 + a] - base + 2 * a] = INFINITY;
-        dst[off[i0 + a + 1] - base + 2 * a + 1] = INFINITY;
+        const int fl = off[i0 + a] - base + 4 * a, fr = off[i0 + a + 1] - base + 4 * a + 2;
+        dst[fl] = INFINITY;
+        dst[fl + 1] = INFINITY;
+        dst[fr] = INFINITY;
+        dst[fr + 1] = INFINITY;
       }
     };
     chunk_costs(0, dchunk, 0, kThreads);
@@ -415,114 +465,113 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       if (w0) {
       const bool feeder = lane == 0;
       const bool real = lane >= 1 && lane <= R;
+      const bool is_last = lane == R;  // hands its row to the next chunk
       const int i = i0 + lane - 1;
-      int mylo = 0, width = 0, bbase = bp_dummy;
-      const double *src = dprev + 1;  // src[-1] and src[width] are the +INF frame of the row
+      // Everything the sweep touches in LDS is addressed by absolute LDS byte addresses (address_space(3) pointers:
+      // no base add per access) that advance by running offsets.
+      typedef __attribute__((address_space(3))) unsigned char lds_u8;
+      typedef __attribute__((address_space(3))) unsigned short lds_u16;
+      typedef __attribute__((address_space(3))) double lds_f64;
+      const int lbase = (int)(unsigned)(uintptr_t)(lds_u8 *)smem;
+      auto lds_addr = [&](const void *q) { return lbase + (int)((const unsigned char *)q - smem); };
+      // steps s = s0 .. s1 in blocks of 8, padded at the FRONT (all-+INF lead-in): the sweep ends exactly on the last
+      // row's last column.  Two steps of lead-in at least: the feeder emits columns lo-1 and lo first.
+      const int s1 = __builtin_amdgcn_readfirstlane((int)hi[i0 + R - 1]) + R;
+      const int nblocks = (s1 - __builtin_amdgcn_readfirstlane((int)lo[i0]) + 9) >> 3;
+      const int s0 = s1 + 1 - 8 * nblocks;
+      int mylo = 0, width = 0;
+      int src = lds_addr(dprev + kSlack);  // byte address of the local cost of the row's column lo
       if (feeder) {
         mylo = prevlo;
         width = prevhi - prevlo + 1;
       } else if (real) {
         mylo = (int)lo[i];
         width = (int)hi[i] - mylo + 1;
-        src = dcur + (off[i] - base) + 2 * (lane - 1) + 1;
-        bbase = off[i];
+        src = lds_addr(dcur + (off[i] - base) + 4 * (lane - 1) + 2);
       }
-      const bool is_last = lane == R;  // hands its row to the next chunk
-      // two steps of lead-in: the feeder emits columns lo-1 and lo first
-      const int s0 = __builtin_amdgcn_readfirstlane((int)lo[i0]) - 1;
-      const int s1 = __builtin_amdgcn_readfirstlane((int)hi[i0 + R - 1]) + R;
-      // The only loop-carried chain is add -> compare -> select -> DPP; the local cost is fetched TWO
-      // steps ahead so that no step waits on an LDS round trip.
-      // Everything the step touches in LDS is addressed by RUNNING BYTE OFFSETS from the start of the
-      // workgroup's LDS (one add per step each) instead of being re-derived from the column index:
-      //   f_off  cost cell two steps ahead (clamped to the row's +INF frame [f_lo, f_hi])
-      //   b_off  this step's back-pointer byte      d_off  this step's cell in the hand-over row
-      // (absolute LDS addresses, dereferenced through address_space(3) pointers: no base add per access)
-      typedef __attribute__((address_space(3))) unsigned char lds_u8;
-      typedef __attribute__((address_space(3))) double lds_f64;
-      const int lbase = (int)(unsigned)(uintptr_t)(lds_u8 *)smem;
-      int cpos = s0 - lane - mylo;  // column of this step relative to the row's window
-      const int src_off = lbase + (int)((const unsigned char *)src - smem);
-      const int f_lo = src_off - 8, f_hi = src_off + 8 * width;
-      auto fetch_at = [&](int o) {
-        int c;
-        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(o), "v"(f_lo), "v"(f_hi));
-        return *(const lds_f64 *)(uintptr_t)(unsigned)c;
-      };
-      const int dummy_b = lbase + (int)(bp - smem) + bp_dummy + Ty + lane;             // this lane's dummy byte
-      const int dummy_d = lbase + (int)((const unsigned char *)(dnext + Ty + 2 + lane) - smem);  // and dummy hand-over slot
-      int f_off = src_off + 8 * (cpos + 2);
-      int b_off = lbase + (int)(bp - smem) + bbase + cpos;
-      int d_off = lbase + (int)((const unsigned char *)(dnext + 1) - smem) + 8 * cpos;
-      double dt_a = fetch_at(f_off - 16), dt_b = fetch_at(f_off - 8);
-      double pub = INFINITY;     // this lane's D at the column of the previous step (INF outside the window)
-      double up_old = INFINITY;  // row above at the previous column
-      double left = INFINITY;    // this row at the previous column (stays INF until the window starts)
-      // One step.  dt_use: this step's cost slot (refilled with the cost two steps ahead); up_w / up_r: where
-      // "row above at this column" is written / where the previous step left it (the diagonal); st_w / st_r:
-      // the stores this step prepares / the ones the previous step prepared.  The loop body is two steps
-      // with the roles of the slots exchanged, so nothing has to be rotated through registers.
-      struct Stores {
-        int b, d;
-        unsigned code;
-        double best;
-      };
-      auto step = [&](double &dt_use, double &up_w, const double &up_r, Stores &st_w, const Stores &st_r) {
-        const double dt = dt_use;
-        *(lds_u8 *)(uintptr_t)(unsigned)st_r.b = (unsigned char)st_r.code;  // stores of the previous step
-        *(lds_f64 *)(uintptr_t)(unsigned)st_r.d = st_r.best;
-        // row above at this column; the feeder receives +0.0, which makes it replay its stored row:
-        // cu = 0 + dt = dt exactly, and neither left + dt nor the diagonal + dt (>= dt, D >= 0) is smaller
-        const double up = wave_shr1z(pub);
-        up_w = up;
-        const bool inwin = (unsigned)cpos < (unsigned)width;
-        const double cu = __dadd_rn(up, dt), cl = __dadd_rn(left, dt), cd = __dadd_rn(up_r, dt);
-        dt_use = fetch_at(f_off);  // after the last use of dt: the slot's register is refilled in place
-        double best = cu;
-        unsigned code = 0u;
-        if (cl < best) { best = cl; code = 1u; }
-        if (cd < best) { best = cd; code = 2u; }
-        // No branches and a fixed number of LDS operations per step (so that the prefetch above is the
-        // only thing a step ever waits for): stores outside the window go to per-lane dummy slots.
-        // Outside the window dt is the +INF frame, so best is +INF there by itself: no select for the
-        // values the neighbours see.  The stores of a step are issued at the top of the NEXT step, right
-        // after the wait for the prefetched cost, so that the in-order LDS counter never makes a step wait
-        // for its own stores.
-        left = best;
-        pub = best;
-        st_w.b = inwin ? b_off : dummy_b;
-        st_w.code = code;
-        st_w.d = (inwin && is_last) ? d_off : dummy_d;
-        st_w.best = best;
-        ++cpos;
-        f_off += 8;
-        b_off += 1;
-        d_off += 8;
-      };
-      Stores stA = {dummy_b, dummy_d, 0u, 0.0}, stB = stA;
-      double upA = INFINITY, upB = up_old;
-      int nsteps = s1 - s0 + 1;
-      if (nsteps & 1) {  // an odd count gets one more (harmless) lead-in step
-        --cpos;
-        f_off -= 8;
-        b_off -= 1;
-        d_off -= 8;
-        ++nsteps;
-        dt_b = dt_a;
-        dt_a = fetch_at(f_off - 16);
+      const int c0 = s0 - lane - mylo;  // column of step 0 relative to the row's window; <= -2 for the rows of the chunk
+      // back-pointer codes, one halfword per block: block q of this row goes to halfword H + q - (first block that
+      // touches the window); blocks outside the window land in the guards around the row's region (or, for the
+      // feeder and the idle lanes, in the lane's throw-away halfword)
+      int g_lo, g_hi, hw_run;
+      g_lo = g_hi = hw_run = lds_addr(bp16 + bp_dummy + lane);
+      if (real) {
+        const int H = (int)(rinfo[i] >> 32), nb = ((width + 6) >> 3) + 1, k_in = -c0;
+        g_lo = lds_addr(bp16) + 2 * (H - 1);
+        g_hi = lds_addr(bp16) + 2 * (H + nb);
+        hw_run = lds_addr(bp16) + 2 * (H - (k_in >> 3));
+        rinfo[i] = (unsigned long long)(unsigned)mylo | ((unsigned long long)hi[i] << 16) |
+                   ((unsigned long long)(unsigned)(8 * H + (k_in & 7)) << 32);
       }
-      for (int k = 0; k < nsteps; k += 2) {
-        step(dt_a, upA, upB, stA, stB);
-        step(dt_b, upB, upA, stB, stA);
+      // local costs, read in pairs (steps 2m, 2m + 1) one block ahead; the pair address is clamped to the row's
+      // +INF frame: [f_lo, f_hi] = the pairs (lo-2, lo-1) .. (hi+1, hi+2).  Pair q of a block:
+      // med3(f_run + 16 q, f_lo, f_hi) = med3(f_run, f_lo - 16 q, f_hi - 16 q) + 16 q, and the + 16 q rides in the
+      // instruction's offset field.
+      const int f_lo = src - 16, f_hi = (feeder || real) ? src + 8 * width : src - 16;
+      int f_run = src + 8 * c0;
+      auto load_block = [&](double (&d)[8]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int a = med3_i32(f_run, f_lo - 16 * q, f_hi - 16 * q);
+          const lds_f64 *pp = (const lds_f64 *)(uintptr_t)(unsigned)a;
+          d[2 * q] = pp[2 * q];
+          d[2 * q + 1] = pp[2 * q + 1];
+        }
+        f_run += 64;
+      };
+      // the row handed to the next chunk (written by the last lane only): a block whose first column lies in
+      // [-kSlack, width] is written as it is (what overhangs the window is +INF by itself and lands in the slack),
+      // any other block -- and every block of the other lanes -- goes to the lane's throw-away slots
+      const int d_m8 = lds_addr(dnext);  // cell -kSlack
+      const int d_dummy = lds_addr(dnext + Ty + 2 * kSlack + lane);
+      const unsigned wlim = is_last ? (unsigned)(width + kSlack + 1) : 0u;
+      int x_run = c0 + kSlack;
+      double pub = INFINITY;  // this lane's D at the column of the previous step (+INF outside the window)
+      double upp = INFINITY;  // row above at the previous column (the diagonal)
+      unsigned acc = 0u;
+      // One block = 8 steps, 13 vector instructions each: the DPP hand-down (2), three adds, two min, two
+      // compare + shift-in, one hand-over store, and half a cost-pair load.  The loop-carried chain is
+      // DPP -> add -> min (the left / diagonal minimum is formed beside it).  The feeder receives +0.0 from the DPP
+      // (bound_ctrl), which makes it replay its stored row: up + dt = diag + dt = dt exactly and left + dt >= dt (D >= 0).
+      // Codes: bit a = "diagonal < left", then bit b = "min(left, diagonal) < up": up unless b, else diagonal if a,
+      // else left -- the first minimum in the order up, left, diagonal, as the oracle's three compares.
+      auto block = [&](const double (&dt)[8]) {
+        const int dbase = ((unsigned)x_run < wlim) ? d_m8 + 8 * x_run : d_dummy;
+        lds_f64 *dw = (lds_f64 *)(uintptr_t)(unsigned)dbase;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const double up = wave_shr1z(pub);
+          const double cl = __dadd_rn(pub, dt[k]), cd = __dadd_rn(upp, dt[k]);
+          const double x = vmin_f64(cl, cd);  // off the cross-lane chain: both operands are a step old
+          acc = shift_in_lt(acc, cd, cl);
+          const double cu = __dadd_rn(up, dt[k]);
+          const double best = vmin_f64(cu, x);
+          acc = shift_in_lt(acc, x, cu);
+          dw[k] = best;
+          upp = up;
+          pub = best;
+        }
+        *(lds_u16 *)(uintptr_t)(unsigned)med3_i32(hw_run, g_lo, g_hi) = (unsigned short)acc;
+        hw_run += 2;
+        x_run += 8;
+      };
+      double dA[8], dB[8];
+      load_block(dA);
+      for (int b = 0; b < nblocks; b += 2) {
+        load_block(dB);
+        block(dA);
+        if (b + 1 >= nblocks) break;
+        load_block(dA);
+        block(dB);
       }
-      *(lds_u8 *)(uintptr_t)(unsigned)stB.b = (unsigned char)stB.code;
-      *(lds_f64 *)(uintptr_t)(unsigned)stB.d = stB.best;
       if (is_last) {  // +INF frame of the row handed to the next chunk
-        dnext[0] = INFINITY;
-        dnext[width + 1] = INFINITY;
+        dnext[kSlack - 2] = INFINITY;
+        dnext[kSlack - 1] = INFINITY;
+        dnext[kSlack + width] = INFINITY;
+        dnext[kSlack + width + 1] = INFINITY;
       }
       // value of the chunk's last cell (bottom-right corner of the level if this is the last chunk)
-      last_val = __shfl(left, R);
+      last_val = __shfl(pub, R);
       }  // w0
       prevlo = (int)lo[i0 + R - 1];
       prevhi = (int)hi[i0 + R - 1];
@@ -535,6 +584,10 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     level_cost = (prevhi == lty - 1) ? last_val : INFINITY;
 
     // ---- 3. back-trace ----
+    // segment length: the shortest of 4 / 8 / 16 rows that keeps the candidates (about cells / rows-per-segment)
+    // within one round of the workgroup's threads -- the walks are the dependent part, shorter is faster
+    const int ncell_lvl = off[ltx];
+    const int kSeg = ncell_lvl <= kSegMin * kThreads ? kSegMin : (ncell_lvl <= 2 * kSegMin * kThreads ? 2 * kSegMin : kSegMax);
     const int G = (ltx + kSeg - 1) / kSeg;  // segment g = rows [g*kSeg, min((g+1)*kSeg, ltx))
     if (w0) {  // candidate-table offsets: one entry per cell of every segment's bottom row
       const int gpl = (G + 63) / 64;
@@ -574,7 +627,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         }
         const int bot = ((a + 1) * kSeg < ltx ? (a + 1) * kSeg : ltx) - 1;
         int nc;
-        const int ex = dtw_walk<false>(rinfo, bp, pth_i, pth_j, bot, (int)lo[bot] + (task - segoff[a]), a * kSeg, 0, &nc);
+        const int ex = dtw_walk<false>(rinfo, bp16, pth_i, pth_j, bot, (int)lo[bot] + (task - segoff[a]), a * kSeg, 0, &nc);
         cnts[task] = (unsigned short)nc;
         unsigned nx = kInvalid;
         if (a == 0) {
@@ -644,7 +697,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         for (int g = tid; g < G; g += kThreads) {
           const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
           int nc;
-          (void)dtw_walk<true>(rinfo, bp, pth_i, pth_j, bot, (int)lo[bot] + segent[g], g * kSeg, segend[g], &nc);
+          (void)dtw_walk<true>(rinfo, bp16, pth_i, pth_j, bot, (int)lo[bot] + segent[g], g * kSeg, segend[g], &nc);
         }
       }
     } else if (w0) {
@@ -654,12 +707,12 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       int bi = ltx - 1, bj = lty - 1, pos = pcap;
       int ok = uni((level_cost < INFINITY) ? 1 : 0);
       while (ok) {
-        const int rl = uni((int)lo[bi]), rh = uni((int)hi[bi]), ro = uni(off[bi]);
+        const int rl = uni((int)lo[bi]), rh = uni((int)hi[bi]), cb = uni((int)(rinfo[bi] >> 32));
         if (bj < rl || bj > rh) { ok = 0; break; }
         bool up = false;
         while (!up) {  // cells of this row on the path
           if (pos == 0 || bj < rl) { ok = 0; break; }
-          const int code = uni((int)bp[ro + bj - rl]);
+          const int code = uni((int)bp_code(bp16, cb + bj - rl));
           --pos;
           if (lane == 0) {
             pth_i[pos] = (unsigned short)bi;
@@ -713,11 +766,11 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
 
 size_t lds_bytes(int Tx, int Ty, int D, const DtwParams &p) {
   size_t b = 0;
-  b += sizeof(double) * (2 * ((size_t)p.chunkcap + 2 * kRows + 2) + 2 * (size_t)(Ty + 72));
+  b += sizeof(double) * (2 * ((size_t)p.chunkcap + 4 * kRows + 4) + 2 * (size_t)(Ty + kHandExtra));
   b += sizeof(unsigned long long) * (size_t)Tx;
-  b += sizeof(int) * ((size_t)(Tx + 1) + 2 * kMaxLevels + 8 + 3 * (size_t)(Tx / kSeg + 3));
+  b += sizeof(int) * ((size_t)(Tx + 1) + 2 * kMaxLevels + 8 + 3 * (size_t)(Tx / kSegMin + 3));
   b += sizeof(unsigned short) * ((size_t)2 * Tx + 2 * (Tx / 2 + 2) + 2 * (size_t)(Tx + Ty));
-  b += (size_t)p.cellcap + (size_t)Ty + 64 + 16;  // back-pointer bytes + the feeder's dummy row + per-lane dummy bytes
+  b += sizeof(unsigned short) * ((size_t)p.hwcap + 64) + 16;  // back-pointer halfwords + one throw-away halfword per lane
   return (b + 15) & ~(size_t)15;
 }
 
@@ -752,6 +805,8 @@ int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, 
   if (full < cc) cc = full + 64;
   p.cellcap = (int)cc;
   p.chunkcap = Ty > 1024 ? Ty : 1024;
+  // back-pointer halfwords: per row ((width + 6) >> 3) + 2 <= width / 8 + 2.75, one guard in front
+  p.hwcap = (int)(cc / 8 + 3 * (long)Tx + 2);
   const size_t lds = lds_bytes(Tx, Ty, D, p);
   if (lds > 160 * 1024) {
     set_error("fastdtw: Tx=%d, Ty=%d, D=%d, radius=%d needs %zu bytes of LDS (> 160 KiB)", Tx, Ty, D, radius, lds);
