@@ -39,6 +39,7 @@
 // with separate multiply/add in ascending k; D = min(up+dt, left+dt, diag+dt)
 // compared after the add, first minimum wins (up, left, diagonal).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -62,11 +63,15 @@ struct DtwParams {
   int N, Tx, Ty, D, radius;
   int32_t *path_i, *path_j, *path_len;
   double *cost;
+  int *cu_tickets;    // 2048 counters, one per CU (any initial value): see "which wavefront sweeps"
   double *pyr;        // N * pyr_stride doubles: x levels >= 1, then y levels >= 1
   size_t pyr_stride;  // (Tx + Ty) * D
-  int cellcap;        // window cells per level (bound)
-  int hwcap;          // back-pointer halfwords per level (bound)
-  int chunkcap;       // cost cells per DP chunk
+  int cellcap;        // window cells per level
+  int hwcap;          // back-pointer halfwords per level
+  int chunkcap;       // doubles per cost buffer without the rows' frames: handed-over row + its slack + the chunk's cells
+  int pcap_lds;       // path entries kept in LDS (levels >= 1)
+  int tier;           // 0: one launch, capacities are bounds.  1: optimistic capacities, a pair that exceeds one is
+                      // marked path_len = -1.  2: bounds again, only the marked pairs
   int dist_kind;      // MLPG_HIP_DIST_*
   double dist_scale;  // factor of MLPG_HIP_DIST_SCALED_L2_NP
 };
@@ -76,8 +81,8 @@ constexpr int kRows = 63;  // rows per chunk: lanes 1..63 of the sweeping wavefr
 constexpr int kSegMin = 4, kSegMax = 16;  // rows per back-trace segment: chosen per level (see the back-trace)
 constexpr int kSlack = 8;        // +INF cells on both sides of a handed-over row (one block of 8 steps may overhang)
 constexpr int kHandDummy = 72;   // 64 lanes x 8 steps of throw-away writes, overlapping
-constexpr int kHandExtra = 2 * kSlack + kHandDummy;
-constexpr int kThreads = 512;  // 8 wavefronts per pair: wavefront 0 sweeps, all of them halve, compute local costs and back-trace
+// threads per pair: wavefront 0 sweeps, all of them halve, compute local costs and back-trace.  512 for few pairs
+// (latency), 256 for many (four pairs resident per CU: launch_fastdtw)
 
 __device__ __forceinline__ double l2_cost(const double *__restrict__ a, const double *__restrict__ b, int D) {
   // The sum runs in ascending k with separate multiply and add (bit-compatible with the oracle); the
@@ -176,9 +181,9 @@ __device__ __forceinline__ unsigned bp_code(const unsigned short *__restrict__ b
 // One back-trace walk from cell (bi, bj) up to (excluding) row `top`: follows the back-pointer
 // codes, WRITE: stores the visited cells at positions wpos-1, wpos-2, ...  Returns the column
 // reached in row top-1 (-2 if the walk leaves the window); *ncells = cells visited.
-template <bool WRITE>
+template <bool WRITE, typename PT>
 __device__ __forceinline__ int dtw_walk(const unsigned long long *__restrict__ rinfo, const unsigned short *__restrict__ bp16,
-                                        unsigned short *__restrict__ pth_i, unsigned short *__restrict__ pth_j, int bi,
+                                        PT *__restrict__ pth_i, PT *__restrict__ pth_j, int bi,
                                         int bj, int top, int wpos, int *ncells) {
   unsigned long long ri = rinfo[bi];
   unsigned long long rnext = bi > 0 ? rinfo[bi - 1] : 0ull;  // the row above is fetched one row ahead
@@ -190,8 +195,8 @@ __device__ __forceinline__ int dtw_walk(const unsigned long long *__restrict__ r
     const unsigned code = bp_code(bp16, cb + bj);
     if (WRITE) {
       --wpos;
-      pth_i[wpos] = (unsigned short)bi;
-      pth_j[wpos] = (unsigned short)bj;
+      pth_i[wpos] = (PT)bi;
+      pth_j[wpos] = (PT)bj;
     }
     if (code != 0u) bj -= 1;  // left or diagonal
     if (code == 1u) {         // left: stay in the row
@@ -228,55 +233,56 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c) {
   return r;
 }
 
+template <int kThreads>
 __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const bool w0 = tid < 64;  // the sweeping wavefront
+  const int lane = threadIdx.x & 63;
   const int n = blockIdx.x;
   const int Tx = p.Tx, Ty = p.Ty, D = p.D, r = p.radius;
-  const int pcap = Tx + Ty;
+  const int pcap = Tx + Ty, pcapL = p.pcap_lds;
 
-  // ---- LDS carve (doubles / 64-bit words, ints, shorts) ----
-  // local costs of a chunk's window cells, two buffers; every row is framed by one +INF cell on each side
-  // (a lane that is outside its window then computes +INF without any select)
-  const int dstride = p.chunkcap + 4 * kRows + 4;  // every row is framed by TWO +INF cells per side (costs are read in pairs)
-  double *dchunk = (double *)smem;
-  // last row of the previous chunk (ping / pong): kSlack cells, the row's window, kSlack cells, then kHandDummy
-  // throw-away slots (lane l writes slots l .. l + 7)
-  double *dprevA = dchunk + 2 * dstride;
-  double *dprevB = dprevA + Ty + kHandExtra;
-  // per row: lo | hi << 16 | B << 32; B = first halfword of the row's back-pointer codes until its chunk is swept,
-  // then the row's cell-index base (see bp_code)
-  unsigned long long *rinfo = (unsigned long long *)(dprevB + Ty + kHandExtra);
-  int *off = (int *)(rinfo + Tx);                  // cell offset of each row (prefix sum of widths)
-  int *lvl_x = off + (Tx + 1);
-  int *lvl_y = lvl_x + kMaxLevels;
-  int *bcast = lvl_y + kMaxLevels;  // [8]
-  const int segcap = Tx / kSegMin + 3;
-  int *segoff = bcast + 8;          // candidate-table offset of each back-trace segment
-  int *segent = segoff + segcap;    // entry column (relative to the bottom row's window) chosen by the stitch
-  int *segend = segent + segcap;    // end (exclusive) of the segment's piece in the path arrays
-  unsigned short *lo = (unsigned short *)(segend + segcap);
-  unsigned short *hi = lo + Tx;
-  unsigned short *cfirst = hi + Tx;
-  unsigned short *clast = cfirst + (Tx / 2 + 2);
-  unsigned short *pth_i = clast + (Tx / 2 + 2);
-  unsigned short *pth_j = pth_i + pcap;
-  // back-pointer codes: 2 bits per sweep step, a halfword per 8 steps; per row the halfwords its window touches
-  // (<= ((width + 6) >> 3) + 1) and one guard halfword, one more guard in front; then one throw-away halfword per lane
-  unsigned short *bp16 = (unsigned short *)(pth_j + pcap);
-  const int bp_dummy = p.hwcap;
-
+  if (p.tier == 2 && p.path_len[n] != -1) return;  // retry launch: only the pairs the optimistic launch gave up on
   const int tx = p.lenx[n], ty = p.leny[n];
   int32_t *out_i = p.path_i + (size_t)n * pcap;
   int32_t *out_j = p.path_j + (size_t)n * pcap;
   if (tx < 1 || ty < 1 || tx > Tx || ty > Ty) {
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
       p.path_len[n] = 0;
       p.cost[n] = NAN;
     }
     return;
   }
+
+  // ---- LDS carve (doubles / 64-bit words, ints, shorts) ----
+  // Two cost buffers.  Buffer of chunk c: the row handed over by chunk c-1 (kSlack cells, its window, kSlack
+  // cells), then the local costs of the chunk's window cells, every row framed by two +INF cells per side (costs are
+  // read in pairs; a lane outside its window computes +INF without any select).
+  const int dstride = p.chunkcap + 4 * kRows + 4;
+  double *dchunk = (double *)smem;
+  double *ddummy = dchunk + 2 * dstride;  // throw-away slots of the hand-over stores (lane l writes slots l .. l + 7)
+  // per row: lo | hi << 16 | B << 32; B = offset of the row's first window cell (prefix sum of the widths) until the
+  // row's chunk is swept, then the row's cell-index base in the back-pointer codes (see bp_code); entry ltx: the total
+  unsigned long long *rinfo = (unsigned long long *)(ddummy + kHandDummy);
+  unsigned *rw = (unsigned *)rinfo;
+  auto LO = [&](int i) { return (int)(rw[2 * i] & 0xffffu); };
+  auto HI = [&](int i) { return (int)(rw[2 * i] >> 16); };
+  auto OFF = [&](int i) { return (int)rw[2 * i + 1]; };
+  int *lvl_x = (int *)(rinfo + Tx + 1);
+  int *lvl_y = lvl_x + kMaxLevels;
+  int *bcast = lvl_y + kMaxLevels;  // [16]
+  const int segcap = Tx / kSegMin + 3;
+  int *segoff = bcast + 16;          // candidate-table offset of each back-trace segment
+  int *segent = segoff + segcap;    // entry column (relative to the bottom row's window) chosen by the stitch
+  int *segend = segent + segcap;    // end (exclusive) of the segment's piece in the path arrays
+  unsigned short *cfirst = (unsigned short *)(segend + segcap);
+  unsigned short *clast = cfirst + (Tx / 2 + 2);
+  unsigned short *pth_i = clast + (Tx / 2 + 2);  // the path of a level >= 1 (level 0 goes straight to the output)
+  unsigned short *pth_j = pth_i + pcapL;
+  // back-pointer codes: 2 bits per sweep step, a halfword per 8 steps; per row the halfwords its window touches
+  // (<= ((width + 6) >> 3) + 1; handed out chunk by chunk by the sweep), then one throw-away halfword per lane
+  unsigned short *bp16 = (unsigned short *)(pth_j + pcapL);
+  const int bp_dummy = p.hwcap;
+
   const double *x0 = p.X + (size_t)n * Tx * D;
   const double *y0 = p.Y + (size_t)n * Ty * D;
   double *px = p.pyr + (size_t)n * p.pyr_stride;
@@ -289,6 +295,27 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
   // number of halvings: level K is the first with a side < radius + 2 (full DTW there)
   int K = 0;
   while (K < kMaxLevels - 1 && (tx >> K) >= r + 2 && (ty >> K) >= r + 2) ++K;
+
+  // ---- 0. which wavefront sweeps ----
+  // The sweep is one wavefront issuing dependent instructions for most of the kernel; with several pairs resident on
+  // a CU the sweepers must not pile up on one SIMD (wavefront w of every workgroup tends to land on the same one).
+  // Every workgroup draws a ticket from a counter of its CU and lets the wavefront that runs on SIMD ticket % 4 sweep;
+  // that wavefront becomes "wavefront 0" of everything below (thread ids are renumbered).
+  {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  // hwreg(HW_REG_HW_ID): simd [5:4], cu/sh/se [15:8]
+    if (lane == 0) bcast[8 + (threadIdx.x >> 6)] = (int)((hwid >> 4) & 3u);
+    if (threadIdx.x == 0) {
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;  // hwreg(HW_REG_XCC_ID, 0, 4)
+      bcast[6] = p.cu_tickets ? (atomicAdd(&p.cu_tickets[(xcc << 8) | ((hwid >> 8) & 0xffu)], 1) & 3) : 0;
+    }
+  }
+  __syncthreads();
+  int sweeper = 0;
+  for (int w = kThreads / 64 - 1; w >= 0; --w)
+    if (bcast[8 + w] == bcast[6]) sweeper = w;
+  const int hw_wave = threadIdx.x >> 6;
+  const int tid = (hw_wave == sweeper ? 0 : (hw_wave == 0 ? sweeper : hw_wave)) * 64 + lane;
+  const bool w0 = tid < 64;  // the sweeping wavefront
 
   // ---- 1. pyramid (levels 1..K) ----
   if (tid == 0) {
@@ -322,7 +349,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
   }
 
   DTW_TICK(0);
-  int pstart = pcap, pn = 0;  // current path = pth[pstart .. pstart+pn)
+  int pstart = pcapL, pn = 0;  // current path = pth[pstart .. pstart+pn)
   double level_cost = INFINITY;
   bool fail = false;
 
@@ -333,10 +360,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
 
     // ---- 2a. per-row windows ----
     if (k == K) {
-      for (int i = tid; i < ltx; i += kThreads) {
-        lo[i] = 0;
-        hi[i] = (unsigned short)(lty - 1);
-      }
+      for (int i = tid; i < ltx; i += kThreads) rw[2 * i] = (unsigned)(lty - 1) << 16;
     } else {
       const int cx = tx >> (k + 1);
       for (int q = tid; q < pn; q += kThreads) {
@@ -351,59 +375,55 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         const int r1 = ci + r > cx - 1 ? cx - 1 : ci + r;
         const int a = 2 * ((int)cfirst[r0] - r);
         const int b = 2 * ((int)clast[r1] + r) + 1;
-        lo[i] = (unsigned short)(a < 0 ? 0 : a);
-        hi[i] = (unsigned short)(b > lty - 1 ? lty - 1 : b);
+        rw[2 * i] = (unsigned)(a < 0 ? 0 : a) | ((unsigned)(b > lty - 1 ? lty - 1 : b) << 16);
       }
     }
     __syncthreads();
 
-    // ---- 2b. row offsets: cells (off); wavefront 0 ----
+    // ---- 2b. row offsets (prefix sum of the widths) and the level's capacity checks; wavefront 0 ----
     if (w0) {
       const int rpl = (ltx + 63) / 64;
       const int b0 = lane * rpl < ltx ? lane * rpl : ltx;
       const int b1 = b0 + rpl < ltx ? b0 + rpl : ltx;
-      int sum = 0, sumhw = 0;
-      for (int i = b0; i < b1; ++i) {
-        const int w_ = (int)hi[i] - (int)lo[i] + 1;
-        sum += w_;
-        sumhw += ((w_ + 6) >> 3) + 2;
-      }
-      int total, totalhw;
+      int sum = 0;
+      for (int i = b0; i < b1; ++i) sum += HI(i) - LO(i) + 1;
+      int total;
       int run = wave_excl_scan(sum, lane, &total);
-      int runhw = 1 + wave_excl_scan(sumhw, lane, &totalhw);  // halfword 0 is the guard in front of row 0
       for (int i = b0; i < b1; ++i) {
-        const int w_ = (int)hi[i] - (int)lo[i] + 1;
-        off[i] = run;
-        rinfo[i] = (unsigned long long)lo[i] | ((unsigned long long)hi[i] << 16) | ((unsigned long long)(unsigned)runhw << 32);
-        run += w_;
-        runhw += ((w_ + 6) >> 3) + 2;
+        rw[2 * i + 1] = (unsigned)run;
+        run += HI(i) - LO(i) + 1;
       }
       if (lane == 0) {
-        off[ltx] = total;
-        bcast[3] = (total > p.cellcap || 1 + totalhw > p.hwcap) ? 1 : 0;
-        // virtual row -1 of the level: D[-1][-1] = 0, nothing else
-        dprevA[kSlack - 2] = INFINITY;
-        dprevA[kSlack - 1] = INFINITY;
-        dprevA[kSlack] = 0.0;
-        dprevA[kSlack + 1] = INFINITY;
-        dprevA[kSlack + 2] = INFINITY;
+        rw[2 * ltx] = 0u;
+        rw[2 * ltx + 1] = (unsigned)total;
+        bcast[3] = total > p.cellcap ? 1 : 0;
+        // virtual row -1 of the level: D[-1][-1] = 0, nothing else -- the row "handed over" to chunk 0
+        dchunk[kSlack - 2] = INFINITY;
+        dchunk[kSlack - 1] = INFINITY;
+        dchunk[kSlack] = 0.0;
+        dchunk[kSlack + 1] = INFINITY;
+        dchunk[kSlack + 2] = INFINITY;
       }
     }
     __syncthreads();
     if (bcast[3]) fail = true;
     if (fail) break;
+    const int ncell_lvl = OFF(ltx);
 
     DTW_TICK(1);
-    // ---- 2c. chunk table (wavefront 0): chunk c = rows [cstart[c], cstart[c+1]), at most 63 rows and
-    // chunkcap cells; the table lives where the coarse-path scratch was (free until the next level) ----
+    // ---- 2c. chunk table (wavefront 0): chunk c = rows [cstart[c], cstart[c+1]), at most 63 rows; its cells and
+    // the row handed over by the chunk before must fit a cost buffer.  The table lives where the coarse-path scratch
+    // was (free until the next level) ----
     unsigned short *cstart = cfirst;
+    // cells in front of a chunk's rows in its cost buffer: the handed-over row (the virtual row -1 has one cell)
+    auto feed_cells = [&](int i0) { return (i0 > 0 ? HI(i0 - 1) - LO(i0 - 1) + 1 : 1) + 2 * kSlack; };
     if (w0) {
       int i0 = 0, nc = 0, bad = 0;
       while (i0 < ltx) {
-        const int base = off[i0];
+        const int base = OFF(i0), room = p.chunkcap - feed_cells(i0);
         // short first chunks: the pipeline (costs of chunk c+1 behind the sweep of chunk c) starts sooner
         const int rowcap = nc == 0 ? 8 : (nc == 1 ? 24 : kRows);
-        const bool fits = (lane < rowcap) && (i0 + lane < ltx) && (off[i0 + lane + 1] - base <= p.chunkcap);
+        const bool fits = (lane < rowcap) && (i0 + lane < ltx) && (OFF(i0 + lane + 1) - base <= room);
         const unsigned long long m = __ballot(fits);
         const int R = __ffsll((long long)~m) - 1;  // bit 63 is never set: R <= 63
         if (R < 1) { bad = 1; break; }
@@ -422,18 +442,19 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     if (fail) break;
     const int nchunk = bcast[2];
 
-    // local costs of every window cell of chunk c into dst, by threads [t0, t0 + nthr)
-    auto chunk_costs = [&](int c, double *dst, int t0, int nthr) {
-      const int i0 = (int)cstart[c], R = (int)cstart[c + 1] - i0, base = off[i0];
-      const int ncell = off[i0 + R] - base;
+    // local costs of every window cell of chunk c into its buffer, by threads [t0, t0 + nthr)
+    auto chunk_costs = [&](int c, double *buf, int t0, int nthr) {
+      const int i0 = (int)cstart[c], R = (int)cstart[c + 1] - i0, base = OFF(i0);
+      const int ncell = OFF(i0 + R) - base;
+      double *dst = buf + feed_cells(i0);
       for (int cc = tid - t0; cc < ncell; cc += nthr) {
         int a = 0, b = R;
         while (b - a > 1) {
           const int mid = (a + b) >> 1;
-          if (off[i0 + mid] - base <= cc) a = mid; else b = mid;
+          if (OFF(i0 + mid) - base <= cc) a = mid; else b = mid;
         }
         const int row = i0 + a;
-        const int j = (int)lo[row] + cc - (off[row] - base);
+        const int j = LO(row) + cc - (OFF(row) - base);
         const double *xr = xk + (size_t)row * D, *yr = yk + (size_t)j * D;
         dst[cc + 4 * a + 2] = p.dist_kind == MLPG_HIP_DIST_L2             ? l2_cost(xr, yr, D)
                               : p.dist_kind == MLPG_HIP_DIST_SCALED_L2_NP ? np_cost<0>(xr, yr, D, p.dist_scale)
@@ -441,7 +462,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
                                                                           : np_cost<2>(xr, yr, D, p.dist_scale);
       }
       for (int a = tid - t0; a < R; a += nthr) {  // the +INF frame of every row
-        const int fl = off[i0 + a] - base + 4 * a, fr = off[i0 + a + 1] - base + 4 * a + 2;
+        const int fl = OFF(i0 + a) - base + 4 * a, fr = OFF(i0 + a + 1) - base + 4 * a + 2;
         dst[fl] = INFINITY;
         dst[fl + 1] = INFINITY;
         dst[fr] = INFINITY;
@@ -454,12 +475,14 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
 
     // ---- 2d. DP: wavefront 0 sweeps chunk c while the other wavefronts prepare the costs of chunk c+1 ----
     int prevlo = -1, prevhi = -1;  // the virtual row -1 has the single cell (-1, -1)
-    double *dprev = dprevA, *dnext = dprevB;
+    int hw_next = 0;               // next free back-pointer halfword
     double last_val = INFINITY;
     for (int c = 0; c < nchunk; ++c) {
-      const int i0 = (int)cstart[c], R = (int)cstart[c + 1] - i0, base = off[i0];
-      const double *dcur = dchunk + (c & 1) * dstride;
-      if (!w0 && c + 1 < nchunk) chunk_costs(c + 1, dchunk + ((c + 1) & 1) * dstride, 64, kThreads - 64);
+      const int i0 = (int)cstart[c], R = (int)cstart[c + 1] - i0, base = OFF(i0);
+      double *dcur = dchunk + (c & 1) * dstride;
+      double *dnxt = dchunk + ((c + 1) & 1) * dstride;  // its head receives the row handed to chunk c+1
+      const int last_lo = LO(i0 + R - 1), last_hi = HI(i0 + R - 1);
+      if (!w0 && c + 1 < nchunk) chunk_costs(c + 1, dnxt, 64, kThreads - 64);
       // anti-diagonal sweep (wavefront 0): lane r >= 1 owns row i0 + r - 1, lane 0 feeds the row above;
       // at step s every lane handles column s - lane of its row
       if (w0) {
@@ -476,33 +499,36 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       auto lds_addr = [&](const void *q) { return lbase + (int)((const unsigned char *)q - smem); };
       // steps s = s0 .. s1 in blocks of 8, padded at the FRONT (all-+INF lead-in): the sweep ends exactly on the last
       // row's last column.  Two steps of lead-in at least: the feeder emits columns lo-1 and lo first.
-      const int s1 = __builtin_amdgcn_readfirstlane((int)hi[i0 + R - 1]) + R;
-      const int nblocks = (s1 - __builtin_amdgcn_readfirstlane((int)lo[i0]) + 9) >> 3;
+      const int s1 = last_hi + R;
+      const int nblocks = (s1 - __builtin_amdgcn_readfirstlane(LO(i0)) + 9) >> 3;
       const int s0 = s1 + 1 - 8 * nblocks;
       int mylo = 0, width = 0;
-      int src = lds_addr(dprev + kSlack);  // byte address of the local cost of the row's column lo
+      int src = lds_addr(dcur + kSlack);  // byte address of the local cost of the row's column lo
       if (feeder) {
         mylo = prevlo;
         width = prevhi - prevlo + 1;
       } else if (real) {
-        mylo = (int)lo[i];
-        width = (int)hi[i] - mylo + 1;
-        src = lds_addr(dcur + (off[i] - base) + 4 * (lane - 1) + 2);
+        const unsigned lh = rw[2 * i];
+        mylo = (int)(lh & 0xffffu);
+        width = (int)(lh >> 16) - mylo + 1;
+        src = lds_addr(dcur + feed_cells(i0) + (OFF(i) - base) + 4 * (lane - 1) + 2);
       }
       const int c0 = s0 - lane - mylo;  // column of step 0 relative to the row's window; <= -2 for the rows of the chunk
-      // back-pointer codes, one halfword per block: block q of this row goes to halfword H + q - (first block that
-      // touches the window); blocks outside the window land in the guards around the row's region (or, for the
-      // feeder and the idle lanes, in the lane's throw-away halfword)
-      int g_lo, g_hi, hw_run;
-      g_lo = g_hi = hw_run = lds_addr(bp16 + bp_dummy + lane);
-      if (real) {
-        const int H = (int)(rinfo[i] >> 32), nb = ((width + 6) >> 3) + 1, k_in = -c0;
-        g_lo = lds_addr(bp16) + 2 * (H - 1);
-        g_hi = lds_addr(bp16) + 2 * (H + nb);
-        hw_run = lds_addr(bp16) + 2 * (H - (k_in >> 3));
-        rinfo[i] = (unsigned long long)(unsigned)mylo | ((unsigned long long)hi[i] << 16) |
-                   ((unsigned long long)(unsigned)(8 * H + (k_in & 7)) << 32);
-      }
+      // back-pointer codes, one halfword per block: the blocks that touch the row's window (steps k_in .. k_in +
+      // width - 1) get consecutive halfwords from H on, every other block -- and all blocks of the feeder and the idle
+      // lanes -- goes to the lane's throw-away halfword
+      const int k_in = -c0;
+      const int nhw = real ? ((k_in + width - 1) >> 3) - (k_in >> 3) + 1 : 0;
+      int hw_total;
+      const int H = hw_next + wave_excl_scan(nhw, lane, &hw_total);
+      hw_next += hw_total;
+      if (hw_next > p.hwcap) {  // uniform: the level does not fit (optimistic capacities); nothing is written
+        if (lane == 0) bcast[3] = 1;
+      } else {
+      const int hw_dummy = lds_addr(bp16 + bp_dummy + lane);
+      int hw_run = lds_addr(bp16) + 2 * H;  // halfword of block q_rel = 0
+      int q_rel = real ? -(k_in >> 3) : 0;  // block index relative to the first block that touches the window
+      if (real) rw[2 * i + 1] = (unsigned)(8 * H + (k_in & 7));  // from here on: the row's cell-index base
       // local costs, read in pairs (steps 2m, 2m + 1) one block ahead; the pair address is clamped to the row's
       // +INF frame: [f_lo, f_hi] = the pairs (lo-2, lo-1) .. (hi+1, hi+2).  Pair q of a block:
       // med3(f_run + 16 q, f_lo, f_hi) = med3(f_run, f_lo - 16 q, f_hi - 16 q) + 16 q, and the + 16 q rides in the
@@ -522,8 +548,8 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       // the row handed to the next chunk (written by the last lane only): a block whose first column lies in
       // [-kSlack, width] is written as it is (what overhangs the window is +INF by itself and lands in the slack),
       // any other block -- and every block of the other lanes -- goes to the lane's throw-away slots
-      const int d_m8 = lds_addr(dnext);  // cell -kSlack
-      const int d_dummy = lds_addr(dnext + Ty + 2 * kSlack + lane);
+      const int d_m8 = lds_addr(dnxt);  // cell -kSlack
+      const int d_dummy = lds_addr(ddummy + lane);
       const unsigned wlim = is_last ? (unsigned)(width + kSlack + 1) : 0u;
       int x_run = c0 + kSlack;
       double pub = INFINITY;  // this lane's D at the column of the previous step (+INF outside the window)
@@ -539,20 +565,20 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         const int dbase = ((unsigned)x_run < wlim) ? d_m8 + 8 * x_run : d_dummy;
         lds_f64 *dw = (lds_f64 *)(uintptr_t)(unsigned)dbase;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k8 = 0; k8 < 8; ++k8) {
           const double up = wave_shr1z(pub);
-          const double cl = __dadd_rn(pub, dt[k]), cd = __dadd_rn(upp, dt[k]);
+          const double cl = __dadd_rn(pub, dt[k8]), cd = __dadd_rn(upp, dt[k8]);
           const double x = vmin_f64(cl, cd);  // off the cross-lane chain: both operands are a step old
           acc = shift_in_lt(acc, cd, cl);
-          const double cu = __dadd_rn(up, dt[k]);
+          const double cu = __dadd_rn(up, dt[k8]);
           const double best = vmin_f64(cu, x);
           acc = shift_in_lt(acc, x, cu);
-          dw[k] = best;
+          dw[k8] = best;
           upp = up;
           pub = best;
         }
-        *(lds_u16 *)(uintptr_t)(unsigned)med3_i32(hw_run, g_lo, g_hi) = (unsigned short)acc;
-        hw_run += 2;
+        *(lds_u16 *)(uintptr_t)(unsigned)((unsigned)q_rel < (unsigned)nhw ? hw_run + 2 * q_rel : hw_dummy) = (unsigned short)acc;
+        q_rel += 1;
         x_run += 8;
       };
       double dA[8], dB[8];
@@ -565,30 +591,33 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         block(dB);
       }
       if (is_last) {  // +INF frame of the row handed to the next chunk
-        dnext[kSlack - 2] = INFINITY;
-        dnext[kSlack - 1] = INFINITY;
-        dnext[kSlack + width] = INFINITY;
-        dnext[kSlack + width + 1] = INFINITY;
+        dnxt[kSlack - 2] = INFINITY;
+        dnxt[kSlack - 1] = INFINITY;
+        dnxt[kSlack + width] = INFINITY;
+        dnxt[kSlack + width + 1] = INFINITY;
       }
       // value of the chunk's last cell (bottom-right corner of the level if this is the last chunk)
       last_val = __shfl(pub, R);
+      }  // fits
       }  // w0
-      prevlo = (int)lo[i0 + R - 1];
-      prevhi = (int)hi[i0 + R - 1];
-      double *tsw = dprev;
-      dprev = dnext;
-      dnext = tsw;
-      __syncthreads();
+      prevlo = last_lo;
+      prevhi = last_hi;
       DTW_TICK(4);
+      __syncthreads();
+      DTW_TICK(2);  // the sweeper waiting for the next chunk's costs
+      if (bcast[3]) break;
     }
+    if (bcast[3]) fail = true;
+    if (fail) break;
     level_cost = (prevhi == lty - 1) ? last_val : INFINITY;
 
     // ---- 3. back-trace ----
     // segment length: the shortest of 4 / 8 / 16 rows that keeps the candidates (about cells / rows-per-segment)
     // within one round of the workgroup's threads -- the walks are the dependent part, shorter is faster
-    const int ncell_lvl = off[ltx];
     const int kSeg = ncell_lvl <= kSegMin * kThreads ? kSegMin : (ncell_lvl <= 2 * kSegMin * kThreads ? 2 * kSegMin : kSegMax);
     const int G = (ltx + kSeg - 1) / kSeg;  // segment g = rows [g*kSeg, min((g+1)*kSeg, ltx))
+    // level 0 writes the path straight to the output arrays (from position 0), the other levels into LDS (right-aligned)
+    const int wcap = k == 0 ? pcap : pcapL;
     if (w0) {  // candidate-table offsets: one entry per cell of every segment's bottom row
       const int gpl = (G + 63) / 64;
       const int g0 = lane * gpl < G ? lane * gpl : G;
@@ -596,14 +625,14 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       int sum = 0;
       for (int g = g0; g < g1; ++g) {
         const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
-        sum += (int)hi[bot] - (int)lo[bot] + 1;
+        sum += HI(bot) - LO(bot) + 1;
       }
       int total;
       int run = wave_excl_scan(sum, lane, &total);
       for (int g = g0; g < g1; ++g) {
         const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
         segoff[g] = run;
-        run += (int)hi[bot] - (int)lo[bot] + 1;
+        run += HI(bot) - LO(bot) + 1;
       }
       if (lane == 0) segoff[G] = total;
     }
@@ -616,7 +645,7 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
     unsigned short *cnts = (unsigned short *)dchunk;
     unsigned short *hop = cnts + ntask;
     constexpr unsigned kInvalid = 0xffffu, kTerminal = 0xfffeu;
-    if ((size_t)ntask * (size_t)(nlev + 1) * sizeof(unsigned short) <= sizeof(double) * 2 * (size_t)p.chunkcap &&
+    if ((size_t)ntask * (size_t)(nlev + 1) * sizeof(unsigned short) <= sizeof(double) * 2 * (size_t)dstride &&
         ntask < 0xfff0 && G < segcap) {
       // pass 1: every (segment, entry column) candidate walks to the top of its segment
       for (int task = tid; task < ntask; task += kThreads) {
@@ -627,23 +656,23 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         }
         const int bot = ((a + 1) * kSeg < ltx ? (a + 1) * kSeg : ltx) - 1;
         int nc;
-        const int ex = dtw_walk<false>(rinfo, bp16, pth_i, pth_j, bot, (int)lo[bot] + (task - segoff[a]), a * kSeg, 0, &nc);
+        const int ex = dtw_walk<false>(rinfo, bp16, pth_i, pth_j, bot, LO(bot) + (task - segoff[a]), a * kSeg, 0, &nc);
         cnts[task] = (unsigned short)nc;
         unsigned nx = kInvalid;
         if (a == 0) {
           if (ex == -1) nx = kTerminal;
         } else if (ex >= 0) {
           const int up = a * kSeg - 1;  // bottom row of the segment above
-          if (ex >= (int)lo[up] && ex <= (int)hi[up]) nx = (unsigned)(segoff[a - 1] + ex - (int)lo[up]);
+          if (ex >= LO(up) && ex <= HI(up)) nx = (unsigned)(segoff[a - 1] + ex - LO(up));
         }
         hop[task] = (unsigned short)nx;
       }
       if (tid == 0) bcast[1] = 1;
       __syncthreads();
       // hop tables by doubling
-      for (int k = 1; k < nlev; ++k) {
-        const unsigned short *hp = hop + (size_t)(k - 1) * ntask;
-        unsigned short *hn = hop + (size_t)k * ntask;
+      for (int q = 1; q < nlev; ++q) {
+        const unsigned short *hp = hop + (size_t)(q - 1) * ntask;
+        unsigned short *hn = hop + (size_t)q * ntask;
         for (int task = tid; task < ntask; task += kThreads) {
           const unsigned j = hp[task];
           hn[task] = j >= kTerminal ? (unsigned short)j : hp[j];
@@ -654,12 +683,12 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       // G-1-g hops above the start
       {
         const int last = ltx - 1;
-        const bool start_ok = (level_cost < INFINITY) && lty - 1 >= (int)lo[last] && lty - 1 <= (int)hi[last];
+        const bool start_ok = (level_cost < INFINITY) && lty - 1 >= LO(last) && lty - 1 <= HI(last);
         for (int g = tid; g < G; g += kThreads) {
-          unsigned t = start_ok ? (unsigned)(segoff[G - 1] + lty - 1 - (int)lo[last]) : kInvalid;
+          unsigned t = start_ok ? (unsigned)(segoff[G - 1] + lty - 1 - LO(last)) : kInvalid;
           const int h = G - 1 - g;
-          for (int k = 0; k < nlev && t < kTerminal; ++k)
-            if ((h >> k) & 1) t = hop[(size_t)k * ntask + t];
+          for (int q = 0; q < nlev && t < kTerminal; ++q)
+            if ((h >> q) & 1) t = hop[(size_t)q * ntask + t];
           bool good = t < kTerminal;
           if (good && g == 0) good = hop[t] == kTerminal;  // the path must end in (-1, -1)
           if (good) {
@@ -681,14 +710,15 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         for (int g = g0; g < g1; ++g) sum += segend[g];
         int total;
         int run = wave_excl_scan(sum, lane, &total);
-        const int first = pcap - total;
+        const int first = k == 0 ? 0 : wcap - total;
         for (int g = g0; g < g1; ++g) {
           run += segend[g];
           segend[g] = first + run;
         }
         if (lane == 0) {
           bcast[0] = first;
-          if (total > pcap) bcast[1] = 0;
+          bcast[5] = total;
+          if (total > wcap) bcast[1] = 0;
         }
       }
       __syncthreads();
@@ -697,45 +727,62 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
         for (int g = tid; g < G; g += kThreads) {
           const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
           int nc;
-          (void)dtw_walk<true>(rinfo, bp16, pth_i, pth_j, bot, (int)lo[bot] + segent[g], g * kSeg, segend[g], &nc);
+          if (k == 0) (void)dtw_walk<true>(rinfo, bp16, out_i, out_j, bot, LO(bot) + segent[g], g * kSeg, segend[g], &nc);
+          else (void)dtw_walk<true>(rinfo, bp16, pth_i, pth_j, bot, LO(bot) + segent[g], g * kSeg, segend[g], &nc);
         }
       }
     } else if (w0) {
       // sequential fallback (very wide windows): the walk is wave-uniform, so the loaded values are
-      // made scalar (readfirstlane) and the control flow runs on the scalar unit
+      // made scalar (readfirstlane) and the control flow runs on the scalar unit.  First pass counts, second writes.
       auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-      int bi = ltx - 1, bj = lty - 1, pos = pcap;
-      int ok = uni((level_cost < INFINITY) ? 1 : 0);
-      while (ok) {
-        const int rl = uni((int)lo[bi]), rh = uni((int)hi[bi]), cb = uni((int)(rinfo[bi] >> 32));
-        if (bj < rl || bj > rh) { ok = 0; break; }
-        bool up = false;
-        while (!up) {  // cells of this row on the path
-          if (pos == 0 || bj < rl) { ok = 0; break; }
-          const int code = uni((int)bp_code(bp16, cb + bj - rl));
-          --pos;
-          if (lane == 0) {
-            pth_i[pos] = (unsigned short)bi;
-            pth_j[pos] = (unsigned short)bj;
+      int ok = uni((level_cost < INFINITY) ? 1 : 0), total = 0, first = 0;
+      for (int pass = 0; pass < 2 && ok; ++pass) {
+        int bi = ltx - 1, bj = lty - 1, pos = first + total;
+        int cnt = 0;
+        while (ok) {
+          const int rl = uni(LO(bi)), rh = uni(HI(bi)), cb = uni(OFF(bi));
+          if (bj < rl || bj > rh) { ok = 0; break; }
+          bool up = false;
+          while (!up) {  // cells of this row on the path
+            if (cnt >= wcap || bj < rl) { ok = 0; break; }
+            const int code = uni((int)bp_code(bp16, cb + bj - rl));
+            ++cnt;
+            if (pass == 1) {
+              --pos;
+              if (lane == 0) {
+                if (k == 0) {
+                  out_i[pos] = bi;
+                  out_j[pos] = bj;
+                } else {
+                  pth_i[pos] = (unsigned short)bi;
+                  pth_j[pos] = (unsigned short)bj;
+                }
+              }
+            }
+            if (code != 0) bj -= 1;
+            up = code != 1;
           }
-          if (code != 0) bj -= 1;
-          up = code != 1;
+          if (!ok) break;
+          bi -= 1;
+          if (bi < 0) {
+            if (bj != -1) ok = 0;
+            break;
+          }
         }
-        if (!ok) break;
-        bi -= 1;
-        if (bi < 0) {
-          if (bj != -1) ok = 0;
-          break;
+        if (pass == 0) {
+          total = cnt;
+          first = k == 0 ? 0 : wcap - total;
         }
       }
       if (lane == 0) {
-        bcast[0] = pos;
+        bcast[0] = first;
+        bcast[5] = total;
         bcast[1] = ok;
       }
     }
     __syncthreads();
     pstart = bcast[0];
-    pn = pcap - pstart;
+    pn = bcast[5];
     if (!bcast[1]) fail = true;
     __syncthreads();
     DTW_TICK(5);
@@ -743,14 +790,10 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
 
   if (fail) {
     if (tid == 0) {
-      p.path_len[n] = 0;
+      p.path_len[n] = p.tier == 1 ? -1 : 0;
       p.cost[n] = NAN;
     }
     return;
-  }
-  for (int q = tid; q < pn; q += kThreads) {
-    out_i[q] = pth_i[pstart + q];
-    out_j[q] = pth_j[pstart + q];
   }
   if (tid == 0) {
     p.path_len[n] = pn;
@@ -764,14 +807,30 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
 #endif
 }
 
-size_t lds_bytes(int Tx, int Ty, int D, const DtwParams &p) {
+size_t lds_bytes(int Tx, int Ty, const DtwParams &p) {
   size_t b = 0;
-  b += sizeof(double) * (2 * ((size_t)p.chunkcap + 4 * kRows + 4) + 2 * (size_t)(Ty + kHandExtra));
-  b += sizeof(unsigned long long) * (size_t)Tx;
-  b += sizeof(int) * ((size_t)(Tx + 1) + 2 * kMaxLevels + 8 + 3 * (size_t)(Tx / kSegMin + 3));
-  b += sizeof(unsigned short) * ((size_t)2 * Tx + 2 * (Tx / 2 + 2) + 2 * (size_t)(Tx + Ty));
+  b += sizeof(double) * (2 * ((size_t)p.chunkcap + 4 * kRows + 4) + kHandDummy);
+  b += sizeof(unsigned long long) * (size_t)(Tx + 1);
+  b += sizeof(int) * (2 * kMaxLevels + 16 + 3 * (size_t)(Tx / kSegMin + 3));
+  b += sizeof(unsigned short) * (2 * (size_t)(Tx / 2 + 2) + 2 * (size_t)p.pcap_lds);
   b += sizeof(unsigned short) * ((size_t)p.hwcap + 64) + 16;  // back-pointer halfwords + one throw-away halfword per lane
   return (b + 15) & ~(size_t)15;
+}
+
+template <int kThreads>
+int launch_one(hipStream_t s, const DtwParams &p, int N, size_t lds) {
+  constexpr int kMaxDevices = 16;
+  static size_t attr_set[kMaxDevices] = {};  // largest dynamic-LDS size the attribute was set to, per device
+  int device = 0;
+  MLPG_HIP_CHECK(hipGetDevice(&device));
+  if (device < 0 || device >= kMaxDevices || attr_set[device] < lds) {
+    MLPG_HIP_CHECK(hipFuncSetAttribute((const void *)fastdtw_kernel<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+    if (device >= 0 && device < kMaxDevices) attr_set[device] = lds;
+  }
+  hipLaunchKernelGGL(fastdtw_kernel<kThreads>, dim3(N), dim3(kThreads), lds, s, p);
+  MLPG_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 }  // namespace
@@ -798,27 +857,44 @@ int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, 
   p.dist_kind = dist_kind;
   p.dist_scale = dist_scale;
   p.pyr_stride = (size_t)(Tx + Ty) * D;
-  // window cells per level <= (4r+2)(tx+ty); the coarsest level runs a
-  // full DTW with one side <= r+1
+  p.pcap_lds = (Tx + Ty) / 2 + 2;
+  p.tier = 0;
+  // BOUNDS: window cells per level <= (4r+2)(tx+ty); the coarsest level runs a full DTW with one side
+  // <= r+1.  Back-pointer halfwords: per row <= ((width + 6) >> 3) + 1 <= width / 8 + 1.75.  A cost buffer must take
+  // the widest handed-over row and the widest row (both <= Ty) with the slack.
   long cc = (long)(4 * radius + 2) * (Tx + Ty) + 64;
   const long full = (long)Tx * Ty;
   if (full < cc) cc = full + 64;
   p.cellcap = (int)cc;
-  p.chunkcap = Ty > 1024 ? Ty : 1024;
-  // back-pointer halfwords: per row ((width + 6) >> 3) + 2 <= width / 8 + 2.75, one guard in front
-  p.hwcap = (int)(cc / 8 + 3 * (long)Tx + 2);
-  const size_t lds = lds_bytes(Tx, Ty, D, p);
+  p.hwcap = (int)(cc / 8 + 2 * (long)Tx + 2);
+  p.chunkcap = 2 * Ty + 2 * kSlack > 1024 ? 2 * Ty + 2 * kSlack : 1024;
+  const size_t lds = lds_bytes(Tx, Ty, p);
   if (lds > 160 * 1024) {
     set_error("fastdtw: Tx=%d, Ty=%d, D=%d, radius=%d needs %zu bytes of LDS (> 160 KiB)", Tx, Ty, D, radius, lds);
     return MLPG_HIP_EINVAL;
   }
-  p.pyr = (double *)scratch(device, s, 1, sizeof(double) * p.pyr_stride * (size_t)N);
-  if (!p.pyr) return MLPG_HIP_ENOMEM;
-  MLPG_HIP_CHECK(hipFuncSetAttribute((const void *)fastdtw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-  hipLaunchKernelGGL(fastdtw_kernel, dim3(N), dim3(kThreads), lds, s, p);
-  MLPG_HIP_CHECK(hipGetLastError());
-  return 0;
+  constexpr size_t kTicketBytes = 2048 * sizeof(int);
+  p.cu_tickets = (int *)scratch(device, s, 1, kTicketBytes + sizeof(double) * p.pyr_stride * (size_t)N);
+  if (!p.cu_tickets) return MLPG_HIP_ENOMEM;
+  p.pyr = (double *)((char *)p.cu_tickets + kTicketBytes);
+  // Many pairs: an optimistic first launch with capacities for the usual window shapes (rows up to ~20 cells) and
+  // 256 threads per pair -- four pairs resident per CU instead of two -- and a second launch with the bounds for
+  // the pairs that did not fit (they are marked path_len = -1; normally none, the launch is a few microseconds).
+  const int cus = 256;
+  DtwParams q = p;
+  q.tier = 1;
+  q.chunkcap = 704;
+  q.hwcap = (int)(2.5 * Tx) + 64;
+  if (q.hwcap > p.hwcap) q.hwcap = p.hwcap;
+  const size_t lds_q = lds_bytes(Tx, Ty, q);
+  static const int force = [] { const char *e = getenv("MLPG_HIP_DTW_FORCE"); return e ? atoi(e) : 0; }();  // measurement switch: 1 two launches, 2 one
+  if (force != 2 && (N > 2 * cus || force == 1) && q.chunkcap < p.chunkcap && lds_q <= 40 * 1024) {
+    if (int rc = launch_one<256>(s, q, N, lds_q)) return rc;
+    static const bool first_only = getenv("MLPG_HIP_DTW_FIRST_LAUNCH_ONLY") != nullptr;  // measurement switch
+    if (first_only) return 0;
+    p.tier = 2;
+  }
+  return launch_one<512>(s, p, N, lds);
 }
 
 }  // namespace mlpg
