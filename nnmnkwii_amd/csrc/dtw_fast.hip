@@ -110,6 +110,66 @@ __device__ __forceinline__ double l2_cost(const double *__restrict__ a, const do
   return __dsqrt_rn(acc);
 }
 
+// Two neighbouring cells of one row at once: sqrt(sum_k (x_k - ya_k)^2) and sqrt(sum_k (x_k - yb_k)^2), each sum
+// exactly as l2_cost (ascending k, separate multiply and add).  The rows are read 16 bytes at a time (they are 8-byte
+// aligned: unaligned dwordx4 loads), 8 elements per row per batch, and the x row only once: a 25-dim pair of cells
+// waits for memory twice, not eight times, and issues less than a third of the load instructions.  The costs under
+// the sweep are bound by exactly that once four pairs share a CU.
+typedef double dtw_d2 __attribute__((ext_vector_type(2), aligned(8)));
+constexpr int kCostPairs = 4;  // 16-byte loads per row per batch
+__device__ __forceinline__ void l2_cost2(const double *__restrict__ x, const double *__restrict__ ya,
+                                         const double *__restrict__ yb, int D, double *c0, double *c1) {
+  double acc0 = 0.0, acc1 = 0.0;
+  const int npair = D >> 1;
+  // the odd last element is fetched first: it lands while the batches are worked on
+  const double tx_ = x[D - 1], ta_ = ya[D - 1], tb_ = yb[D - 1];
+  auto batch = [&](const dtw_d2 (&vx)[kCostPairs], const dtw_d2 (&vya)[kCostPairs], const dtw_d2 (&vyb)[kCostPairs], int cnt) {
+#pragma unroll
+    for (int q = 0; q < kCostPairs; ++q) {
+      if (q < cnt) {
+        double d0 = __dsub_rn(vx[q].x, vya[q].x), d1 = __dsub_rn(vx[q].x, vyb[q].x);
+        acc0 = __dadd_rn(acc0, __dmul_rn(d0, d0));
+        acc1 = __dadd_rn(acc1, __dmul_rn(d1, d1));
+        d0 = __dsub_rn(vx[q].y, vya[q].y);
+        d1 = __dsub_rn(vx[q].y, vyb[q].y);
+        acc0 = __dadd_rn(acc0, __dmul_rn(d0, d0));
+        acc1 = __dadd_rn(acc1, __dmul_rn(d1, d1));
+      }
+    }
+  };
+  int k = 0;
+#pragma unroll 1
+  for (; k + kCostPairs <= npair; k += kCostPairs) {  // full batches: one address per row, offsets in the instructions
+    dtw_d2 vx[kCostPairs], vya[kCostPairs], vyb[kCostPairs];
+    const dtw_d2 *px_ = (const dtw_d2 *)(x + 2 * k), *pa_ = (const dtw_d2 *)(ya + 2 * k), *pb_ = (const dtw_d2 *)(yb + 2 * k);
+#pragma unroll
+    for (int q = 0; q < kCostPairs; ++q) {
+      vx[q] = px_[q];
+      vya[q] = pa_[q];
+      vyb[q] = pb_[q];
+    }
+    batch(vx, vya, vyb, kCostPairs);
+  }
+  if (k < npair) {  // the rest: indices past the end read the last pair again (not used)
+    dtw_d2 vx[kCostPairs], vya[kCostPairs], vyb[kCostPairs];
+#pragma unroll
+    for (int q = 0; q < kCostPairs; ++q) {
+      const int e = 2 * (k + q < npair ? k + q : npair - 1);
+      vx[q] = *(const dtw_d2 *)(x + e);
+      vya[q] = *(const dtw_d2 *)(ya + e);
+      vyb[q] = *(const dtw_d2 *)(yb + e);
+    }
+    batch(vx, vya, vyb, npair - k);
+  }
+  if (D & 1) {
+    const double d0 = __dsub_rn(tx_, ta_), d1 = __dsub_rn(tx_, tb_);
+    acc0 = __dadd_rn(acc0, __dmul_rn(d0, d0));
+    acc1 = __dadd_rn(acc1, __dmul_rn(d1, d1));
+  }
+  *c0 = __dsqrt_rn(acc0);
+  *c1 = __dsqrt_rn(acc1);
+}
+
 // scale * sqrt(sum_k (a_k - b_k)^2) with the sum in numpy's order for a contiguous float64 vector of D <= 128
 // elements (numpy/core/src/umath/loops_utils.h.src, pairwise sum: sequential below 8 elements, else eight
 // partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail): what
@@ -234,7 +294,7 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c) {
 }
 
 template <int kThreads>
-__global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void fastdtw_kernel(DtwParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x;
@@ -329,22 +389,53 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
   }
   __syncthreads();
   {
-    const double *srcx = x0, *srcy = y0;  // both series advance one level per round
-    for (int k = 1; k <= K; ++k) {
-      double *dstx = px + lvl_x[k], *dsty = py + lvl_y[k];
-      const int cntx = (tx >> k) * D, cnty = (ty >> k) * D;
-#pragma unroll 4
-      for (int e = tid; e < cntx + cnty; e += kThreads) {
-        const bool isx = e < cntx;
-        const int ee = isx ? e : e - cntx;
+    // up to three levels per round (one barrier each): an item reads a column of 8 / 4 / 2 consecutive source rows and
+    // produces the 4 + 2 + 1 means above them -- every mean the same two-operand expression as level by level
+    const double *srcx = x0, *srcy = y0;
+    int cx = tx, cy = ty;  // rows of the source level
+    for (int k0 = 0; k0 < K;) {
+      const int nl = K - k0 < 3 ? K - k0 : 3, span = 1 << nl, half = span >> 1;
+      const int nbx = ((cx >> 1) + half - 1) / half, nby = ((cy >> 1) + half - 1) / half;
+      const int itx = nbx * D, items = (nbx + nby) * D;
+      for (int e = tid; e < items; e += kThreads) {
+        const bool isx = e < itx;
+        const int ee = isx ? e : e - itx;
+        const int blk = ee / D, c = ee - blk * D;
         const double *src = isx ? srcx : srcy;
-        const int row = ee / D, c = ee - row * D;
-        (isx ? dstx : dsty)[ee] = __dadd_rn(src[(size_t)(2 * row) * D + c], src[(size_t)(2 * row + 1) * D + c]) * 0.5;
+        const int cnt0 = isx ? cx : cy;
+        double *base_ = isx ? px : py;
+        const int *lvl = isx ? lvl_x : lvl_y;
+        double v[8], a1[4], a2[2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int row = blk * span + q;
+          v[q] = (q < span && row < cnt0) ? src[(size_t)row * D + c] : 0.0;
+        }
+        double *d1 = base_ + lvl[k0 + 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a1[q] = __dadd_rn(v[2 * q], v[2 * q + 1]) * 0.5;
+          const int r1 = blk * half + q;
+          if (q < half && r1 < (cnt0 >> 1)) d1[(size_t)r1 * D + c] = a1[q];
+        }
+        if (nl >= 2) {
+          double *d2 = base_ + lvl[k0 + 2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            a2[q] = __dadd_rn(a1[2 * q], a1[2 * q + 1]) * 0.5;
+            const int r2 = blk * (half >> 1) + q;
+            if (q < (half >> 1) && r2 < (cnt0 >> 2)) d2[(size_t)r2 * D + c] = a2[q];
+          }
+          if (nl >= 3 && blk < (cnt0 >> 3)) (base_ + lvl[k0 + 3])[(size_t)blk * D + c] = __dadd_rn(a2[0], a2[1]) * 0.5;
+        }
       }
       __threadfence_block();
       __syncthreads();
-      srcx = dstx;
-      srcy = dsty;
+      k0 += nl;
+      srcx = px + lvl_x[k0];
+      srcy = py + lvl_y[k0];
+      cx >>= nl;
+      cy >>= nl;
     }
   }
 
@@ -447,6 +538,30 @@ __global__ __launch_bounds__(kThreads) void fastdtw_kernel(DtwParams p) {
       const int i0 = (int)cstart[c], R = (int)cstart[c + 1] - i0, base = OFF(i0);
       const int ncell = OFF(i0 + R) - base;
       double *dst = buf + feed_cells(i0);
+      if (p.dist_kind == MLPG_HIP_DIST_L2 && D >= 2) {
+        // two cells per thread and round: cells 2t, 2t + 1 of the chunk.  Windows start on even columns and have even
+        // widths except where they are clipped at the level's last column, so the two are neighbours in one row almost
+        // always (one evaluation with the x row shared); a pair that a row boundary splits is evaluated cell by cell.
+        for (int cc = 2 * (tid - t0); cc < ncell; cc += 2 * nthr) {
+          int a = 0, b = R;
+          while (b - a > 1) {
+            const int mid = (a + b) >> 1;
+            if (OFF(i0 + mid) - base <= cc) a = mid; else b = mid;
+          }
+          const int row = i0 + a, j = LO(row) + cc - (OFF(row) - base);
+          const double *xr = xk + (size_t)row * D, *yr = yk + (size_t)j * D;
+          const bool two = cc + 1 < ncell;
+          if (!two || cc + 1 < OFF(row + 1) - base) {
+            double c0, c1;
+            l2_cost2(xr, yr, two ? yr + D : yr, D, &c0, &c1);
+            dst[cc + 4 * a + 2] = c0;
+            if (two) dst[cc + 4 * a + 3] = c1;
+          } else {
+            dst[cc + 4 * a + 2] = l2_cost(xr, yr, D);
+            dst[cc + 1 + 4 * (a + 1) + 2] = l2_cost(xr + D, yk + (size_t)LO(row + 1) * D, D);
+          }
+        }
+      } else
       for (int cc = tid - t0; cc < ncell; cc += nthr) {
         int a = 0, b = R;
         while (b - a > 1) {
