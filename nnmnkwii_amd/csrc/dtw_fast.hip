@@ -41,6 +41,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #ifdef MLPG_DTW_TIMING
@@ -676,7 +678,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       // (bound_ctrl), which makes it replay its stored row: up + dt = diag + dt = dt exactly and left + dt >= dt (D >= 0).
       // Codes: bit a = "diagonal < left", then bit b = "min(left, diagonal) < up": up unless b, else diagonal if a,
       // else left -- the first minimum in the order up, left, diagonal, as the oracle's three compares.
-      auto block = [&](const double (&dt)[8]) {
+      auto block = [&](const double (&dt)[8], auto store_tag) {
+        constexpr bool STORE = decltype(store_tag)::value;
         const int dbase = ((unsigned)x_run < wlim) ? d_m8 + 8 * x_run : d_dummy;
         lds_f64 *dw = (lds_f64 *)(uintptr_t)(unsigned)dbase;
 #pragma unroll
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
           const double cu = __dadd_rn(up, dt[k8]);
           const double best = vmin_f64(cu, x);
           acc = shift_in_lt(acc, x, cu);
-          dw[k8] = best;
+          if (STORE) dw[k8] = best;
           upp = up;
           pub = best;
         }
@@ -696,14 +699,25 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
         q_rel += 1;
         x_run += 8;
       };
+      // The last lane reaches its window only in the final blocks of the chunk: the blocks before (an even number of
+      // them) run without the hand-over stores -- a sixth of the sweep's time when every block carried them.
+      const int c0_last = s0 - R - last_lo;  // the last lane's c0 (uniform)
+      int b_st = (-c0_last - kSlack) >> 3;   // its first block whose columns reach -kSlack: floor((-kSlack - c0) / 8)
+      b_st = b_st < 0 ? 0 : (b_st > nblocks ? nblocks : b_st) & ~1;
       double dA[8], dB[8];
       load_block(dA);
-      for (int b = 0; b < nblocks; b += 2) {
+      for (int b = 0; b < b_st; b += 2) {
         load_block(dB);
-        block(dA);
+        block(dA, std::false_type());
+        load_block(dA);
+        block(dB, std::false_type());
+      }
+      for (int b = b_st; b < nblocks; b += 2) {
+        load_block(dB);
+        block(dA, std::true_type());
         if (b + 1 >= nblocks) break;
         load_block(dA);
-        block(dB);
+        block(dB, std::true_type());
       }
       if (is_last) {  // +INF frame of the row handed to the next chunk
         dnxt[kSlack - 2] = INFINITY;
