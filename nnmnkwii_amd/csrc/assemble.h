@@ -46,7 +46,7 @@ __device__ __forceinline__ SysView<TIN, BWD> make_view(const Problem &p, const W
   v.var_mode = p.var_mode;
   v.ld_in = p.ld_in;
   v.ld_gout = p.ld_gout;
-  v.sd = p.sd;
+  v.sd = p.pitch ? p.pitch : p.sd;  // SysView::sd is the pitch between a dim's windows
   v.d = d;
   v.T = T;
   v.mw = ws.mw;

@@ -7,6 +7,9 @@
 #include <mutex>
 #include <utility>
 
+#include <limits.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace mlpg {
@@ -192,6 +195,14 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     }
     algo = MLPG_HIP_ALGO_STRIP;
   }
+  if (p.pitch && p.pitch != p.sd) {
+    // a piece of a stream (window pitch != number of dims): the kernels that take the pitch separately
+    if (backward) {
+      set_error("a stream piece (pitch %d, %d dims) has no backward pass", p.pitch, p.sd);
+      return MLPG_HIP_EINVAL;
+    }
+    algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
+  }
   if (algo == MLPG_HIP_ALGO_AUTO) {
     if (strip_preferred(p, ws, backward, in_dtype) || (strip_supported(p, ws) && !wave_supported(p, ws))) algo = MLPG_HIP_ALGO_STRIP;
     else algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
@@ -255,11 +266,14 @@ int solve_entry(int device, void *stream, int in_dtype, int out_dtype, int algo,
 int stream_entry(int device, hipStream_t st, int dtype, int algo, const void *mean, const void *var, int var_mode,
                  long ld_in, const int32_t *lengths, int B, int Tmax, const mlpg_hip_stream_t &sm, const int32_t *wl,
                  const int32_t *wu, const double *wc, void *out, long ld_out, int32_t *status, int ld_status,
-                 int status_col) {
+                 int status_col, int d_first = 0, int d_count = -1) {
+  // [d_first, d_first + d_count): the stream's static dims this call solves (all of them by default)
   const size_t esz = dtype == MLPG_HIP_F32 ? 4 : 8;
-  const int sd = sm.static_dim, nw = sm.num_windows;
-  const char *mean_s = (const char *)mean + esz * (size_t)sm.in_col;
-  char *out_s = (char *)out + esz * (size_t)sm.out_col;
+  const int nw = sm.num_windows;
+  const int sd = d_count < 0 ? sm.static_dim : d_count;
+  const char *mean_s = (const char *)mean + esz * (size_t)(sm.in_col + d_first);
+  char *out_s = (char *)out + esz * (size_t)(sm.out_col + d_first);
+  status_col += d_first;
   if (nw == 0) return launch_copy_cols(st, dtype, mean_s, ld_in, lengths, B, Tmax, sd, out_s, ld_out);
   size_t coff = 0;
   for (int w = 0; w < sm.win_first; ++w) coff += (size_t)(wl[w] + wu[w] + 1);
@@ -267,7 +281,7 @@ int stream_entry(int device, hipStream_t st, int dtype, int algo, const void *me
   if (int rc = pack_windows(nw, wl + sm.win_first, wu + sm.win_first, wc + coff, &ws)) return rc;
   Problem p;
   p.mean = mean_s;
-  p.var = var ? (const char *)var + esz * (size_t)sm.in_col : nullptr;
+  p.var = var ? (const char *)var + esz * (size_t)(sm.in_col + d_first) : nullptr;
   p.grad_out = nullptr;
   p.lengths = lengths;
   p.out = out_s;
@@ -277,6 +291,7 @@ int stream_entry(int device, hipStream_t st, int dtype, int algo, const void *me
   p.Tmax = Tmax;
   p.D = nw * sd;
   p.sd = sd;
+  p.pitch = sd != sm.static_dim ? sm.static_dim : 0;
   p.ld_in = ld_in;
   p.ld_gout = 0;
   p.ld_out = ld_out;
@@ -393,10 +408,129 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
   // The streams are independent: the widest one runs on the caller's stream, every other one on a side stream of
   // this device that is forked from and joined back into the caller's stream with events (no host synchronisation,
   // capturable), so that a narrow stream's launch fills the tail of the wide one instead of queueing behind it.
+  if (num_streams > 64) {
+    set_error("forward_streams: more than 64 streams");
+    return MLPG_HIP_EINVAL;
+  }
+  int status_cols[64];
+  {
+    int c = 0;
+    for (int k = 0; k < num_streams; ++k) { status_cols[k] = c; c += streams_h[k].static_dim; }
+  }
+  // Streams with the same three windows (extent <= 1) and per-frame variances can share ONE strip-kernel launch: their
+  // static dims sit side by side on the lanes (66 = 60 + 1 + 5 dims of a Merlin-style row: one group of 64 and one of
+  // 2), every row of the batch is fetched once instead of once per stream.  Taken when it does not add lane groups
+  // and the launch is one the strip kernel would be chosen for anyway.
+  bool merged_flag[64] = {};
+  // The merged launch holds full groups of 64 lanes only: a last group of a few lanes would hold its workgroup slots
+  // as long as a full group's while moving almost nothing (66 dims in one launch: 1.39 ms on the config-5 batch, the
+  // full row in 64 lanes + the rest alone: see DESIGN.md).  So when the dims do not fill their last group at least half,
+  // the streams are packed greedily (widest first) into the full groups and the others run on their own as before.
+  StreamMap smap;
+  WinSet ws_merged;
+  Problem p_merged;
+  bool have_merged = false;
+  int piece_stream = -1, piece_first = 0;  // stream cut between the merged launch (dims < piece_first) and its own launch
+  if ((algo == MLPG_HIP_ALGO_AUTO || algo == MLPG_HIP_ALGO_STRIP) && var_mode == MLPG_HIP_VAR_FRAME) {
+    int first = -1, cnt = 0, total = 0;
+    int members[64];
+    size_t coff_first = 0;
+    for (int k = 0; k < num_streams; ++k) {
+      const mlpg_hip_stream_t &sm = streams_h[k];
+      if (sm.static_dim <= 0 || sm.num_windows != 3) continue;
+      size_t coff = 0;
+      for (int w = 0; w < sm.win_first; ++w) coff += (size_t)(win_l_h[w] + win_u_h[w] + 1);
+      bool same = true;
+      size_t nco = 0;
+      for (int w = 0; w < 3 && same; ++w) {
+        const int l = win_l_h[sm.win_first + w], u = win_u_h[sm.win_first + w];
+        if (l < 0 || u < 0 || l > 1 || u > 1) same = false;
+        else if (first >= 0 && (l != win_l_h[streams_h[first].win_first + w] || u != win_u_h[streams_h[first].win_first + w])) same = false;
+        else nco += (size_t)(l + u + 1);
+      }
+      if (same && first >= 0) same = memcmp(win_coef_h + coff, win_coef_h + coff_first, nco * sizeof(double)) == 0;
+      if (!same) continue;
+      if (first < 0) { first = k; coff_first = coff; }
+      members[cnt++] = k;
+      total += sm.static_dim;
+    }
+    int cap = total;
+    if (total > 64 && total % 64 < 32) cap = total - total % 64;
+    // widest first (insertion sort, stable), then greedy
+    for (int i = 1; i < cnt; ++i)
+      for (int j = i; j > 0 && streams_h[members[j]].static_dim > streams_h[members[j - 1]].static_dim; --j) {
+        const int t_ = members[j]; members[j] = members[j - 1]; members[j - 1] = t_;
+      }
+    memset(&smap, 0, sizeof(smap));
+    for (int q = 0; q < 4; ++q) smap.begin[q] = INT_MAX;
+    int n = 0, pos = 0;
+    for (int i = 0; i < cnt && n < 4; ++i) {
+      const mlpg_hip_stream_t &sm = streams_h[members[i]];
+      if (pos + sm.static_dim > cap) continue;
+      smap.begin[n] = pos;
+      smap.in_col[n] = sm.in_col;
+      smap.sd[n] = sm.static_dim;
+      smap.out_col[n] = sm.out_col;
+      smap.stat_col[n] = status_cols[members[i]];
+      merged_flag[members[i]] = true;
+      pos += sm.static_dim;
+      ++n;
+    }
+    // lanes left over: the first dims of one more stream; the rest of it runs as a piece (wave-per-system kernel)
+    if (pos < cap && n < 4)
+      for (int i = 0; i < cnt; ++i) {
+        const int k = members[i];
+        if (merged_flag[k]) continue;
+        const mlpg_hip_stream_t &sm = streams_h[k];
+        smap.begin[n] = pos;
+        smap.in_col[n] = sm.in_col;
+        smap.sd[n] = sm.static_dim;
+        smap.out_col[n] = sm.out_col;
+        smap.stat_col[n] = status_cols[k];
+        piece_stream = k;
+        piece_first = cap - pos;
+        pos = cap;
+        ++n;
+        break;
+      }
+    smap.n = n;
+    smap.total = pos;
+    bool ok = n >= 2 && (pos + 63) / 64 <= n &&
+              pack_windows(3, win_l_h + streams_h[first].win_first, win_u_h + streams_h[first].win_first, win_coef_h + coff_first, &ws_merged) == 0;
+    if (ok) {
+      Problem &p = p_merged;
+      p.mean = mean;
+      p.var = var;
+      p.grad_out = nullptr;
+      p.lengths = lengths;
+      p.out = out;
+      p.status = status;
+      p.var_mode = var_mode;
+      p.B = B;
+      p.Tmax = Tmax;
+      p.sd = pos;
+      p.D = 3 * pos;
+      p.ld_in = ld_in;
+      p.ld_gout = 0;
+      p.ld_out = ld_out;
+      p.ld_status = (int)sd_total;
+      // the decision the widest group would get alone (long utterances, or enough 64-frame strips)
+      Problem pw = p;
+      pw.sd = pos < 64 ? pos : 64;
+      pw.D = 3 * pw.sd;
+      ok = strip_supported(p, ws_merged) && (algo == MLPG_HIP_ALGO_STRIP || strip_preferred(pw, ws_merged, false, dtype));
+    }
+    have_merged = ok;
+    if (!ok) {
+      memset(merged_flag, 0, sizeof(merged_flag));
+      piece_stream = -1;
+    }
+  }
   int widest = -1;
   for (int k = 0; k < num_streams; ++k)
-    if (streams_h[k].static_dim > 0 && (widest < 0 || streams_h[k].static_dim * (streams_h[k].num_windows + 1) >
-                                                          streams_h[widest].static_dim * (streams_h[widest].num_windows + 1)))
+    if (streams_h[k].static_dim > 0 && !merged_flag[k] &&
+        (widest < 0 || streams_h[k].static_dim * (streams_h[k].num_windows + 1) >
+                           streams_h[widest].static_dim * (streams_h[widest].num_windows + 1)))
       widest = k;
   hipStream_t main_st = (hipStream_t)stream;
   SideStreams *side = side_streams(device);
@@ -407,7 +541,8 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
   // The fork is recorded BEFORE anything of this call is queued on the caller's stream and the widest stream is
   // launched last: the narrow streams' kernels then only wait for what preceded the call, not for the wide kernel.
   int n_narrow = 0;
-  for (int k = 0; k < num_streams; ++k) n_narrow += streams_h[k].static_dim > 0 && k != widest;
+  for (int k = 0; k < num_streams; ++k) n_narrow += streams_h[k].static_dim > 0 && k != widest && !merged_flag[k];
+  if (have_merged && widest >= 0) ++n_narrow;  // the merged launch takes the caller's stream first
   if (side && n_narrow > 0) MLPG_HIP_CHECK(hipEventRecord(side->fork, main_st));
   auto join_side = [&]() -> int {  // also on the error paths: an unjoined side stream would break a graph capture
     for (int q = 0; q < nside; ++q) {
@@ -417,19 +552,12 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
     nside = 0;
     return 0;
   };
-  int status_cols[64];
-  {
-    int c = 0;
-    for (int k = 0; k < num_streams && k < 64; ++k) { status_cols[k] = c; c += streams_h[k].static_dim; }
-  }
-  if (num_streams > 64) {
-    set_error("forward_streams: more than 64 streams");
-    return MLPG_HIP_EINVAL;
-  }
   auto run_stream = [&](const int k, hipStream_t st) -> int {
     const mlpg_hip_stream_t &sm = streams_h[k];
+    const bool piece = k == piece_stream;
     if (int rc = stream_entry(device, st, dtype, algo, mean, var, var_mode, (long)ld_in, lengths, B, Tmax, sm, win_l_h,
-                              win_u_h, win_coef_h, out, (long)ld_out, status, (int)sd_total, status_cols[k]))
+                              win_u_h, win_coef_h, out, (long)ld_out, status, (int)sd_total, status_cols[k],
+                              piece ? piece_first : 0, piece ? sm.static_dim - piece_first : -1))
       return rc;
     if (sm.num_windows == 0 && status) {
       // pass-through streams cannot fail: their status columns are cleared
@@ -442,7 +570,7 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
   // 1 everything on the caller's stream; 2 widest first, narrow streams behind it on ONE side stream
   static const int mode = [] { const char *e = getenv("MLPG_HIP_STREAMS_MODE"); return e ? atoi(e) : 0; }();
   if (mode == 1) side = nullptr;
-  if (mode == 2 && widest >= 0) {
+  if (mode == 2 && widest >= 0 && !have_merged) {
     if (int rc = run_stream(widest, main_st)) return rc;
     bool forked = false;
     for (int k = 0; k < num_streams; ++k) {
@@ -460,7 +588,7 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
     return join_side();
   }
   for (int k = 0; k < num_streams; ++k) {
-    if (streams_h[k].static_dim <= 0 || k == widest) continue;
+    if (streams_h[k].static_dim <= 0 || k == widest || merged_flag[k]) continue;
     hipStream_t st = main_st;
     if (side && nside < SideStreams::kN) {
       st = side->st[nside];
@@ -472,6 +600,23 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
       }
     }
     if (int rc = run_stream(k, st)) {
+      (void)join_side();
+      return rc;
+    }
+  }
+  if (have_merged) {
+    int rc = launch_strip_multi(main_st, dtype, p_merged, ws_merged, smap, device);
+    if (rc == -1000) {  // the grid cannot hold an utterance (nothing enqueued): one stream after the other
+      rc = 0;
+      for (int k = 0; k < num_streams && rc == 0; ++k)
+        if (merged_flag[k]) rc = run_stream(k, main_st);
+      if (rc == 0 && piece_stream >= 0) {  // and the head of the cut stream
+        const mlpg_hip_stream_t &sm = streams_h[piece_stream];
+        rc = stream_entry(device, main_st, dtype, algo, mean, var, var_mode, (long)ld_in, lengths, B, Tmax, sm, win_l_h, win_u_h,
+                          win_coef_h, out, (long)ld_out, status, (int)sd_total, status_cols[piece_stream], 0, piece_first);
+      }
+    }
+    if (rc) {
       (void)join_side();
       return rc;
     }

@@ -34,6 +34,10 @@ struct Problem {
   int32_t *status;
   int var_mode;
   int B, Tmax, D, sd;
+  // Columns between a dim's windows in a row; 0 = sd.  Differs from sd when the problem is a PIECE of a stream (some of
+  // its static dims: mlpg_hip_forward_streams cuts streams to fill lane groups): forward pass on the wave-per-system
+  // and the natural-order kernels only.
+  int pitch = 0;
   // Row strides in elements; the utterance stride is Tmax * row stride (the parent array is a
   // densely packed (B, Tmax, ld) batch of which this problem is a column slice: one stream of a
   // multi-stream acoustic feature matrix).  Dense problems: ld_in = D, ld_gout = sd,
@@ -42,6 +46,14 @@ struct Problem {
   long ld_gout;   // grad_out rows (backward)
   long ld_out;    // out rows
   int ld_status;  // status[b * ld_status + d]
+};
+
+// Several streams of one (B, Tmax, ld) batch solved by ONE strip-kernel launch: their static dims sit side by side on
+// the lanes (merged index begin[s] .. begin[s+1]).  Columns are absolute in the parent arrays; unused entries of
+// begin[] are INT_MAX.
+struct StreamMap {
+  int n, total;
+  int begin[4], in_col[4], sd[4], out_col[4], stat_col[4];
 };
 
 void set_error(const char *fmt, ...);
@@ -59,6 +71,8 @@ bool strip_supported(const Problem &p, const WinSet &w);
 bool strip_preferred(const Problem &p, const WinSet &w, bool backward, int in_dtype);
 int launch_strip(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
                  int device);
+// forward pass of several streams (p: the parent arrays, sd/D unused) -- per-frame variances, three windows of extent <= 1
+int launch_strip_multi(hipStream_t s, int dtype, const Problem &p, const WinSet &w, const StreamMap &sm, int device);
 bool unit_mse_supported(int Tmax, const WinSet &w);
 size_t unit_mse_workspace_bytes(int B, int sd);
 int launch_unit_mse(hipStream_t s, int dtype, const Problem &p, const WinSet &w, const void *target, void *y_out,

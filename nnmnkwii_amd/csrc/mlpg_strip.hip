@@ -11,6 +11,8 @@ int launch_strip_fwd_f64(hipStream_t st, int out_dtype, const Problem &p, const 
 int launch_strip_fwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl);
 int launch_strip_bwd_f64(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl);
 int launch_strip_bwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl);
+int launch_strip_multi_f64(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl, const StreamMap &sm);
+int launch_strip_multi_f32(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl, const StreamMap &sm);
 
 namespace {
 constexpr int kStripFrames = 64;   // strip::kW * strip::kM
@@ -52,31 +54,44 @@ bool strip_preferred(const Problem &p, const WinSet &ws, bool backward, int in_d
   return nitems >= 512;
 }
 
+namespace {
+std::mutex g_clean_mu;
+std::map<std::pair<int, hipStream_t>, std::pair<unsigned long long, size_t>> g_clean;  // allocation, zero bytes at its head
+// a launch that enqueued nothing (kStripNotResident) after strip_scratch: nothing is known about the control area
+void strip_scratch_forget(hipStream_t st, int device) {
+  std::lock_guard<std::mutex> lk(g_clean_mu);
+  g_clean[{device, st}].second = 0;
+}
+// scratch (control words + records) of one launch and whether its control area is known to be zero already
+void *strip_scratch(hipStream_t st, int device, size_t nsg, int R, bool *zero_ctrl) {
+  const size_t ctrl = (((1 + 16 + nsg) * 32 + nsg * (size_t)((R + 31) / 32 * 32)) * sizeof(int) + 255) / 256 * 256;  // >= strip::ctrl_bytes
+  unsigned long long gen = 0;
+  void *sc = scratch(device, st, 3, ctrl + nsg * R * kRecBytes, &gen);
+  if (!sc) return nullptr;
+  // The control words must be zero when the kernel starts.  verdict_kernel leaves them zero again, so a launch on
+  // the same scratch whose control area is not larger than the previous one's (everything beyond it held records)
+  // needs no memset -- one dependent launch less per call.  Never trusted while the stream is being captured
+  // into a graph: a replay may follow launches this bookkeeping has not seen.
+  *zero_ctrl = true;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+  std::lock_guard<std::mutex> lk(g_clean_mu);
+  auto &c = g_clean[{device, st}];
+  if (!capturing && c.first == gen && ctrl <= c.second) *zero_ctrl = false;
+  c = {gen, capturing ? (size_t)0 : ctrl};
+  return sc;
+}
+}  // namespace
+
 int launch_strip(hipStream_t st, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &ws,
                  int device) {
   const int R = (p.Tmax + kStripFrames - 1) / kStripFrames;
   const int ndg = (p.sd + 63) / 64;
   const int dgw = (p.sd + ndg - 1) / ndg;
   const size_t nsg = (size_t)p.B * ndg;
-  const size_t ctrl = (((1 + 16 + nsg) * 32 + nsg * (size_t)((R + 31) / 32 * 32)) * sizeof(int) + 255) / 256 * 256;  // >= strip::ctrl_bytes
-  unsigned long long gen = 0;
-  void *sc = scratch(device, st, 3, ctrl + nsg * R * kRecBytes, &gen);
-  if (!sc) return MLPG_HIP_ENOMEM;
-  // The control words must be zero when the kernel starts.  verdict_kernel leaves them zero again, so a launch on
-  // the same scratch whose control area is not larger than the previous one's (everything beyond it held records)
-  // needs no memset -- one dependent launch less per call.  Never trusted while the stream is being captured
-  // into a graph: a replay may follow launches this bookkeeping has not seen.
   bool zero_ctrl = true;
-  {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, std::pair<unsigned long long, size_t>> clean;  // allocation, zero bytes at its head
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
-    std::lock_guard<std::mutex> lk(mu);
-    auto &c = clean[{device, st}];
-    if (!capturing && c.first == gen && ctrl <= c.second) zero_ctrl = false;
-    c = {gen, capturing ? (size_t)0 : ctrl};
-  }
+  void *sc = strip_scratch(st, device, nsg, R, &zero_ctrl);
+  if (!sc) return MLPG_HIP_ENOMEM;
   int rc;
   if (!backward)
     rc = dtype == MLPG_HIP_F32 ? launch_strip_fwd_f32(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl)
@@ -85,10 +100,28 @@ int launch_strip(hipStream_t st, int dtype, int out_dtype, bool backward, const 
     rc = dtype == MLPG_HIP_F32 ? launch_strip_bwd_f32(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl)
                                : launch_strip_bwd_f64(st, out_dtype, p, ws, sc, R, ndg, dgw, zero_ctrl);
   if (rc == kStripNotResident) {
+    strip_scratch_forget(st, device);
     // fewer workgroups can be resident than an utterance has strips (a smaller device, or an occupancy the runtime
     // reports lower than expected): nothing was enqueued; the natural-order kernel has no such requirement
     return launch_generic(st, dtype, out_dtype, backward, p, ws, device);
   }
+  return rc;
+}
+
+// Several streams of one batch in one launch (mlpg_hip_forward_streams): the lanes run over the static dims of all of
+// them, groups of 64.  Returns kStripNotResident (nothing enqueued) if the grid cannot hold an utterance: the caller
+// then runs the streams one by one.
+int launch_strip_multi(hipStream_t st, int dtype, const Problem &p, const WinSet &ws, const StreamMap &sm, int device) {
+  const int R = (p.Tmax + kStripFrames - 1) / kStripFrames;
+  const int ndg = (sm.total + 63) / 64;
+  const int dgw = 64;  // full groups first: 66 dims = 64 + 2, not 33 + 33 (a group costs its frames whatever its lanes)
+  const size_t nsg = (size_t)p.B * ndg;
+  bool zero_ctrl = true;
+  void *sc = strip_scratch(st, device, nsg, R, &zero_ctrl);
+  if (!sc) return MLPG_HIP_ENOMEM;
+  const int rc = dtype == MLPG_HIP_F32 ? launch_strip_multi_f32(st, p, ws, sc, R, ndg, dgw, zero_ctrl, sm)
+                                       : launch_strip_multi_f64(st, p, ws, sc, R, ndg, dgw, zero_ctrl, sm);
+  if (rc == kStripNotResident) strip_scratch_forget(st, device);
   return rc;
 }
 

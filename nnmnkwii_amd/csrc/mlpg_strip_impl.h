@@ -41,6 +41,8 @@
 //
 // Reference semantics as in mlpg_wave_impl.h (paramgen/_mlpg.py:92-199, :202-281).
 #pragma once
+#include <string.h>
+
 #include <mutex>
 #include <vector>
 #include "assemble.h"
@@ -165,7 +167,18 @@ struct Args {
                               // that the kernel holds them in scalar registers)
   int nlists;    // work lists: 8 (system group g belongs to list g % 8, drawn first by the workgroups that run on
                  // XCD g % 8, so that an utterance's strips share one L2) or 1 (small launches)
+  StreamMap sm;  // MULTI kernels only: the streams whose static dims sit side by side on the lanes
 };
+
+// MULTI kernels: the stream a merged static-dim index belongs to (at most 4 streams, begin[] ascending, unused
+// entries = INT_MAX) and the dim's columns there
+struct LaneStream { int sd, din, dstat, dout; };
+__device__ __forceinline__ LaneStream lane_stream(const StreamMap &sm, int d) {
+  const int s_ = (d >= sm.begin[1]) + (d >= sm.begin[2]) + (d >= sm.begin[3]);
+  auto pick = [&](const int (&v)[4]) { return s_ == 0 ? v[0] : s_ == 1 ? v[1] : s_ == 2 ? v[2] : v[3]; };
+  const int dl = d - pick(sm.begin);
+  return {pick(sm.sd), dl + pick(sm.in_col), dl + pick(sm.stat_col), dl + pick(sm.out_col)};
+}
 
 constexpr size_t kLdsStage = (size_t)kStage * kRec * 64 * 8;     // level-3 staging; its head doubles as the level-1 records
 constexpr size_t kLdsPark = (size_t)kPark * 64 * 8;
@@ -499,7 +512,7 @@ template <typename TIN>
 struct RingDepth { static constexpr int value = MLPG_STRIP_RING_F64; };   // frames of loads in flight per wavefront (float64: 36 loads, 18 KB)
 template <>
 struct RingDepth<float> { static constexpr int value = MLPG_STRIP_RING_F32; };  // float32 values take half the registers
-template <typename TIN, bool BWD, int VM, bool EDGE, int NW>
+template <typename TIN, bool BWD, int VM, bool EDGE, int NW, bool MULTI = false>
 __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, __amdgpu_buffer_rsrc_t vrs,
                                                    __amdgpu_buffer_rsrc_t grs, const TIN *__restrict__ vglob,
                                                    unsigned loff, long ldi, long ldg, int sd, int f0, int T, int mw,
@@ -534,14 +547,18 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
     for (int w = 0; w < NW; ++w) {
       int t = f0 + i;
       if (EDGE) t = t < cl[w] ? cl[w] : (t >= ch[w] ? ch[w] - 1 : t);
-      const unsigned soff = (unsigned)t * ldi_bytes + (unsigned)w * win_bytes;
+      // MULTI: `sd` is this LANE's window pitch (the static dim of its stream), so the window offset is part of the
+      // lane offset; otherwise it is wave-uniform and rides in the scalar offset
+      const unsigned soff = MULTI ? (unsigned)t * ldi_bytes : (unsigned)t * ldi_bytes + (unsigned)w * win_bytes;
+      const unsigned voff = MULTI ? loff + (unsigned)w * win_bytes : loff;
 #ifdef MLPG_STRIP_FAKE_LOADS  // timing experiment only: no memory traffic, opaque per-lane values instead
       (void)soff;
+      (void)voff;
       if (VM == MLPG_HIP_VAR_FRAME) { TIN x = (TIN)1.5; asm volatile("" : "+v"(x)); v[w] = x; }
       if (!BWD) { TIN x = (TIN)0.25; asm volatile("" : "+v"(x)); m[w] = x; }
 #else
-      if (VM == MLPG_HIP_VAR_FRAME) v[w] = ld_row<TIN>(vrs, soff, loff);
-      if (!BWD) m[w] = ld_row<TIN>(mrs, soff, loff);
+      if (VM == MLPG_HIP_VAR_FRAME) v[w] = ld_row<TIN>(vrs, soff, voff);
+      if (!BWD) m[w] = ld_row<TIN>(mrs, soff, voff);
 #endif
     }
   };
@@ -919,7 +936,7 @@ __device__ __forceinline__ void backsub(const double (&Pd)[kM], const double (&P
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------
-template <typename TIN, typename TOUT, bool BWD, int VM>
+template <typename TIN, typename TOUT, bool BWD, int VM, bool MULTI = false>
 __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws, Args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   double *lds_rec = (double *)smem;                                  // [kW][kRec][64]   (level 1 -> 2)
@@ -950,16 +967,26 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
   int *cur_ticket = nullptr;
   auto body = [&](const int g, const int r) __attribute__((always_inline)) {
   const int b = g / a.ndg, dg = g - b * a.ndg;
-  const int sd = p.sd, Tmax = p.Tmax;
+  const int Tmax = p.Tmax;
   const long ldi = p.ld_in, ldg = p.ld_gout, ldo = p.ld_out;
   int T = p.lengths ? p.lengths[b] : Tmax;
   T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
   const int Ract = (T + kW * kM - 1) / (kW * kM);  // strips of this utterance that hold live frames
   const bool xwg = MLPG_STRIP_ABLATE ? false : Ract > 1;  // the utterance spans several strips: level 3 runs
   const int d0 = dg * a.dgw;
-  const int nd = sd - d0 < a.dgw ? sd - d0 : a.dgw;
+  const int sd_all = MULTI ? a.sm.total : p.sd;  // MULTI: the lanes run over the static dims of all streams
+  const int nd = sd_all - d0 < a.dgw ? sd_all - d0 : a.dgw;
   const bool lane_ok = lane < nd;
-  const int d = d0 + (lane_ok ? lane : nd - 1);  // idle lanes shadow the group's last dim (never stored)
+  int d = d0 + (lane_ok ? lane : nd - 1);  // idle lanes shadow the group's last dim (never stored)
+  // sd: the pitch between a dim's windows in a row; d: its output (and status) column; din: its window-0 input column
+  int sd = p.sd, din = d, dstat = d;
+  if (MULTI) {
+    const LaneStream ls = lane_stream(a.sm, d);
+    sd = ls.sd;
+    din = ls.din;
+    dstat = ls.dstat;
+    d = ls.dout;
+  }
   const int f0 = (r * kW + wv) * kM;
   const int nw = ws.nw, mw = ws.mw;
 
@@ -979,19 +1006,22 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       }
     }
 #if !defined(MLPG_STRIP_TIMING) && !defined(MLPG_STRIP_TRACE)
-    if (r == 0 && wv == 0 && lane_ok && p.status) p.status[(size_t)b * p.ld_status + d] = 0;  // T == 0
+    if (r == 0 && wv == 0 && lane_ok && p.status) p.status[(size_t)b * p.ld_status + dstat] = 0;  // T == 0
 #endif
     return;
   }
 
   // wave-uniform bases (utterance b, frame 0, first dim of the group) + this lane's byte offset
-  const unsigned loff = (unsigned)(d - d0) * (unsigned)sizeof(TIN);
-  const __amdgpu_buffer_rsrc_t mrs = make_rsrc(BWD ? (const TIN *)p.out : (const TIN *)p.mean + (size_t)b * Tmax * ldi + d0);
+  // (MULTI: the base is column 0 of the parent array and the lane offset the dim's absolute input column)
+  const int dbase = MULTI ? 0 : d0;
+  const unsigned loff = (unsigned)(din - dbase) * (unsigned)sizeof(TIN);
+  const __amdgpu_buffer_rsrc_t mrs = make_rsrc(BWD ? (const TIN *)p.out : (const TIN *)p.mean + (size_t)b * Tmax * ldi + dbase);
   const __amdgpu_buffer_rsrc_t vrs =
-      make_rsrc(VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)b * Tmax * ldi + d0 : (const TIN *)p.out);
+      make_rsrc(VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)b * Tmax * ldi + dbase : (const TIN *)p.out);
   const TIN *vglob = VM == MLPG_HIP_VAR_GLOBAL ? (const TIN *)p.var + d : nullptr;
   const __amdgpu_buffer_rsrc_t grs = make_rsrc(BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * ldg + d0 : (const TIN *)p.out);
   const TIN *vcol = VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)b * Tmax * ldi + d : nullptr;  // backward epilogue
+  (void)vcol;
 #ifdef MLPG_STRIP_TIMING
   const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();  // 100 MHz constant clock, comparable across CUs
 #endif
@@ -1021,8 +1051,8 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
     const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < T - mw;
     if (MLPG_STRIP_STREAM == 1 && nw == 3 && MLPG_STRIP_ABLATE < 2) {
       // the usual three windows: assembly and elimination streamed in frame order
-      if (interior) bad = assemble_eliminate<TIN, BWD, VM, false, 3>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
-      else bad = assemble_eliminate<TIN, BWD, VM, true, 3>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
+      if (interior) bad = assemble_eliminate<TIN, BWD, VM, false, 3, MULTI>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
+      else bad = assemble_eliminate<TIN, BWD, VM, true, 3, MULTI>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
       STRIP_TICK(1);
 #ifdef MLPG_STRIP_TRACE
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1520,7 +1550,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       if (to) __hip_atomic_store(line + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #if !defined(MLPG_STRIP_TIMING) && !defined(MLPG_STRIP_TRACE)
-    if (r == 0 && lane_ok && p.status) p.status[(size_t)b * p.ld_status + d] = 0;
+    if (r == 0 && lane_ok && p.status) p.status[(size_t)b * p.ld_status + dstat] = 0;
 #endif
   }
   const bool zero_out = sys_bad || timed_out;
@@ -1690,7 +1720,11 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
 
   for (int k = 0; k < a.nlists; ++k) {
     const int lst = (xcd + phase * 8 + k) % a.nlists;
-    const int lim = ((a.nsg - lst + a.nlists - 1) / a.nlists) * R;  // items of this list
+    // items of this list.  MULTI: the lists are dealt by UTTERANCE (all its dim groups in one list, a full group and
+    // the narrow last one alternating) -- by system group, the full groups of 66 = 64 + 2 dims would all land in
+    // the even lists and the XCDs behind the odd ones would idle
+    const int lim = MULTI ? ((a.nsg / a.ndg - lst + a.nlists - 1) / a.nlists) * a.ndg * R
+                          : ((a.nsg - lst + a.nlists - 1) / a.nlists) * R;
     int *ticket = a.ctrl + (1 + lst) * kCtrlLine;
     cur_lst = lst;
     cur_lim = lim;
@@ -1714,7 +1748,8 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
       t_prev = (long long)__builtin_readcyclecounter();
       for (int q = 0; q < 16; ++q) tq[q] = 0;
 #endif
-      body((tk / R) * a.nlists + lst, tk % R);
+      if (MULTI) body((((tk / R) / a.ndg) * a.nlists + lst) * a.ndg + (tk / R) % a.ndg, tk % R);
+      else body((tk / R) * a.nlists + lst, tk % R);
       __syncthreads();
     }
     __syncthreads();
@@ -1726,7 +1761,7 @@ __global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws,
 // reference's verdict: status = natural-order first failing pivot (-2 if that scan finds none: the blocked
 // elimination broke down on a numerically singular system; -1 after a time-out) and an all-zero output column,
 // exactly what the other kernels deliver.  It also re-zeroes the control words for the next launch.
-template <typename TIN, typename TOUT, bool BWD>
+template <typename TIN, typename TOUT, bool BWD, bool MULTI = false>
 __global__ void __launch_bounds__(256) verdict_kernel(const Problem p, const WinSet ws, const Args a) {
   const int lane = threadIdx.x & 63;
   const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1743,18 +1778,36 @@ __global__ void __launch_bounds__(256) verdict_kernel(const Problem p, const Win
   if (m == 0ull) return;
   const int b = g / a.ndg, dg = g - b * a.ndg;
   const int d0 = dg * a.dgw;
-  const int nd = p.sd - d0 < a.dgw ? p.sd - d0 : a.dgw;
+  const int sd_all = MULTI ? a.sm.total : p.sd;
+  const int nd = sd_all - d0 < a.dgw ? sd_all - d0 : a.dgw;
   if (lane >= nd || !((m >> lane) & 1ull)) return;
-  const int d = d0 + lane, Tmax = p.Tmax;
+  int d = d0 + lane, dstat = d;
+  const int Tmax = p.Tmax;
   int T = p.lengths ? p.lengths[b] : Tmax;
   T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
   int status = -1;
-  if (!timed_out) {
+  if (MULTI) {
+    // the dim's own stream as a problem of its own: column slices of the parent arrays
+    const LaneStream ls = lane_stream(a.sm, d);
+    Problem q = p;
+    q.sd = ls.sd;
+    q.D = ws.nw * ls.sd;
+    // make_view addresses column (w * sd + dloc) of q.mean: shift the bases so that dloc = 0 is this dim
+    q.mean = (const TIN *)p.mean + ls.din;
+    q.var = p.var ? (const void *)((const TIN *)p.var + ls.din) : nullptr;
+    if (!timed_out) {
+      const SysView<TIN, BWD> view = make_view<TIN, BWD>(q, ws, b, 0, T);
+      status = first_bad_pivot<2, TIN, BWD>(view, ws);
+      if (status == 0) status = -2;
+    }
+    dstat = ls.dstat;
+    d = ls.dout;
+  } else if (!timed_out) {
     const SysView<TIN, BWD> view = make_view<TIN, BWD>(p, ws, b, d, T);
     status = first_bad_pivot<2, TIN, BWD>(view, ws);
     if (status == 0) status = -2;
   }
-  if (p.status) p.status[(size_t)b * p.ld_status + d] = status;
+  if (p.status) p.status[(size_t)b * p.ld_status + dstat] = status;
   TOUT *out_b = (TOUT *)p.out + (size_t)b * Tmax * p.ld_out;
   for (int t = 0; t < Tmax; ++t) {
     if (!BWD) out_b[(size_t)t * p.ld_out + d] = (TOUT)0;
@@ -1796,10 +1849,12 @@ inline int resident_grid(const void *kern, int threads, size_t lds, int *out) {
   return 0;
 }
 
-template <typename TIN, typename TOUT, bool BWD>
-int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, int ndg, int dgw,
-             bool zero_ctrl) {
+template <typename TIN, typename TOUT, bool BWD, bool MULTI>
+int launch_impl(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, int ndg, int dgw,
+                bool zero_ctrl, const StreamMap *smap) {
   Args a;
+  memset(&a.sm, 0, sizeof(a.sm));
+  if (MULTI) a.sm = *smap;
   const int nsg = p.B * ndg;
   a.ctrl = (int *)scratch_base;
   a.rec = (double *)((char *)scratch_base + ctrl_bytes(nsg, R));
@@ -1831,15 +1886,31 @@ int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_b
     const long grid = nitems < resident ? nitems : resident;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kW * 64), kLdsBytes, st, p, ws, a);
     MLPG_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL((verdict_kernel<TIN, TOUT, BWD>), dim3((unsigned)((nsg + 3) / 4)), dim3(256), 0, st, p, ws, a);
+    hipLaunchKernelGGL((verdict_kernel<TIN, TOUT, BWD, MULTI>), dim3((unsigned)((nsg + 3) / 4)), dim3(256), 0, st, p, ws, a);
     MLPG_HIP_CHECK(hipGetLastError());
     return 0;
   };
-  switch (p.var_mode) {
-    case MLPG_HIP_VAR_FRAME: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_FRAME>);
-    case MLPG_HIP_VAR_GLOBAL: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_GLOBAL>);
-    default: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_UNIT>);
+  if constexpr (MULTI) {
+    // several streams side by side on the lanes: forward, per-frame variances, three windows (the caller checked)
+    return go(strip_kernel<TIN, TOUT, false, MLPG_HIP_VAR_FRAME, true>);
+  } else {
+    switch (p.var_mode) {
+      case MLPG_HIP_VAR_FRAME: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_FRAME>);
+      case MLPG_HIP_VAR_GLOBAL: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_GLOBAL>);
+      default: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_UNIT>);
+    }
   }
+}
+
+template <typename TIN, typename TOUT, bool BWD>
+int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, int ndg, int dgw,
+             bool zero_ctrl) {
+  return launch_impl<TIN, TOUT, BWD, false>(st, p, ws, scratch_base, R, ndg, dgw, zero_ctrl, nullptr);
+}
+template <typename TIN, typename TOUT>
+int launch_multi_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, int ndg, int dgw,
+                   bool zero_ctrl, const StreamMap &smap) {
+  return launch_impl<TIN, TOUT, false, true>(st, p, ws, scratch_base, R, ndg, dgw, zero_ctrl, &smap);
 }
 
 }  // namespace strip

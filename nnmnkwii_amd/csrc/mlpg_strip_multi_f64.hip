@@ -1,0 +1,7 @@
+// strip MLPG kernels: forward pass of several streams in one launch, double
+#include "mlpg_strip_impl.h"
+namespace mlpg {
+int launch_strip_multi_f64(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl, const StreamMap &sm) {
+  return strip::launch_multi_t<double, double>(st, p, ws, scratch, R, ndg, dgw, zero_ctrl, sm);
+}
+}  // namespace mlpg

@@ -409,6 +409,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
   const int b = (slot / ngrp) * 8 + xcd, dgrp = slot % ngrp;
   if (b >= p.B) return;
   const int sd = p.sd, Tmax = p.Tmax;
+  const int wp = (!BWD && p.pitch) ? p.pitch : sd;  // columns between a dim's windows (a piece of a stream: > sd)
   const int ldi = (int)p.ld_in, ldg = (int)p.ld_gout, ldo = (int)p.ld_out;  // row strides (elements)
   const int d0 = dgrp * kG, d = d0 + wv;
   const int gvalid = sd - d0 < kG ? sd - d0 : kG;
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
     const double *cw = ws.c + ws.off[w];
     const double cm = l ? cw[0] : 0.0, c0 = cw[l], cp = u ? cw[l + 1] : 0.0;  // W[t,t-1], W[t,t], W[t,t+1]
     double tau_glob = 1.0;
-    if (VM == MLPG_HIP_VAR_GLOBAL && sys_valid) tau_glob = tau_of<TIN>(var_b[w * sd + d]);
+    if (VM == MLPG_HIP_VAR_GLOBAL && sys_valid) tau_glob = tau_of<TIN>(var_b[w * wp + d]);
     const double c00 = c0 * c0, cpp = cp * cp, cmm = cm * cm, cp0 = cp * c0, c0m = c0 * cm, cpm = cp * cm;
     const unsigned long long live = w ? liveD : liveS;
 
@@ -507,14 +508,14 @@ __global__ __launch_bounds__(kG * 64, MINW) void wave_kernel(Problem p, WinSet w
                         // the transfer runs behind this window's arithmetic
       MLPG_TICK(2);
       if (w + 1 < nw && MLPG_WAVE_ABLATE != 2) {
-        if (kVarTile) load_tile_dma<M, TIN>(tileV, var_b + (w + 1) * sd + d0, ldi, T, gvalid, wv, lane);
-        if (!BWD) load_tile_dma<M, TIN>(tileM, mean_b + (w + 1) * sd + d0, ldi, T, gvalid, wv, lane);
+        if (kVarTile) load_tile_dma<M, TIN>(tileV, var_b + (w + 1) * wp + d0, ldi, T, gvalid, wv, lane);
+        if (!BWD) load_tile_dma<M, TIN>(tileM, mean_b + (w + 1) * wp + d0, ldi, T, gvalid, wv, lane);
       }
       MLPG_TICK(3);
     } else {
       if (MLPG_WAVE_ABLATE != 2) {
-        if (kVarTile) load_tile_regs<M, TIN>(tileV, var_b + w * sd + d0, ldi, T, gvalid, tid);
-        if (!BWD) load_tile_regs<M, TIN>(tileM, mean_b + w * sd + d0, ldi, T, gvalid, tid);
+        if (kVarTile) load_tile_regs<M, TIN>(tileV, var_b + w * wp + d0, ldi, T, gvalid, tid);
+        if (!BWD) load_tile_regs<M, TIN>(tileM, mean_b + w * wp + d0, ldi, T, gvalid, tid);
       }
       __syncthreads();
       if (kVarTile) {
@@ -672,7 +673,7 @@ template <typename TIN>
 bool dma_ok(const Problem &p) {
   constexpr int epl = 16 / (int)sizeof(TIN);
   if (MLPG_WAVE_DMA == 0) return false;
-  if (kG % epl || p.ld_in % epl || p.ld_gout % epl || p.sd % epl) return false;
+  if (kG % epl || p.ld_in % epl || p.ld_gout % epl || p.sd % epl || p.pitch % epl) return false;
   auto al = [](const void *q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
   return al(p.mean) && (p.var_mode != MLPG_HIP_VAR_FRAME || al(p.var)) && al(p.grad_out);
 }

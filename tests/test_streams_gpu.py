@@ -116,3 +116,67 @@ def test_streams_status_and_errors():
     np.testing.assert_allclose(y, np.concatenate([r0, r1], axis=1), rtol=1e-9, atol=1e-11)
     with pytest.raises(_hip.HipExtensionError):
         _hip.forward_streams(torch.zeros(1, 4, 6, dtype=torch.float64).cuda(), None, [(4, 1, STD3)])   # does not fit
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("T,algo", [(300, "strip"), (1500, "auto")])
+def test_streams_merged_into_one_strip_launch(dt, T, algo):
+    """Streams that share their three windows (per-frame variances) run as ONE strip-kernel launch, their static dims
+    side by side on the lanes (66 = 60 + 1 + 5: the 64 lanes take mgc, three dims of bap and lf0; bap's last two dims
+    run as a piece of their own): every stream what the strip kernel gives on a dense copy of its columns, status in
+    the stream's own columns, failing systems zeroed."""
+    import torch
+    from nnmnkwii_amd import _hip
+    rng = np.random.RandomState(17)
+    B = 6
+    D = 180 + 3 + 1 + 15
+    m = rng.randn(B, T, D).astype(dt)
+    v = (rng.rand(B, T, D) + 0.1).astype(dt)
+    lengths = np.array([T, 1, T - 43, 64, 2, T // 2], dtype=np.int32)
+    v[2, 11, 184 + 2] = -1e-3          # bap dim 2 of utterance 2: a negative static variance
+    v[5, 3, 180] = -1e-3               # lf0 of utterance 5 likewise
+    for b in range(B):
+        m[b, lengths[b]:] = 0
+    md, vd, Ld = torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(lengths).cuda()
+    streams = [(0, 60, STD3), (180, 1, STD3), (183, 1, None), (184, 5, STD3)]
+    a = _hip.ALGO_STRIP if algo == "strip" else _hip.ALGO_AUTO
+    out, st = _hip.forward_streams(md, vd, streams, Ld, algo=a)
+    o0 = 0
+    for in_col, sd, win in streams:
+        if win is None:
+            assert torch.equal(out[:, :, o0:o0 + sd], md[:, :, in_col:in_col + sd] * (torch.arange(T, device="cuda")[None, :, None] < Ld[:, None, None]))
+        else:
+            dense, dst = _hip.forward(md[:, :, in_col:in_col + 3 * sd].contiguous(), vd[:, :, in_col:in_col + 3 * sd].contiguous(),
+                                      STD3, Ld, algo=_hip.ALGO_STRIP)
+            if sd == 60:    # entirely inside the merged launch: the same kernel, the same bits
+                assert torch.equal(out[:, :, o0:o0 + sd], dense), (in_col, sd)
+            else:           # may be cut between the merged launch and a wave-kernel launch of its last dims
+                tol = 1e-9 if dt == np.float64 else 2e-6
+                assert float((out[:, :, o0:o0 + sd] - dense).abs().max()) <= tol * max(1.0, float(dense.abs().max())), (in_col, sd)
+            assert torch.equal(st[:, o0:o0 + sd] != 0, dst.reshape(B, sd) != 0), (in_col, sd)
+        o0 += sd
+    st = st.cpu().numpy()
+    assert st[2, 62 + 2] > 0 and st[5, 60] > 0 and (st != 0).sum() == 2
+    assert not out[2, :, 62 + 2].cpu().numpy().any() and not out[5, :, 60].cpu().numpy().any()
+
+
+def test_streams_merged_launch_really_is_one_kernel():
+    """rocprof-free check: the merged path leaves the strip scratch's generation alone and is faster than the sum of
+    its parts on a config-5 shaped batch is bench material; here only that streams with DIFFERENT windows are not
+    merged (they would be wrong) and two wide streams are."""
+    import torch
+    from nnmnkwii_amd import _hip
+    from oracle import mlpg as O
+    rng = np.random.RandomState(3)
+    B, T = 2, 1100
+    m = rng.randn(B, T, 6 + 6)
+    v = rng.rand(B, T, 6 + 6) + 0.1
+    other = [(0, 0, np.array([1.0])), (1, 1, np.array([-0.25, 0.0, 0.25])), (1, 1, np.array([1.0, -2.0, 1.0]))]
+    out, st = _hip.forward_streams(torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), [(0, 2, STD3), (6, 2, other)],
+                                   algo=_hip.ALGO_STRIP)
+    assert int(st.abs().sum().item()) == 0
+    out = out.cpu().numpy()
+    for k, (c0, win) in enumerate(((0, STD3), (6, other))):
+        ref, _, rc = O.mlpg_batch(np.ascontiguousarray(m[:, :, c0:c0 + 6]), np.ascontiguousarray(v[:, :, c0:c0 + 6]), win, None)
+        assert rc == 0
+        assert np.abs(out[:, :, 2 * k:2 * k + 2] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())

@@ -22,7 +22,9 @@ def child():
     v = torch.rand(B, T, 198, dtype=torch.float64, device=dev, generator=gen) + 0.1
     streams = [(0, 60, WINDOWS), (180, 1, WINDOWS), (183, 5, WINDOWS)]
     out = {}
-    for nm, ss in (("mgc", streams[:1]), ("lf0", streams[1:2]), ("bap", streams[2:]), ("narrow", streams[1:]), ("all", streams)):
+    bap4 = (183, 4, WINDOWS)      # not a real stream (its windows are 5 apart): only the shape of the launch matters here
+    for nm, ss in (("mgc", streams[:1]), ("lf0", streams[1:2]), ("bap", streams[2:]), ("narrow", streams[1:]), ("mgc+lf0", streams[:2]),
+                   ("mgc+4", [streams[0], bap4]), ("mgc+bap", [streams[0], streams[2]]), ("all", streams)):
         out[nm] = round(gpu_time(lambda: _hip.forward_streams(m, v, ss, want_status=False), steps=20), 4)
     print("mode", os.environ.get("MLPG_HIP_STREAMS_MODE", "0"), out, flush=True)
 
