@@ -527,7 +527,7 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
     }
   }
   int widest = -1;
-  for (int k = 0; k < num_streams; ++k)
+  for (int k = 0; k < num_streams && !have_merged; ++k)  // (with a merged launch, that one takes the caller's stream)
     if (streams_h[k].static_dim > 0 && !merged_flag[k] &&
         (widest < 0 || streams_h[k].static_dim * (streams_h[k].num_windows + 1) >
                            streams_h[widest].static_dim * (streams_h[widest].num_windows + 1)))
@@ -542,7 +542,6 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
   // launched last: the narrow streams' kernels then only wait for what preceded the call, not for the wide kernel.
   int n_narrow = 0;
   for (int k = 0; k < num_streams; ++k) n_narrow += streams_h[k].static_dim > 0 && k != widest && !merged_flag[k];
-  if (have_merged && widest >= 0) ++n_narrow;  // the merged launch takes the caller's stream first
   if (side && n_narrow > 0) MLPG_HIP_CHECK(hipEventRecord(side->fork, main_st));
   auto join_side = [&]() -> int {  // also on the error paths: an unjoined side stream would break a graph capture
     for (int q = 0; q < nside; ++q) {

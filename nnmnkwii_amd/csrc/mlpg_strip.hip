@@ -15,7 +15,10 @@ int launch_strip_multi_f64(hipStream_t st, const Problem &p, const WinSet &ws, v
 int launch_strip_multi_f32(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl, const StreamMap &sm);
 
 namespace {
-constexpr int kStripFrames = 64;   // strip::kW * strip::kM
+#ifndef MLPG_STRIP_W
+#define MLPG_STRIP_W 4
+#endif
+constexpr int kStripFrames = 16 * MLPG_STRIP_W;   // strip::kW * strip::kM
 constexpr int kMaxStrips = 256;    // strips of one utterance must be able to be resident together (2 per CU)
 constexpr int kRecBytes = 14 * 64 * 8;
 constexpr int kStripNotResident = -1000;  // = strip::kNotResident (mlpg_strip_impl.h)

@@ -64,11 +64,14 @@
 namespace mlpg {
 namespace strip {
 
-constexpr int kW = 4;        // chunks (wavefronts) per strip (workgroup)
+#ifndef MLPG_STRIP_W
+#define MLPG_STRIP_W 4   // 8: 128-frame strips, one workgroup of 8 wavefronts per CU (experiment; mlpg_strip.hip must match)
+#endif
+constexpr int kW = MLPG_STRIP_W;  // chunks (wavefronts) per strip (workgroup)
 constexpr int kM = 16;       // frames per chunk
 constexpr int kN = kM - 2;   // interior frames of a chunk; frames kN, kN+1 are its separator
 constexpr int kRec = 14;     // doubles per lane in a level-1 / level-2 record
-constexpr int kStage = 6;    // records of level 3 staged in LDS per batch
+constexpr int kStage = kW > 6 ? 8 : 6;  // records of level 3 staged in LDS per batch (even, >= kW)
 constexpr int kPark = 2 * kN;  // doubles per lane that wavefront 0 parks in LDS while it runs levels 2 and 3
 constexpr int kFac = 10;     // doubles per lane kept per eliminated separator of level 2
 constexpr int kSpinLimit = 1 << 20;
@@ -187,7 +190,7 @@ constexpr size_t kLdsU = (size_t)(kW + 1) * 2 * 64 * 8;
 constexpr size_t kLdsMisc = 64 + kW * 256;  // control words + a throw-away line per wavefront (MLPG_STRIP_PREFETCH)
 constexpr size_t kLdsBytes = kLdsStage + kLdsPark + kLdsFac + kLdsU + kLdsMisc;
 static_assert(kW * kRec <= kStage * kRec, "level-1 records must fit the staging area");
-static_assert(kLdsBytes <= 80 * 1024, "two workgroups per CU");
+static_assert(kLdsBytes <= (kW <= 4 ? 80 : 160) * 1024, "two workgroups of 4 wavefronts per CU, or one of 8");
 
 __device__ __forceinline__ double fast_rcp(double d) {
   double x = __builtin_amdgcn_rcp(d);
@@ -937,7 +940,7 @@ __device__ __forceinline__ void backsub(const double (&Pd)[kM], const double (&P
 
 // ---- the kernel ---------------------------------------------------------------------------------
 template <typename TIN, typename TOUT, bool BWD, int VM, bool MULTI = false>
-__global__ __launch_bounds__(kW * 64, 2) void strip_kernel(Problem p, WinSet ws, Args a) {
+__global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem p, WinSet ws, Args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   double *lds_rec = (double *)smem;                                  // [kW][kRec][64]   (level 1 -> 2)
   double *lds_stage = (double *)smem;                                // [kStage][kRec][64] (level 3), same bytes
