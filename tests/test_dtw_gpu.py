@@ -190,3 +190,33 @@ def test_against_the_real_fastdtw_package_when_installed():
             pi, pj, pl, cost = _hip.fastdtw_l2(X, Y, lx, ly, radius)
             n = int(pl[0])
             assert list(zip(pi[0, :n].tolist(), pj[0, :n].tolist())) == [tuple(p) for p in p_ref]
+
+
+@pytest.mark.parametrize("radius", [1, 3])   # radius 3: rows of ~26 cells, no pair fits the optimistic back-pointer capacity
+def test_many_pairs_take_the_two_launch_form_and_wide_windows_are_retried(radius):
+    """More than 512 pairs: the first launch runs 256 threads per pair with optimistic LDS capacities (four pairs per
+    CU), pairs whose windows do not fit are marked and run again by a second launch with the proven bounds.  The
+    batch mixes ordinary pairs with pairs whose warping path has long horizontal and vertical runs (rows hundreds of
+    cells wide at every level): every path equals the oracle's, whichever launch produced it."""
+    rng = np.random.RandomState(77)
+    N, D = 640, 3
+    pairs = []
+    for n in range(N):
+        if n % 40 == 7:
+            # a step function against a ramp: the path runs along the axes
+            tx, ty = int(rng.randint(300, 420)), int(rng.randint(300, 420))
+            x = np.zeros((tx, D)); x[tx // 2:] = 5.0
+            x += 1e-3 * rng.randn(tx, D)
+            y = np.linspace(0.0, 5.0, ty)[:, None] * np.ones((1, D)) + 1e-3 * rng.randn(ty, D)
+        else:
+            tx, ty = int(rng.randint(40, 160)), int(rng.randint(40, 160))
+            x, y = _tracks(rng, tx, D), _tracks(rng, ty, D)
+        pairs.append((x, y))
+    pi, pj, pl, cost = _run_pairs(pairs, radius)
+    assert (pl > 0).all()
+    for n in list(range(0, N, 11)) + [n for n in range(N) if n % 40 == 7]:
+        x, y = pairs[n]
+        d, path = OD.fastdtw(x, y, radius)
+        assert pl[n] == len(path), n
+        assert np.array_equal(pi[n, :pl[n]], path[:, 0]) and np.array_equal(pj[n, :pl[n]], path[:, 1]), n
+        assert abs(cost[n] - d) <= 1e-12 * max(d, 1e-300), n

@@ -119,7 +119,7 @@ def test_streams_status_and_errors():
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
-@pytest.mark.parametrize("T,algo", [(300, "strip"), (1500, "auto")])
+@pytest.mark.parametrize("T,algo", [(300, "strip"), (1500, "auto"), (2100, "auto")])   # 2100: the piece runs on the natural-order kernel
 def test_streams_merged_into_one_strip_launch(dt, T, algo):
     """Streams that share their three windows (per-frame variances) run as ONE strip-kernel launch, their static dims
     side by side on the lanes (66 = 60 + 1 + 5: the 64 lanes take mgc, three dims of bap and lf0; bap's last two dims
