@@ -491,7 +491,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "peak_measured": copy_gbs,
-                "peak_measured_kernel": "mlpg_hip_stream_copy, 512 MiB -> 512 MiB, (read + written bytes) / best of 5 x 10 launches, same run",
+                "peak_measured_kernel": "mlpg_hip_stream_copy, 512 MiB -> 512 MiB, (read + written bytes) / best of 16 x 50 launches, same run",
                 "frac_of_measured": (achieved / copy_gbs) if (achieved and copy_gbs) else None,
                 "traffic": measured_traffic(B, T, sd, args.algo),
                 "traffic_unit": "bytes/launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE; taken from the committed rocprofv3 pass "
