@@ -13,6 +13,10 @@
 // launches and a dozen framework kernels (0.26 ms of host time per step; 0.10 ms as a captured graph).
 #include "mlpg_wave_impl.h"
 
+#ifndef MLPG_FUSED_KEEP
+#define MLPG_FUSED_KEEP 1   // 0: the backward solve re-forms and re-factorises the matrix (round 3's first version)
+#endif
+
 namespace mlpg {
 namespace {
 
@@ -148,7 +152,11 @@ __global__ __launch_bounds__(kG * 64, 2) void wave_fused_kernel(Problem p, WinSe
     }
     fix_edges();
     double *parkA = (double *)tileA + wv * RL::TPAD + lane * (M + kSkew), *parkB = (double *)tileB + wv * RL::TPAD + lane * (M + kSkew);
-    bool bad = solve_chunk<M, kPark>(Pd, P1, P2, rhs, lane, parkA, parkB);
+    // up to 8 frames per lane the cyclic reduction's blocks stay in registers and the backward solve is a second
+    // right-hand side for the factorised matrix (no re-forming, no matrix arithmetic, a fifth of the shuffles)
+    constexpr bool kKeep = (M <= 8) && !kPark && MLPG_FUSED_KEEP;
+    PcrKeep keep;
+    bool bad = solve_chunk<M, kPark, kKeep>(Pd, P1, P2, rhs, lane, parkA, parkB, &keep);
     int status = 0;
     if ((__ballot(bad) != 0ull) && sys_valid) {  // (cannot happen for window sets with a static window; kept for the contract)
       if (lane == 0) {
@@ -186,17 +194,22 @@ __global__ __launch_bounds__(kG * 64, 2) void wave_fused_kernel(Problem p, WinSe
         rhs[i] = fa.scale * e;
       }
     }
-    // ---- backward: z = P^-1 g with the same matrix, re-formed from the windows alone ----
+    // ---- backward: z = P^-1 g with the same matrix ----
+    if (kKeep) {
+      solve_again<M>(Pd, P1, P2, rhs, lane, keep);
+    } else {
+      // re-formed from the windows alone and factorised again
 #pragma unroll
-    for (int i = 0; i < M; ++i) Pd[i] = P1[i] = P2[i] = 0.0;
-    {
-      const TIN none[M + 2] = {};
-      for (int w = 0; w < nw; ++w) accumulate(w, false, none);
+      for (int i = 0; i < M; ++i) Pd[i] = P1[i] = P2[i] = 0.0;
+      {
+        const TIN none[M + 2] = {};
+        for (int w = 0; w < nw; ++w) accumulate(w, false, none);
+      }
+      fix_edges();
+      __syncthreads();  // the tiles double as the solver's parking area
+      bad = solve_chunk<M, kPark>(Pd, P1, P2, rhs, lane, parkA, parkB);
+      (void)bad;
     }
-    fix_edges();
-    __syncthreads();  // the tiles double as the solver's parking area
-    bad = solve_chunk<M, kPark>(Pd, P1, P2, rhs, lane, parkA, parkB);
-    (void)bad;
     // grad[t, w*sd+d] = tau_w[t] * (cm z[t-1] + c0 z[t] + cp z[t+1])   (paramgen/_mlpg.py:202-281, unit variances)
     double xl = __shfl_up(rhs[M - 1], 1), xr = __shfl_down(rhs[0], 1);
     if (lane == 0) xl = 0.0;

@@ -203,9 +203,17 @@ __device__ __forceinline__ void store_tile(const TOUT *__restrict__ tile, TOUT *
 // reduction across the lanes, interior back-substitution.  On return rhs[] holds the solution
 // of the chunk.  Returns true if a non-positive pivot was met anywhere (then the matrix is not
 // positive definite).  parkA/parkB: per-lane LDS scratch of M-2 doubles each (PARK only).
-template <int M, bool PARK>
+// What a second solve with the SAME matrix needs from the cyclic reduction: per step the inverse of the diagonal block
+// and the coupling block as they stood when the step began, and the last step's inverse.  (The interior multipliers
+// stay in Pd/P1/P2.)  46 doubles per lane.
+struct PcrKeep {
+  double I11[6], I12[6], I22[6], L11[6], L12[6], L21[6], L22[6];
+  double F11, F12, F22, Fi;  // the last block (D22, D12, D11) and 1 / det
+};
+
+template <int M, bool PARK, bool KEEP = false>
 __device__ __forceinline__ bool solve_chunk(double (&Pd)[M], double (&P1)[M], double (&P2)[M], double (&rhs)[M],
-                                            int lane, double *parkA, double *parkB) {
+                                            int lane, double *parkA, double *parkB, PcrKeep *keep = nullptr) {
   constexpr int n = M - 2;  // interior frames per lane; frames n, n+1 form the lane's separator
   // coupling of this chunk's first two frames to the previous lane's separator (frames f0-2, f0-1)
   double ca = __shfl_up(P2[M - 2], 1);  // P[f0,   f0-2]
@@ -288,6 +296,12 @@ __device__ __forceinline__ bool solve_chunk(double (&Pd)[M], double (&P1)[M], do
     bad |= (D11 <= 0.0) | (det <= 0.0);
     const double idet = fast_rcp(det);
     const double I11 = D22 * idet, I12 = -D12 * idet, I22 = D11 * idet;
+    if (KEEP) {
+      constexpr int kLog[33] = {0, 0, 1, 0, 2, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 5};
+      const int k = kLog[s];
+      keep->I11[k] = I11; keep->I12[k] = I12; keep->I22[k] = I22;
+      keep->L11[k] = L11; keep->L12[k] = L12; keep->L21[k] = L21; keep->L22[k] = L22;
+    }
     // G_j = D_j^-1 F_j and H_j = D_j^-1 L_j are what the neighbours need from row j
     const double G1 = I11 * F1 + I12 * F2, G2 = I12 * F1 + I22 * F2;
     const double H11 = I11 * L11 + I12 * L21, H12 = I11 * L12 + I12 * L22;
@@ -347,6 +361,7 @@ __device__ __forceinline__ bool solve_chunk(double (&Pd)[M], double (&P1)[M], do
     const double idet = fast_rcp(det);
     u1 = (D22 * F1 - D12 * F2) * idet;
     u2 = (D11 * F2 - D12 * F1) * idet;
+    if (KEEP) { keep->F11 = D22; keep->F12 = D12; keep->F22 = D11; keep->Fi = idet; }
   }
   double ul1 = __shfl_up(u1, 1), ul2 = __shfl_up(u2, 1);
   if (lane == 0) ul1 = ul2 = 0.0;
@@ -386,6 +401,97 @@ __device__ __forceinline__ bool solve_chunk(double (&Pd)[M], double (&P1)[M], do
     rhs[n + 1] = u2;
   }
   return bad;
+}
+
+// ---- a further right-hand side for the matrix solve_chunk<M, false, true> has just factorised ---------------
+// Pd/P1/P2[0..M-2) hold 1/d, l1, l2 of the interior, Pd/P1/P2's separator couplings are untouched, `keep` holds the
+// cyclic reduction's blocks.  Every operation on the right-hand side is the one solve_chunk performs, in its order
+// (so the result equals a full second solve bit for bit) -- none of the matrix arithmetic, a fifth of the cross-lane
+// traffic.  On return rhs[] holds the solution.
+template <int M>
+__device__ __forceinline__ void solve_again(const double (&Pd)[M], const double (&P1)[M], const double (&P2)[M],
+                                            double (&rhs)[M], int lane, const PcrKeep &keep) {
+  constexpr int n = M - 2;
+  double ca = __shfl_up(P2[M - 2], 1);
+  double cb = __shfl_up(P1[M - 1], 1);
+  double cc = __shfl_up(P2[M - 1], 1);
+  if (lane == 0) ca = cb = cc = 0.0;
+  double h0 = 0.0, h1 = 0.0;
+  double g1 = 0.0, g2 = 0.0, va1 = 0.0, va2 = 0.0, vb1 = 0.0, vb2 = 0.0;
+  double l1p = 0.0, l2p = 0.0, l2pp = 0.0;
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    const double dinv = Pd[i], l1 = P1[i], l2 = P2[i];
+    const double gi = rhs[i] - l1p * g1 - l2pp * g2;
+    const double ba = (i == 0) ? ca : 0.0;
+    const double bb = (i == 0) ? cb : ((i == 1) ? cc : 0.0);
+    const double va = ba - l1p * va1 - l2pp * va2;
+    const double vb = bb - l1p * vb1 - l2pp * vb2;
+    const double wa = va * dinv, wb = vb * dinv;
+    h0 += wa * gi;
+    h1 += wb * gi;
+    rhs[i] = gi;
+    g2 = g1; g1 = gi;
+    va2 = va1; va1 = va;
+    vb2 = vb1; vb1 = vb;
+    l2pp = l2p; l2p = l2; l1p = l1;
+  }
+  rhs[n] -= l1p * g1 + l2pp * g2;
+  rhs[n + 1] -= l2p * g1;
+  double F1 = rhs[n], F2 = rhs[n + 1];
+  {
+    const double nh0 = __shfl_down(h0, 1), nh1 = __shfl_down(h1, 1);
+    if (lane < 63) { F1 -= nh0; F2 -= nh1; }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int s = 1 << k;
+    const double G1 = keep.I11[k] * F1 + keep.I12[k] * F2, G2 = keep.I12[k] * F1 + keep.I22[k] * F2;
+    const bool hasm = lane - s >= 0, hasp = lane + s < 64;
+    {
+      double mG1 = __shfl_up(G1, s), mG2 = __shfl_up(G2, s);
+      if (!hasm) { mG1 = mG2 = 0.0; }
+      F1 -= keep.L11[k] * mG1 + keep.L12[k] * mG2;
+      F2 -= keep.L21[k] * mG1 + keep.L22[k] * mG2;
+    }
+    {
+      double pL11 = __shfl_down(keep.L11[k], s), pL12 = __shfl_down(keep.L12[k], s), pL21 = __shfl_down(keep.L21[k], s), pL22 = __shfl_down(keep.L22[k], s);
+      double pG1 = __shfl_down(G1, s), pG2 = __shfl_down(G2, s);
+      if (!hasp) { pL11 = pL12 = pL21 = pL22 = 0.0; pG1 = pG2 = 0.0; }
+      F1 -= pL11 * pG1 + pL21 * pG2;
+      F2 -= pL12 * pG1 + pL22 * pG2;
+    }
+  }
+  const double u1 = (keep.F11 * F1 - keep.F12 * F2) * keep.Fi;
+  const double u2 = (keep.F22 * F2 - keep.F12 * F1) * keep.Fi;
+  double ul1 = __shfl_up(u1, 1), ul2 = __shfl_up(u2, 1);
+  if (lane == 0) ul1 = ul2 = 0.0;
+  {
+    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const double ba = (i == 0) ? ca : 0.0;
+      const double bb = (i == 0) ? cb : ((i == 1) ? cc : 0.0);
+      const double va = ba - q1 * a1 - q3 * a2;
+      const double vb = bb - q1 * b1 - q3 * b2;
+      rhs[i] -= va * ul1 + vb * ul2;
+      a2 = a1; a1 = va;
+      b2 = b1; b1 = vb;
+      q3 = q2; q2 = P2[i]; q1 = P1[i];
+    }
+  }
+  {
+    double x1 = u1, x2 = u2;
+#pragma unroll
+    for (int i = n - 1; i >= 0; --i) {
+      const double xi = rhs[i] * Pd[i] - P1[i] * x1 - P2[i] * x2;
+      rhs[i] = xi;
+      x2 = x1;
+      x1 = xi;
+    }
+    rhs[n] = u1;
+    rhs[n + 1] = u2;
+  }
 }
 
 // ---- the kernel ------------------------------------------------------------------------------
