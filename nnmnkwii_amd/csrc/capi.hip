@@ -565,27 +565,6 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
     }
     return 0;
   };
-  // MLPG_HIP_STREAMS_MODE (measurement switch): 0 narrow streams first on side streams, widest last (default);
-  // 1 everything on the caller's stream; 2 widest first, narrow streams behind it on ONE side stream
-  static const int mode = [] { const char *e = getenv("MLPG_HIP_STREAMS_MODE"); return e ? atoi(e) : 0; }();
-  if (mode == 1) side = nullptr;
-  if (mode == 2 && widest >= 0 && !have_merged) {
-    if (int rc = run_stream(widest, main_st)) return rc;
-    bool forked = false;
-    for (int k = 0; k < num_streams; ++k) {
-      if (streams_h[k].static_dim <= 0 || k == widest) continue;
-      hipStream_t st = main_st;
-      if (side) {
-        st = side->st[0];
-        if (!forked) {
-          if (hipStreamWaitEvent(st, side->fork, 0) != hipSuccess) { (void)hipGetLastError(); st = main_st; side = nullptr; }
-          else { forked = true; nside = 1; }
-        }
-      }
-      if (int rc = run_stream(k, st)) { (void)join_side(); return rc; }
-    }
-    return join_side();
-  }
   for (int k = 0; k < num_streams; ++k) {
     if (streams_h[k].static_dim <= 0 || k == widest || merged_flag[k]) continue;
     hipStream_t st = main_st;

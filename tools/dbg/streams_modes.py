@@ -1,7 +1,5 @@
-"""config 5 in place from one (B, T, 198) batch: every stream alone and the one-call form, per MLPG_HIP_STREAMS_MODE.
-
-    python tools/dbg/streams_modes.py            (spawns one child per mode: the switch is read once per process)
-"""
+"""config 5 in place from one (B, T, 198) batch: every stream alone, combinations of them and the one-call form
+(mlpg_hip_forward_streams merges streams that share their windows into one strip launch: DESIGN.md K1m)."""
 import os
 import subprocess
 import sys
@@ -26,13 +24,11 @@ def child():
     for nm, ss in (("mgc", streams[:1]), ("lf0", streams[1:2]), ("bap", streams[2:]), ("narrow", streams[1:]), ("mgc+lf0", streams[:2]),
                    ("mgc+4", [streams[0], bap4]), ("mgc+bap", [streams[0], streams[2]]), ("all", streams)):
         out[nm] = round(gpu_time(lambda: _hip.forward_streams(m, v, ss, want_status=False), steps=20), 4)
-    print("mode", os.environ.get("MLPG_HIP_STREAMS_MODE", "0"), out, flush=True)
+    print(out, flush=True)
 
 
 if __name__ == "__main__":
     if sys.argv[1:2] == ["child"]:
         child()
     else:
-        for mode in (sys.argv[1:] or ["0", "1", "2"]):
-            env = dict(os.environ, MLPG_HIP_STREAMS_MODE=mode)
-            subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, check=False)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "child"], check=False)
