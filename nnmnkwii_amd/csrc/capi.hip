@@ -584,7 +584,7 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
   }
   if (have_merged) {
     int rc = launch_strip_multi(main_st, dtype, p_merged, ws_merged, smap, device);
-    if (rc == -1000) {  // the grid cannot hold an utterance (nothing enqueued): one stream after the other
+    if (rc == kStripMultiNotResident) {  // the grid cannot hold an utterance (nothing enqueued): one stream after the other
       rc = 0;
       for (int k = 0; k < num_streams && rc == 0; ++k)
         if (merged_flag[k]) rc = run_stream(k, main_st);

@@ -71,6 +71,8 @@ bool strip_supported(const Problem &p, const WinSet &w);
 bool strip_preferred(const Problem &p, const WinSet &w, bool backward, int in_dtype);
 int launch_strip(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
                  int device);
+// launch_strip_multi's "nothing was enqueued" result: fewer workgroups can be resident than an utterance has strips
+constexpr int kStripMultiNotResident = -1000;
 // forward pass of several streams (p: the parent arrays, sd/D unused) -- per-frame variances, three windows of extent <= 1
 int launch_strip_multi(hipStream_t s, int dtype, const Problem &p, const WinSet &w, const StreamMap &sm, int device);
 bool unit_mse_supported(int Tmax, const WinSet &w);

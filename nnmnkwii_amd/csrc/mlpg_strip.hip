@@ -21,7 +21,7 @@ namespace {
 constexpr int kStripFrames = 16 * MLPG_STRIP_W;   // strip::kW * strip::kM
 constexpr int kMaxStrips = 256;    // strips of one utterance must be able to be resident together (2 per CU)
 constexpr int kRecBytes = 14 * 64 * 8;
-constexpr int kStripNotResident = -1000;  // = strip::kNotResident (mlpg_strip_impl.h)
+constexpr int kStripNotResident = kStripMultiNotResident;  // = strip::kNotResident (mlpg_strip_impl.h)
 }  // namespace
 
 bool strip_supported(const Problem &p, const WinSet &ws) {
