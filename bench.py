@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-check", action="store_true", help="profiling/ablation only: skip status and parity checks")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL all-gather of the outputs (reported separately)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live PMC pass (two rocprofv3 child runs, ~40 s)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object (the other BASELINE configs and kernel variants, timed after the metric)")
     ap.add_argument("--regions", type=int, default=9,
@@ -160,9 +161,56 @@ def cpu_baseline(T, D, seconds):
     }
 
 
+def live_traffic(B, T, sd, algo, timeout_s=150.0):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script (the metric's workload
+    only, 5 launches) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- counters in their own
+    passes, as the MI355X guide prescribes -- read back from the rocpd database.  gfx950: FETCH_SIZE counts half of a
+    16 B/lane streaming read, hence 2 x FETCH_SIZE + WRITE_SIZE (both in KiB).  Returns (bytes or None, note)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    kib = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        try:
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "run", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary", "--no-traffic", "--regions", "0",
+                   "--steps", "5", "--warmup", "1", "--algo", str(algo), "--batch", str(B), "--frames", str(T),
+                   "--static-dim", str(sd)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = cur.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? "
+                               "group by kernel_name order by sum(value) desc", (counter,)).fetchall()
+            rows = [x for x in rows if "strip_kernel" in x[0] or "pipe_kernel" in x[0] or "wave_kernel" in x[0] or "generic" in x[0]]
+            if not rows:
+                return None, "no %s rows for the MLPG kernel" % counter
+            kib[counter] = (float(rows[0][1]), int(rows[0][2]), rows[0][0])
+        except (subprocess.TimeoutExpired, OSError, sqlite3.Error) as e:
+            return None, "%s pass: %s" % (counter, type(e).__name__)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    nbytes = (2.0 * kib["FETCH_SIZE"][0] + kib["WRITE_SIZE"][0]) * 1024.0
+    return nbytes, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate child passes of this "
+                    "workload, mean of %d dispatches of %s, %.0f s): 2 x %.1f + %.1f KiB"
+                    % (kib["FETCH_SIZE"][1], kib["FETCH_SIZE"][2].split("(")[0].replace("void ", ""), time.perf_counter() - t0,
+                       kib["FETCH_SIZE"][0], kib["WRITE_SIZE"][0]))
+
+
 def measured_traffic(B, T, sd, algo):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (profiles/traffic.json),
-    if it was taken on this exact workload and kernel; bench.py cannot run rocprofv3 on itself."""
+    if it was taken on this exact workload and kernel: the fall-back when the live pass (live_traffic) is not possible."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
@@ -457,6 +505,18 @@ def main():
             if not args.no_check:
                 assert err < 1e-9, err
 
+        # HBM traffic of the dominant kernel: measured now (N = 1), else the committed PMC pass of this command
+        traffic, traffic_note = None, "not measured"
+        if not dry:
+            why = "skipped (--no-traffic)" if args.no_traffic else "N > 1"
+            if world == 1 and not args.no_traffic:
+                traffic, why = live_traffic(B, T, sd, args.algo)
+            traffic_note = why
+            if traffic is None:
+                traffic = measured_traffic(B, T, sd, args.algo)
+                traffic_note = ("taken from the committed rocprofv3 pass profiles/traffic.json of this command (live pass: %s)" % why
+                                if traffic is not None else "none (live pass: %s)" % why)
+
         frames = world * B * T * args.steps
         alg_bytes = 56.0 * sd * B * T            # 56 B per (frame, static dim) per launch
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms else None
@@ -493,9 +553,8 @@ def main():
                 "peak_measured": copy_gbs,
                 "peak_measured_kernel": "mlpg_hip_stream_copy, 512 MiB -> 512 MiB, (read + written bytes) / best of 16 x 50 launches, same run",
                 "frac_of_measured": (achieved / copy_gbs) if (achieved and copy_gbs) else None,
-                "traffic": measured_traffic(B, T, sd, args.algo),
-                "traffic_unit": "bytes/launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE; taken from the committed rocprofv3 pass "
-                                "profiles/traffic.json of this command -- bench.py cannot run the PMC pass on itself)",
+                "traffic": traffic,
+                "traffic_unit": "bytes/launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE); " + traffic_note,
                 "kernel_ms": kern_ms,
                 "kernel_ms_steady": steady_ms,
                 "algorithmic_bytes": alg_bytes,
