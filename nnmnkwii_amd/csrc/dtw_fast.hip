@@ -351,7 +351,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
   double *py = px + (size_t)Tx * D;
 
 #ifdef MLPG_DTW_TIMING
-  long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // pyramid, windows+offsets, staging, costs, sweep, backtrace, output
+  long long tq[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // pyramid, windows+offsets, staging, costs, sweep, backtrace, output
   long long t_prev = (long long)__builtin_readcyclecounter();
 #endif
   // number of halvings: level K is the first with a side < radius + 2 (full DTW there)
@@ -766,6 +766,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       if (lane == 0) segoff[G] = total;
     }
     __syncthreads();
+    DTW_TICK(7);
     const int ntask = segoff[G];
     // candidate tables in the (now idle) cost buffers: cnts, then `nlev` hop tables of ntask entries
     // each; hop table k maps a candidate to the candidate reached 2^k segments further up
@@ -798,6 +799,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       }
       if (tid == 0) bcast[1] = 1;
       __syncthreads();
+      DTW_TICK(8);
       // hop tables by doubling
       for (int q = 1; q < nlev; ++q) {
         const unsigned short *hp = hop + (size_t)(q - 1) * ntask;
@@ -851,6 +853,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
         }
       }
       __syncthreads();
+      DTW_TICK(9);
       // pass 2: every segment writes its piece of the path
       if (bcast[1]) {
         for (int g = tid; g < G; g += kThreads) {
@@ -932,7 +935,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
   DTW_TICK(6);
   __syncthreads();
   if (tid == 0)
-    for (int q = 0; q < 7; ++q) out_i[pcap - 8 + q] = (int)(tq[q] >> 4);   // profiling build: cycles / 16 in the tail of path_i
+    for (int q = 0; q < 11; ++q) out_i[pcap - 12 + q] = (int)(tq[q] >> 4);   // profiling build: cycles / 16 in the tail of path_i
 #endif
 }
 

@@ -14,5 +14,8 @@ Xd, Yd = torch.from_numpy(X).cuda().repeat(8, 1, 1)[:M].contiguous(), torch.from
 lx, ly = _hip.trim_lengths(Xd), _hip.trim_lengths(Yd)
 for _ in range(2):
     pi, pj, pl, c = _hip.fastdtw_l2(Xd, Yd, lx, ly, 1)
-t = pi[:, -8:-1].cpu().numpy().astype(np.float64) * 16
-print(M, 'pairs; cycles (pyramid, windows, wait-for-costs, first-costs, sweep, backtrace, output):', t.mean(0).astype(int).tolist(), 'total', int(t.mean(0).sum()))
+t = pi[:, -12:-1].cpu().numpy().astype(np.float64) * 16
+m = t.mean(0)
+print(M, 'pairs; cycles (pyramid, windows, wait-for-costs, first-costs, sweep, backtrace, output):',
+      [int(m[0]), int(m[1]), int(m[2]), int(m[3]), int(m[4]), int(m[5] + m[7] + m[8] + m[9]), int(m[6])], 'total', int(m.sum()),
+      '| backtrace = candidate offsets %d + pass 1 %d + doubling/select/prefix %d + pass 2 %d' % (m[7], m[8], m[9], m[5]))
