@@ -727,6 +727,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       }
       // value of the chunk's last cell (bottom-right corner of the level if this is the last chunk)
       last_val = __shfl(pub, R);
+      if (lane == 0) *(double *)(bcast + 12) = last_val;  // for every wavefront: the back-trace's segments are dealt to all threads
       }  // fits
       }  // w0
       prevlo = last_lo;
@@ -738,6 +739,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     }
     if (bcast[3]) fail = true;
     if (fail) break;
+    last_val = *(const double *)(bcast + 12);  // (written before the last chunk's barrier)
     level_cost = (prevhi == lty - 1) ? last_val : INFINITY;
 
     // ---- 3. back-trace ----

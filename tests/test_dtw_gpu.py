@@ -54,6 +54,8 @@ def test_paths_bit_exact_vs_oracle(radius):
     (30, [(300, 280), (257, 300), (64, 300)]),       # windows too wide for the candidate tables: sequential back-trace
     (8, [(500, 9), (9, 500), (12, 13), (700, 650)]),  # one side shorter than radius + 2: full DTW at level 0 / 1
     (1, [(900, 450), (450, 900), (1000, 1000)]),      # slope 2 windows, 16+ chunks, 63 segments
+    (1, [(280, 1), (324, 2), (1, 300), (511, 3)]),    # full DTW of a tall thin matrix: > 64 back-trace segments of 4 rows
+    (3, [(324, 1), (300, 4), (420, 2)]),
 ])
 def test_paths_bit_exact_wide_and_lopsided(radius, sizes):
     rng = np.random.RandomState(100 + radius)
