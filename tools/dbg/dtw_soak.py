@@ -1,5 +1,5 @@
 """Random soak of the fastdtw kernel against the C oracle (oracle/dtw_oracle.c): batches of random size (both the
-512-thread single launch and the 256-thread two-launch form), random lengths 1..420, feature dims 1..30, radius 1..6,
+512-thread single launch and the 256-thread two-launch form), random lengths 1..420, feature dims 1..30, radius 1..30,
 smooth tracks, white noise, integer-valued (tie-heavy) and step/ramp pairs.  Prints the number of pairs checked and the
 first mismatch, if any.   usage: python tools/dbg/dtw_soak.py [seconds]"""
 import os
@@ -21,7 +21,7 @@ bad = None
 while time.time() - t0 < budget and bad is None:
     N = int(rng.choice([3, 40, 130, 520, 700]))
     D = int(rng.randint(1, 31))
-    radius = int(rng.choice([1, 1, 1, 2, 3, 6]))
+    radius = int(rng.choice([1, 1, 1, 2, 3, 6, 12, 30]))
     tmax = int(rng.choice([12, 60, 200, 420]))
     kind = rng.randint(0, 4)
     pairs = []
