@@ -13,50 +13,55 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from nnmnkwii_amd import _hip  # noqa: E402
 from oracle import dtw as OD  # noqa: E402
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
-rng = np.random.RandomState(20260926)
-t0 = time.time()
-checked = batches = 0
-bad = None
-while time.time() - t0 < budget and bad is None:
-    N = int(rng.choice([3, 40, 130, 520, 700]))
-    D = int(rng.randint(1, 31))
-    radius = int(rng.choice([1, 1, 1, 2, 3, 6, 12, 30]))
-    tmax = int(rng.choice([12, 60, 200, 420]))
-    kind = rng.randint(0, 4)
-    pairs = []
-    for n in range(N):
-        tx, ty = int(rng.randint(1, tmax + 1)), int(rng.randint(1, tmax + 1))
-        if kind == 0:
-            x, y = np.cumsum(rng.randn(tx, D), 0) * 0.1, np.cumsum(rng.randn(ty, D), 0) * 0.1
-        elif kind == 1:
-            x, y = rng.randn(tx, D), rng.randn(ty, D)
-        elif kind == 2:
-            x, y = rng.randint(0, 3, (tx, D)).astype(np.float64), rng.randint(0, 3, (ty, D)).astype(np.float64)
-        else:
-            x = np.zeros((tx, D)); x[tx // 2:] = 5.0; x += 1e-3 * rng.randn(tx, D)
-            y = np.linspace(0.0, 5.0, ty)[:, None] * np.ones((1, D)) + 1e-3 * rng.randn(ty, D)
-        pairs.append((x, y))
-    Tx, Ty = max(len(x) for x, _ in pairs), max(len(y) for _, y in pairs)
-    X, Y = np.zeros((N, Tx, D)), np.zeros((N, Ty, D))
-    for n, (x, y) in enumerate(pairs):
-        X[n, :len(x)] = x
-        Y[n, :len(y)] = y
-    lx = torch.tensor([len(x) for x, _ in pairs], dtype=torch.int32, device="cuda")
-    ly = torch.tensor([len(y) for _, y in pairs], dtype=torch.int32, device="cuda")
-    pi, pj, pl, cost = _hip.fastdtw_l2(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), lx, ly, radius)
-    pi, pj, pl, cost = pi.cpu().numpy(), pj.cpu().numpy(), pl.cpu().numpy(), cost.cpu().numpy()
-    step = max(1, N // 60)
-    for n in range(0, N, step):
-        x, y = pairs[n]
-        d, path = OD.fastdtw(x, y, radius)
-        ok = pl[n] == len(path) and np.array_equal(pi[n, :pl[n]], path[:, 0]) and np.array_equal(pj[n, :pl[n]], path[:, 1])
-        # tie-heavy data: equal cost is what the reference itself guarantees; everything else bit for bit
-        if not ok and kind == 2 and pl[n] > 0 and abs(cost[n] - d) <= 1e-12 * max(d, 1e-300):
-            ok = True
-        if not ok or not (abs(cost[n] - d) <= 1e-12 * max(d, 1e-300)):
-            bad = (batches, n, N, D, radius, kind, len(x), len(y), int(pl[n]), len(path), float(cost[n]), float(d))
-            break
-        checked += 1
-    batches += 1
-print("batches", batches, "pairs checked", checked, "mismatch", bad)
+def soak(budget=40.0, seed=20260926):
+    rng = np.random.RandomState(seed)
+    t0 = time.time()
+    checked = batches = 0
+    bad = None
+    while time.time() - t0 < budget and bad is None:
+        N = int(rng.choice([3, 40, 130, 520, 700]))
+        D = int(rng.randint(1, 31))
+        radius = int(rng.choice([1, 1, 1, 2, 3, 6, 12, 30]))
+        tmax = int(rng.choice([12, 60, 200, 420]))
+        kind = rng.randint(0, 4)
+        pairs = []
+        for n in range(N):
+            tx, ty = int(rng.randint(1, tmax + 1)), int(rng.randint(1, tmax + 1))
+            if kind == 0:
+                x, y = np.cumsum(rng.randn(tx, D), 0) * 0.1, np.cumsum(rng.randn(ty, D), 0) * 0.1
+            elif kind == 1:
+                x, y = rng.randn(tx, D), rng.randn(ty, D)
+            elif kind == 2:
+                x, y = rng.randint(0, 3, (tx, D)).astype(np.float64), rng.randint(0, 3, (ty, D)).astype(np.float64)
+            else:
+                x = np.zeros((tx, D)); x[tx // 2:] = 5.0; x += 1e-3 * rng.randn(tx, D)
+                y = np.linspace(0.0, 5.0, ty)[:, None] * np.ones((1, D)) + 1e-3 * rng.randn(ty, D)
+            pairs.append((x, y))
+        Tx, Ty = max(len(x) for x, _ in pairs), max(len(y) for _, y in pairs)
+        X, Y = np.zeros((N, Tx, D)), np.zeros((N, Ty, D))
+        for n, (x, y) in enumerate(pairs):
+            X[n, :len(x)] = x
+            Y[n, :len(y)] = y
+        lx = torch.tensor([len(x) for x, _ in pairs], dtype=torch.int32, device="cuda")
+        ly = torch.tensor([len(y) for _, y in pairs], dtype=torch.int32, device="cuda")
+        pi, pj, pl, cost = _hip.fastdtw_l2(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), lx, ly, radius)
+        pi, pj, pl, cost = pi.cpu().numpy(), pj.cpu().numpy(), pl.cpu().numpy(), cost.cpu().numpy()
+        step = max(1, N // 60)
+        for n in range(0, N, step):
+            x, y = pairs[n]
+            d, path = OD.fastdtw(x, y, radius)
+            ok = pl[n] == len(path) and np.array_equal(pi[n, :pl[n]], path[:, 0]) and np.array_equal(pj[n, :pl[n]], path[:, 1])
+            # tie-heavy data: equal cost is what the reference itself guarantees; everything else bit for bit
+            if not ok and kind == 2 and pl[n] > 0 and abs(cost[n] - d) <= 1e-12 * max(d, 1e-300):
+                ok = True
+            if not ok or not (abs(cost[n] - d) <= 1e-12 * max(d, 1e-300)):
+                bad = (batches, n, N, D, radius, kind, len(x), len(y), int(pl[n]), len(path), float(cost[n]), float(d))
+                break
+            checked += 1
+        batches += 1
+    return batches, checked, bad
+
+
+if __name__ == "__main__":
+    r = soak(float(sys.argv[1]) if len(sys.argv) > 1 else 40.0)
+    print("batches", r[0], "pairs checked", r[1], "mismatch", r[2])

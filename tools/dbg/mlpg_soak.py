@@ -17,69 +17,74 @@ from cases import WINDOW_SETS  # noqa: E402
 from nnmnkwii_amd import _hip  # noqa: E402
 
 STD3 = WINDOW_SETS["std3"]
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
-rng = np.random.RandomState(4711)
-t0 = time.time()
-n_streams = n_fused = 0
-bad = None
-while time.time() - t0 < budget and bad is None:
-    dt = [np.float64, np.float32][rng.randint(2)]
-    tol = 1e-9 if dt == np.float64 else 3e-6
-    if rng.rand() < 0.6:
-        # ---- multi-stream ----
-        B = int(rng.randint(1, 9))
-        T = int(rng.choice([40, 300, 700, 1100, 1500, 2100]))
-        k = int(rng.randint(2, 6))
-        sds = [int(rng.choice([1, 2, 3, 5, 7, 20, 40, 60, 64, 66])) for _ in range(k)]
-        passthru = [rng.rand() < 0.2 for _ in range(k)]
-        cols, c = [], 0
-        for sd, pt in zip(sds, passthru):
-            cols.append(c)
-            c += sd if pt else 3 * sd
-            c += int(rng.randint(0, 3))           # unused columns between streams
-        D = c
-        m = rng.randn(B, T, D).astype(dt)
-        v = (rng.rand(B, T, D) + 0.1).astype(dt)
-        lengths = rng.randint(1, T + 1, size=B).astype(np.int32)
-        lengths[rng.randint(B)] = T
-        for b in range(B):
-            m[b, lengths[b]:] = 0
-        md, vd, Ld = torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(lengths).cuda()
-        streams = [(cols[i], sds[i], None if passthru[i] else STD3) for i in range(k)]
-        algo = _hip.ALGO_STRIP if rng.rand() < 0.5 else _hip.ALGO_AUTO
-        out, st = _hip.forward_streams(md, vd, streams, Ld, algo=algo)
-        o0 = 0
-        for (c0, sd, win) in streams:
-            if win is not None:
-                dense, dst = _hip.forward(md[:, :, c0:c0 + 3 * sd].contiguous(), vd[:, :, c0:c0 + 3 * sd].contiguous(), STD3, Ld)
-                err = float((out[:, :, o0:o0 + sd] - dense).abs().max())
-                if not (err <= tol * max(1.0, float(dense.abs().max()))) or int(st[:, o0:o0 + sd].abs().sum()) != 0:
-                    bad = ("streams", dt.__name__, B, T, streams, algo, c0, sd, err)
-                    break
-            o0 += sd
-        n_streams += 1
-    else:
-        # ---- fused unit-variance step ----
-        B = int(rng.randint(1, 40))
-        T = int(rng.choice([1, 2, 5, 37, 64, 200, 256, 257, 500, 512, 513, 900]))
-        sd = int(rng.randint(1, 70))
-        m = torch.from_numpy(rng.rand(B, T, 3 * sd).astype(dt)).cuda()
-        tg = torch.from_numpy(rng.rand(B, T, sd).astype(dt)).cuda()
-        lengths = None
-        if rng.rand() < 0.5:
-            ln = rng.randint(1, T + 1, size=B).astype(np.int32)
-            lengths = torch.from_numpy(ln).cuda()
-        loss, grad, y, _ = _hip.unit_mse_step(m, tg, STD3, lengths=lengths, want_y=True)
-        yr, _ = _hip.forward(m, None, STD3, lengths)
-        mask = torch.ones(B, T, 1, device="cuda", dtype=m.dtype)
-        if lengths is not None:
-            mask = (torch.arange(T, device="cuda")[None, :, None] < lengths[:, None, None]).to(m.dtype)
-        g = 2.0 * (yr - tg) * mask / float(B * T * sd)
-        gr, _ = _hip.backward(None, g.contiguous(), STD3, 3 * sd, lengths=lengths, out_dtype=m.dtype)
-        lr = float((((yr - tg) * mask) ** 2).sum() / float(B * T * sd))
-        e1 = float((y * mask - yr * mask).abs().max())
-        e2 = float((grad - gr).abs().max())
-        if not (e1 <= tol and e2 <= tol * max(1e-6, float(gr.abs().max())) + 1e-30 and abs(float(loss) - lr) <= 10 * tol * max(lr, 1e-30)):
-            bad = ("fused", dt.__name__, B, T, sd, lengths is not None, e1, e2, float(loss), lr)
-        n_fused += 1
-print("multi-stream cases", n_streams, "fused cases", n_fused, "mismatch", bad)
+def soak(budget=40.0, seed=4711):
+    rng = np.random.RandomState(seed)
+    t0 = time.time()
+    n_streams = n_fused = 0
+    bad = None
+    while time.time() - t0 < budget and bad is None:
+        dt = [np.float64, np.float32][rng.randint(2)]
+        tol = 1e-9 if dt == np.float64 else 3e-6
+        if rng.rand() < 0.6:
+            # ---- multi-stream ----
+            B = int(rng.randint(1, 9))
+            T = int(rng.choice([40, 300, 700, 1100, 1500, 2100]))
+            k = int(rng.randint(2, 6))
+            sds = [int(rng.choice([1, 2, 3, 5, 7, 20, 40, 60, 64, 66])) for _ in range(k)]
+            passthru = [rng.rand() < 0.2 for _ in range(k)]
+            cols, c = [], 0
+            for sd, pt in zip(sds, passthru):
+                cols.append(c)
+                c += sd if pt else 3 * sd
+                c += int(rng.randint(0, 3))           # unused columns between streams
+            D = c
+            m = rng.randn(B, T, D).astype(dt)
+            v = (rng.rand(B, T, D) + 0.1).astype(dt)
+            lengths = rng.randint(1, T + 1, size=B).astype(np.int32)
+            lengths[rng.randint(B)] = T
+            for b in range(B):
+                m[b, lengths[b]:] = 0
+            md, vd, Ld = torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(lengths).cuda()
+            streams = [(cols[i], sds[i], None if passthru[i] else STD3) for i in range(k)]
+            algo = _hip.ALGO_STRIP if rng.rand() < 0.5 else _hip.ALGO_AUTO
+            out, st = _hip.forward_streams(md, vd, streams, Ld, algo=algo)
+            o0 = 0
+            for (c0, sd, win) in streams:
+                if win is not None:
+                    dense, dst = _hip.forward(md[:, :, c0:c0 + 3 * sd].contiguous(), vd[:, :, c0:c0 + 3 * sd].contiguous(), STD3, Ld)
+                    err = float((out[:, :, o0:o0 + sd] - dense).abs().max())
+                    if not (err <= tol * max(1.0, float(dense.abs().max()))) or int(st[:, o0:o0 + sd].abs().sum()) != 0:
+                        bad = ("streams", dt.__name__, B, T, streams, algo, c0, sd, err)
+                        break
+                o0 += sd
+            n_streams += 1
+        else:
+            # ---- fused unit-variance step ----
+            B = int(rng.randint(1, 40))
+            T = int(rng.choice([1, 2, 5, 37, 64, 200, 256, 257, 500, 512, 513, 900]))
+            sd = int(rng.randint(1, 70))
+            m = torch.from_numpy(rng.rand(B, T, 3 * sd).astype(dt)).cuda()
+            tg = torch.from_numpy(rng.rand(B, T, sd).astype(dt)).cuda()
+            lengths = None
+            if rng.rand() < 0.5:
+                ln = rng.randint(1, T + 1, size=B).astype(np.int32)
+                lengths = torch.from_numpy(ln).cuda()
+            loss, grad, y, _ = _hip.unit_mse_step(m, tg, STD3, lengths=lengths, want_y=True)
+            yr, _ = _hip.forward(m, None, STD3, lengths)
+            mask = torch.ones(B, T, 1, device="cuda", dtype=m.dtype)
+            if lengths is not None:
+                mask = (torch.arange(T, device="cuda")[None, :, None] < lengths[:, None, None]).to(m.dtype)
+            g = 2.0 * (yr - tg) * mask / float(B * T * sd)
+            gr, _ = _hip.backward(None, g.contiguous(), STD3, 3 * sd, lengths=lengths, out_dtype=m.dtype)
+            lr = float((((yr - tg) * mask) ** 2).sum() / float(B * T * sd))
+            e1 = float((y * mask - yr * mask).abs().max())
+            e2 = float((grad - gr).abs().max())
+            if not (e1 <= tol and e2 <= tol * max(1e-6, float(gr.abs().max())) + 1e-30 and abs(float(loss) - lr) <= 10 * tol * max(lr, 1e-30)):
+                bad = ("fused", dt.__name__, B, T, sd, lengths is not None, e1, e2, float(loss), lr)
+            n_fused += 1
+    return n_streams, n_fused, bad
+
+
+if __name__ == "__main__":
+    r = soak(float(sys.argv[1]) if len(sys.argv) > 1 else 40.0)
+    print("multi-stream cases", r[0], "fused cases", r[1], "mismatch", r[2])
