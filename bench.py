@@ -161,7 +161,7 @@ def cpu_baseline(T, D, seconds):
     }
 
 
-def live_traffic(B, T, sd, algo, timeout_s=150.0):
+def live_traffic(B, T, sd, algo, timeout_s=90.0):
     """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script (the metric's workload
     only, 5 launches) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- counters in their own
     passes, as the MI355X guide prescribes -- read back from the rocpd database.  gfx950: FETCH_SIZE counts half of a
