@@ -510,34 +510,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     unsigned short *cstart = cfirst;
     // cells in front of a chunk's rows in its cost buffer: the handed-over row (the virtual row -1 has one cell)
     auto feed_cells = [&](int i0) { return (i0 > 0 ? HI(i0 - 1) - LO(i0 - 1) + 1 : 1) + 2 * kSlack; };
-    if (w0) {
-      int i0 = 0, nc = 0, bad = 0;
-      while (i0 < ltx) {
-        const int base = OFF(i0), room = p.chunkcap - feed_cells(i0);
-        // short first chunks: the pipeline (costs of chunk c+1 behind the sweep of chunk c) starts sooner
-        const int rowcap = nc == 0 ? 8 : (nc == 1 ? 24 : kRows);
-        const bool fits = (lane < rowcap) && (i0 + lane < ltx) && (OFF(i0 + lane + 1) - base <= room);
-        const unsigned long long m = __ballot(fits);
-        const int R = __ffsll((long long)~m) - 1;  // bit 63 is never set: R <= 63
-        if (R < 1) { bad = 1; break; }
-        if (lane == 0) cstart[nc] = (unsigned short)i0;
-        ++nc;
-        i0 += R;
-      }
-      if (lane == 0) {
-        cstart[nc] = (unsigned short)ltx;
-        bcast[2] = nc;
-        bcast[3] = bad;
-      }
-    }
-    __syncthreads();
-    if (bcast[3]) fail = true;
-    if (fail) break;
-    const int nchunk = bcast[2];
-
-    // local costs of every window cell of chunk c into its buffer, by threads [t0, t0 + nthr)
-    auto chunk_costs = [&](int c, double *buf, int t0, int nthr) {
-      const int i0 = (int)cstart[c], R = (int)cstart[c + 1] - i0, base = OFF(i0);
+    // local costs of every window cell of the chunk of rows [i0, i0 + R) into its buffer, by threads [t0, t0 + nthr)
+    auto chunk_costs_rows = [&](int i0, int R, double *buf, int t0, int nthr) {
+      const int base = OFF(i0);
       const int ncell = OFF(i0 + R) - base;
       double *dst = buf + feed_cells(i0);
       if (p.dist_kind == MLPG_HIP_DIST_L2 && D >= 2) {
@@ -586,8 +561,41 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
         dst[fr + 1] = INFINITY;
       }
     };
-    chunk_costs(0, dchunk, 0, kThreads);
+    auto chunk_costs = [&](int c, double *buf, int t0, int nthr) {
+      chunk_costs_rows((int)cstart[c], (int)cstart[c + 1] - (int)cstart[c], buf, t0, nthr);
+    };
+    if (w0) {
+      int i0 = 0, nc = 0, bad = 0;
+      while (i0 < ltx) {
+        const int base = OFF(i0), room = p.chunkcap - feed_cells(i0);
+        // short first chunks: the pipeline (costs of chunk c+1 behind the sweep of chunk c) starts sooner
+        const int rowcap = nc == 0 ? 8 : (nc == 1 ? 24 : kRows);
+        const bool fits = (lane < rowcap) && (i0 + lane < ltx) && (OFF(i0 + lane + 1) - base <= room);
+        const unsigned long long m = __ballot(fits);
+        const int R = __ffsll((long long)~m) - 1;  // bit 63 is never set: R <= 63
+        if (R < 1) { bad = 1; break; }
+        if (lane == 0) cstart[nc] = (unsigned short)i0;
+        ++nc;
+        i0 += R;
+      }
+      if (lane == 0) {
+        cstart[nc] = (unsigned short)ltx;
+        bcast[2] = nc;
+        bcast[3] = bad;
+      }
+    } else {
+      // meanwhile the other wavefronts compute the local costs of chunk 0 -- its rows follow from the same rule (at
+      // most 8 rows, cells within the buffer), which every thread evaluates for itself
+      const int room0 = p.chunkcap - feed_cells(0);
+      int R0 = 0;
+      for (int r_ = 1; r_ <= 8 && r_ <= ltx && OFF(r_) <= room0; ++r_) R0 = r_;
+      if (R0 >= 1) chunk_costs_rows(0, R0, dchunk, 64, kThreads - 64);
+    }
     __syncthreads();
+    if (bcast[3]) fail = true;
+    if (fail) break;
+    const int nchunk = bcast[2];
+
     DTW_TICK(3);
 
     // ---- 2d. DP: wavefront 0 sweeps chunk c while the other wavefronts prepare the costs of chunk c+1 ----
