@@ -598,6 +598,31 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
 
     DTW_TICK(3);
 
+    // Back-trace segments (section 3): the shortest of 4 / 8 / 16 rows that keeps the candidates (about cells /
+    // rows-per-segment) within one round of the workgroup's threads -- the walks are the dependent part, shorter is faster
+    const int kSeg = ncell_lvl <= kSegMin * kThreads ? kSegMin : (ncell_lvl <= 2 * kSegMin * kThreads ? 2 * kSegMin : kSegMax);
+    const int G = (ltx + kSeg - 1) / kSeg;  // segment g = rows [g*kSeg, min((g+1)*kSeg, ltx))
+    // candidate-table offsets: one entry per cell of every segment's bottom row.  They depend on the windows only:
+    // one of the cost wavefronts computes them while the last chunk is swept (it has no further chunk to prepare).
+    auto candidate_offsets = [&]() {
+      const int gpl = (G + 63) / 64;
+      const int g0 = lane * gpl < G ? lane * gpl : G;
+      const int g1 = g0 + gpl < G ? g0 + gpl : G;
+      int sum = 0;
+      for (int g = g0; g < g1; ++g) {
+        const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
+        sum += HI(bot) - LO(bot) + 1;
+      }
+      int total;
+      int run = wave_excl_scan(sum, lane, &total);
+      for (int g = g0; g < g1; ++g) {
+        const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
+        segoff[g] = run;
+        run += HI(bot) - LO(bot) + 1;
+      }
+      if (lane == 0) segoff[G] = total;
+    };
+
     // ---- 2d. DP: wavefront 0 sweeps chunk c while the other wavefronts prepare the costs of chunk c+1 ----
     int prevlo = -1, prevhi = -1;  // the virtual row -1 has the single cell (-1, -1)
     int hw_next = 0;               // next free back-pointer halfword
@@ -608,6 +633,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       double *dnxt = dchunk + ((c + 1) & 1) * dstride;  // its head receives the row handed to chunk c+1
       const int last_lo = LO(i0 + R - 1), last_hi = HI(i0 + R - 1);
       if (!w0 && c + 1 < nchunk) chunk_costs(c + 1, dnxt, 64, kThreads - 64);
+      if (c + 1 == nchunk && (tid >> 6) == 1) candidate_offsets();
       // anti-diagonal sweep (wavefront 0): lane r >= 1 owns row i0 + r - 1, lane 0 feeds the row above;
       // at step s every lane handles column s - lane of its row
       if (w0) {
@@ -751,31 +777,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     level_cost = (prevhi == lty - 1) ? last_val : INFINITY;
 
     // ---- 3. back-trace ----
-    // segment length: the shortest of 4 / 8 / 16 rows that keeps the candidates (about cells / rows-per-segment)
-    // within one round of the workgroup's threads -- the walks are the dependent part, shorter is faster
-    const int kSeg = ncell_lvl <= kSegMin * kThreads ? kSegMin : (ncell_lvl <= 2 * kSegMin * kThreads ? 2 * kSegMin : kSegMax);
-    const int G = (ltx + kSeg - 1) / kSeg;  // segment g = rows [g*kSeg, min((g+1)*kSeg, ltx))
     // level 0 writes the path straight to the output arrays (from position 0), the other levels into LDS (right-aligned)
     const int wcap = k == 0 ? pcap : pcapL;
-    if (w0) {  // candidate-table offsets: one entry per cell of every segment's bottom row
-      const int gpl = (G + 63) / 64;
-      const int g0 = lane * gpl < G ? lane * gpl : G;
-      const int g1 = g0 + gpl < G ? g0 + gpl : G;
-      int sum = 0;
-      for (int g = g0; g < g1; ++g) {
-        const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
-        sum += HI(bot) - LO(bot) + 1;
-      }
-      int total;
-      int run = wave_excl_scan(sum, lane, &total);
-      for (int g = g0; g < g1; ++g) {
-        const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
-        segoff[g] = run;
-        run += HI(bot) - LO(bot) + 1;
-      }
-      if (lane == 0) segoff[G] = total;
-    }
-    __syncthreads();
     DTW_TICK(7);
     const int ntask = segoff[G];
     // candidate tables in the (now idle) cost buffers: cnts, then `nlev` hop tables of ntask entries
