@@ -279,16 +279,19 @@ static_assert(kHB * kNB == kM + 2, "batches must tile the 18 frames");
 // per-load 64-bit address arithmetic and no address registers (global_load with 64-bit VGPR addresses costs two VALU
 // instructions and a register pair per load, which is what drove this kernel into scratch).
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+#ifndef MLPG_STRIP_LOAD_AUX
+#define MLPG_STRIP_LOAD_AUX 0   // cache policy of the row loads (experiment: 2 = nt)
+#endif
 template <typename TIN>
 __device__ __forceinline__ TIN ld_row(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff);
 template <>
 __device__ __forceinline__ double ld_row<double>(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff) {
-  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, loff, soff, 0);
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, loff, soff, MLPG_STRIP_LOAD_AUX);
   return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
 }
 template <>
 __device__ __forceinline__ float ld_row<float>(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, loff, soff, 0));
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, loff, soff, MLPG_STRIP_LOAD_AUX));
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
   // the base must be wave-uniform PROVABLY (a lane-tainted descriptor is wrapped in a waterfall loop per load)
