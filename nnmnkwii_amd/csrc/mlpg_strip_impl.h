@@ -293,6 +293,22 @@ template <>
 __device__ __forceinline__ float ld_row<float>(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, loff, soff, MLPG_STRIP_LOAD_AUX));
 }
+// the backward's grad_out rows (read once; MLPG_STRIP_GOUT_AUX = 2: nt, so that they do not displace the variance rows the
+// epilogue reads a second time)
+#ifndef MLPG_STRIP_GOUT_AUX
+#define MLPG_STRIP_GOUT_AUX 0
+#endif
+template <typename TIN>
+__device__ __forceinline__ TIN ld_row_g(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff);
+template <>
+__device__ __forceinline__ double ld_row_g<double>(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, loff, soff, MLPG_STRIP_GOUT_AUX);
+  return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+}
+template <>
+__device__ __forceinline__ float ld_row_g<float>(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, loff, soff, MLPG_STRIP_GOUT_AUX));
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
   // the base must be wave-uniform PROVABLY (a lane-tainted descriptor is wrapped in a waterfall loop per load)
   const unsigned long long u = (unsigned long long)base;
@@ -411,7 +427,7 @@ __device__ __forceinline__ void assemble(__amdgpu_buffer_rsrc_t mrs, __amdgpu_bu
     for (int i = 0; i < kM; ++i) {
       int t = f0 + i;
       if (EDGE) t = t >= T ? T - 1 : t;
-      rhs[i] = (double)ld_row<TIN>(grs, (unsigned)t * (unsigned)ldg * (unsigned)sizeof(TIN), loff);  // rows >= T are reset below
+      rhs[i] = (double)ld_row_g<TIN>(grs, (unsigned)t * (unsigned)ldg * (unsigned)sizeof(TIN), loff);  // rows >= T are reset below
     }
   }
   for (int w = 0; w < nw; ++w) {
@@ -668,7 +684,7 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
     for (int i = 0; i < kM; ++i) {
       int t = f0 + i;
       if (EDGE) t = t >= T ? T - 1 : t;
-      rhs[i] = (double)ld_row<TIN>(grs, (unsigned)t * (unsigned)ldg * (unsigned)sizeof(TIN), loff);  // rows >= T are reset by fix_row
+      rhs[i] = (double)ld_row_g<TIN>(grs, (unsigned)t * (unsigned)ldg * (unsigned)sizeof(TIN), loff);  // rows >= T are reset by fix_row
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -871,7 +887,7 @@ __device__ __forceinline__ bool assemble_eliminate_halo(const int last, double *
     for (int i = 0; i < kM; ++i) {
       int t = f0 + i;
       if (EDGE) t = t >= T ? T - 1 : t;
-      rhs[i] = (double)ld_row<TIN>(grs, (unsigned)t * (unsigned)ldg * (unsigned)sizeof(TIN), loff);  // rows >= T are reset by fix_row
+      rhs[i] = (double)ld_row_g<TIN>(grs, (unsigned)t * (unsigned)ldg * (unsigned)sizeof(TIN), loff);  // rows >= T are reset by fix_row
     }
   }
   __builtin_amdgcn_sched_barrier(0);
