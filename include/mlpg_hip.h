@@ -175,8 +175,14 @@ void mlpg_hip_host_free(void *p);
  *          them).  num_windows == 0: no dynamic features, the static columns
  *          are copied through (frames >= lengths[b] zero-filled).
  *   status : int32 (B, sum_k static_dim), streams in table order; may be NULL.
- * The slices are consumed in place (no repacking); each stream is one launch
- * on `stream`.
+ * The slices are consumed in place (no repacking).  Streams that share their
+ * three windows (extents <= 1) and have per-frame variances are solved by ONE
+ * launch (their static dims side by side on the lanes; a stream may be cut to
+ * fill the last 64-lane group, its remaining dims then run as a launch of their
+ * own); every other stream is one launch.  Launches other than the widest go
+ * to internal streams forked from and joined back into `stream` with events
+ * (no host synchronisation; capturable): when the call returns, everything is
+ * ordered on `stream`.  The results do not depend on the grouping.
  */
 typedef struct {
   int32_t in_col;      /* first column of the stream in mean / var rows  */
