@@ -182,7 +182,8 @@ void mlpg_hip_host_free(void *p);
  * own); every other stream is one launch.  Launches other than the widest go
  * to internal streams forked from and joined back into `stream` with events
  * (no host synchronisation; capturable): when the call returns, everything is
- * ordered on `stream`.  The results do not depend on the grouping.
+ * ordered on `stream`.  Which kernel solves a dim depends on the grouping, the
+ * results agree to rounding (every kernel is held to the same parity bar).
  */
 typedef struct {
   int32_t in_col;      /* first column of the stream in mean / var rows  */
