@@ -391,12 +391,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
   }
   __syncthreads();
   {
-    // up to three levels per round (one barrier each): an item reads a column of 8 / 4 / 2 consecutive source rows and
-    // produces the 4 + 2 + 1 means above them -- every mean the same two-operand expression as level by level
+    // up to four levels per round (one barrier each): an item reads a column of 16 / 8 / 4 / 2 consecutive source rows
+    // and produces the 8 + 4 + 2 + 1 means above them -- every mean the same two-operand expression as level by level
+    constexpr int kPyr = 4, kSpan = 1 << kPyr;
     const double *srcx = x0, *srcy = y0;
     int cx = tx, cy = ty;  // rows of the source level
     for (int k0 = 0; k0 < K;) {
-      const int nl = K - k0 < 3 ? K - k0 : 3, span = 1 << nl, half = span >> 1;
+      const int nl = K - k0 < kPyr ? K - k0 : kPyr, span = 1 << nl, half = span >> 1;
       const int nbx = ((cx >> 1) + half - 1) / half, nby = ((cy >> 1) + half - 1) / half;
       const int itx = nbx * D, items = (nbx + nby) * D;
       for (int e = tid; e < items; e += kThreads) {
@@ -407,28 +408,25 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
         const int cnt0 = isx ? cx : cy;
         double *base_ = isx ? px : py;
         const int *lvl = isx ? lvl_x : lvl_y;
-        double v[8], a1[4], a2[2];
+        double v[kSpan];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < kSpan; ++q) {
           const int row = blk * span + q;
           v[q] = (q < span && row < cnt0) ? src[(size_t)row * D + c] : 0.0;
         }
-        double *d1 = base_ + lvl[k0 + 1];
+        // level k0 + j: rows blk * (span >> j) + q, q < span >> j, means of pairs of the level below (in place in v)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          a1[q] = __dadd_rn(v[2 * q], v[2 * q + 1]) * 0.5;
-          const int r1 = blk * half + q;
-          if (q < half && r1 < (cnt0 >> 1)) d1[(size_t)r1 * D + c] = a1[q];
-        }
-        if (nl >= 2) {
-          double *d2 = base_ + lvl[k0 + 2];
+        for (int j = 1; j <= kPyr; ++j) {
+          if (j <= nl) {
+            double *dj = base_ + lvl[k0 + j];
+            const int per = span >> j, cntj = cnt0 >> j;
 #pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            a2[q] = __dadd_rn(a1[2 * q], a1[2 * q + 1]) * 0.5;
-            const int r2 = blk * (half >> 1) + q;
-            if (q < (half >> 1) && r2 < (cnt0 >> 2)) d2[(size_t)r2 * D + c] = a2[q];
+            for (int q = 0; q < (kSpan >> j); ++q) {
+              v[q] = __dadd_rn(v[2 * q], v[2 * q + 1]) * 0.5;
+              const int rj = blk * per + q;
+              if (q < per && rj < cntj) dj[(size_t)rj * D + c] = v[q];
+            }
           }
-          if (nl >= 3 && blk < (cnt0 >> 3)) (base_ + lvl[k0 + 3])[(size_t)blk * D + c] = __dadd_rn(a2[0], a2[1]) * 0.5;
         }
       }
       __threadfence_block();
