@@ -153,3 +153,34 @@ def test_compat_install_provides_the_reference_names():
     finally:
         compat.uninstall()
     assert "nnmnkwii" not in sys.modules and "nnmnkwii.paramgen" not in sys.modules
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """include/mlpg_hip.h is what a cgo / JNI / ctypes binding reads: it must compile as C (no C++-isms), and a C
+    program must link against the library and get its ABI version -- no GPU needed for that."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    from nnmnkwii_amd import _hip
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = _hip.SO_PATH
+    if not os.path.exists(so):
+        pytest.skip("library not built")
+    src = tmp_path / "demo.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "mlpg_hip.h"\n'
+        "int main(void) {\n"
+        "  mlpg_hip_stream_t s; s.in_col = 0; s.out_col = 0; s.static_dim = 1; s.num_windows = 0; s.win_first = 0; (void)s;\n"
+        '  printf("%d %d %d\\n", mlpg_hip_abi_version(), MLPG_HIP_ALGO_PIPE, MLPG_HIP_DIST_SCALED_SQL2_NP);\n'
+        "  return 0;\n}\n")
+    exe = tmp_path / "demo"
+    cmd = [gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), so,
+           "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert r.returncode == 0, r.stdout
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, env=env)
+    assert out.returncode == 0, out.stdout
+    assert out.stdout.split() == ["10", "4", "3"], out.stdout
