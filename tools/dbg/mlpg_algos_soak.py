@@ -26,7 +26,7 @@ def soak(budget=40.0, seed=99):
     while time.time() - t0 < budget and bad is None:
         dt = [np.float64, np.float32][rng.randint(2)]
         tol = 2e-9 if dt == np.float64 else 3e-6
-        wname = ["std3", "std2", "static", "wide3"][rng.randint(4)]
+        wname = ["std3", "std2", "static", "wide3", "zero2", "asym2"][rng.randint(6)]
         win = WINDOW_SETS[wname]
         nw = len(win)
         B = int(rng.randint(1, 7))
