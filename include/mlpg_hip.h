@@ -60,6 +60,9 @@ extern "C" {
 #define MLPG_HIP_ALGO_STRIP 3   /* lane-per-static-dim, wavefront per 16-frame chunk, any T */
 #define MLPG_HIP_ALGO_PIPE 4    /* the strip scheme software-pipelined: 3 chunk wavefronts + 1 chain wavefront per CU,
                                    level 1 of item s+1 runs under the level-2/3 latency chain of item s (3 windows) */
+#define MLPG_HIP_ALGO_CONST 5   /* global (D,) / unit variances: the matrix of a static dim is the same for every
+                                   utterance (_mlpg.py:169-170 tiles the variances) -- factorised once per launch, the
+                                   solves are constant-coefficient recurrences, lane-per-static-dim, any T */
 
 int mlpg_hip_abi_version(void);
 const char *mlpg_hip_last_error(void);

@@ -27,7 +27,7 @@ void set_error(const char *fmt, ...) {
 // Launches on different streams of one device never share a buffer; a buffer is only ever
 // reused, grown or freed behind work of its own stream.
 namespace {
-constexpr int kMaxDevices = 16, kSlots = 4;
+constexpr int kMaxDevices = 16, kSlots = 6;
 struct Slot {
   void *ptr = nullptr;
   size_t bytes = 0;
@@ -174,7 +174,7 @@ int check_common(int B, int Tmax, int D, int nw) {
 // ones, generic kernel for window extents > 1 or utterances longer than either supports.
 int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool backward, const Problem &p,
                    const WinSet &ws, int device) {
-  if (algo < MLPG_HIP_ALGO_AUTO || algo > MLPG_HIP_ALGO_PIPE) {
+  if (algo < MLPG_HIP_ALGO_AUTO || algo > MLPG_HIP_ALGO_CONST) {
     set_error("unknown algo %d", algo);
     return MLPG_HIP_EINVAL;
   }
@@ -184,6 +184,10 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
   }
   if (algo == MLPG_HIP_ALGO_STRIP && !strip_supported(p, ws)) {
     set_error("MLPG_HIP_ALGO_STRIP does not support this problem (T=%d, half-bandwidth %d)", p.Tmax, ws.q);
+    return MLPG_HIP_EINVAL;
+  }
+  if (algo == MLPG_HIP_ALGO_CONST && !const_supported(p, ws)) {
+    set_error("MLPG_HIP_ALGO_CONST needs global or unit variances and 2-3 windows of extent <= 1 (var_mode %d, %d windows, T=%d)", p.var_mode, ws.nw, p.Tmax);
     return MLPG_HIP_EINVAL;
   }
   if (algo == MLPG_HIP_ALGO_PIPE && !pipe_supported(p, ws)) {
@@ -204,9 +208,11 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
   }
   if (algo == MLPG_HIP_ALGO_AUTO) {
-    if (strip_preferred(p, ws, backward, in_dtype) || (strip_supported(p, ws) && !wave_supported(p, ws))) algo = MLPG_HIP_ALGO_STRIP;
+    if (const_preferred(p, ws)) algo = MLPG_HIP_ALGO_CONST;
+    else if (strip_preferred(p, ws, backward, in_dtype) || (strip_supported(p, ws) && !wave_supported(p, ws))) algo = MLPG_HIP_ALGO_STRIP;
     else algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
   }
+  if (algo == MLPG_HIP_ALGO_CONST) return launch_const(st, in_dtype, out_dtype, backward, p, ws, device);
   if (algo == MLPG_HIP_ALGO_PIPE) return launch_pipe(st, in_dtype, out_dtype, backward, p, ws, device);
   if (algo == MLPG_HIP_ALGO_STRIP) return launch_strip(st, in_dtype, out_dtype, backward, p, ws, device);
   if (algo == MLPG_HIP_ALGO_WAVE) return launch_wave(st, in_dtype, out_dtype, backward, p, ws, device);

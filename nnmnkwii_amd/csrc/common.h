@@ -58,7 +58,7 @@ struct StreamMap {
 
 void set_error(const char *fmt, ...);
 // Grow-only scratch, cached per (device, stream, slot): slot 0 generic factor, 1 fastdtw pyramids,
-// 2 generic status, 3 strip records.  Returns nullptr (and sets the error) on failure.
+// 2 generic status, 3 strip records, 4 constant-coefficient kernel (control words, records, factor table).  Returns nullptr (and sets the error) on failure.
 void *scratch(int device, hipStream_t stream, int slot, size_t bytes, unsigned long long *gen = nullptr);
 
 // launchers (one per translation unit)
@@ -79,6 +79,9 @@ bool unit_mse_supported(int Tmax, const WinSet &w);
 size_t unit_mse_workspace_bytes(int B, int sd);
 int launch_unit_mse(hipStream_t s, int dtype, const Problem &p, const WinSet &w, const void *target, void *y_out,
                     double n_elems, double *loss, void *workspace);
+bool const_supported(const Problem &p, const WinSet &w);
+bool const_preferred(const Problem &p, const WinSet &w);
+int launch_const(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
 bool pipe_supported(const Problem &p, const WinSet &w);
 int launch_pipe(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
 int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,

@@ -1,0 +1,14 @@
+#!/usr/bin/env bash
+# constant-coefficient kernel: parity tests, then timings and phase timers per shape (MLPG_CONST_SHAPE)
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_const_gpu.py -m gpu -x -q 2>&1 | tail -15
+for sh in 0 2 1; do
+  echo "=== shape $sh"
+  MLPG_CONST_SHAPE=$sh timeout 300 python tools/dbg/const_time.py 2>&1 | grep -v amdgpu.ids | grep "const\|ERR"
+done
+MLPG_HIP_EXTRA_FLAGS="-DMLPG_CONST_TIMING" python nnmnkwii_amd/csrc/build.py --quiet --only=mlpg_const_fwd_f64 > /tmp/build.log 2>&1 || { echo BUILD FAILED; tail -5 /tmp/build.log; }
+for sh in 0 2; do
+  echo "=== timers, shape $sh"
+  MLPG_CONST_SHAPE=$sh timeout 120 python tools/dbg/const_timing.py 256 1000 60 f64 global 2>&1 | grep -v amdgpu.ids
+done
