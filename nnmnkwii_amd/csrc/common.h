@@ -80,6 +80,8 @@ size_t unit_mse_workspace_bytes(int B, int sd);
 int launch_unit_mse(hipStream_t s, int dtype, const Problem &p, const WinSet &w, const void *target, void *y_out,
                     double n_elems, double *loss, void *workspace);
 bool const_supported(const Problem &p, const WinSet &w);
+// true once per scratch allocation (device, stream): the constant-coefficient kernel's table holds nothing yet
+bool const_scratch_fresh(int device, hipStream_t stream, unsigned long long gen);
 bool const_preferred(const Problem &p, const WinSet &w);
 int launch_const(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
 bool pipe_supported(const Problem &p, const WinSet &w);

@@ -1,6 +1,8 @@
 // Constant-coefficient MLPG kernels (global / unit variances): dispatch.  The kernels live in mlpg_const_impl.h and
 // are instantiated per dtype in mlpg_const_{fwd,bwd}_{f32,f64}.hip so that they compile in parallel.
-#include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "common.h"
 
 namespace mlpg {
@@ -10,10 +12,18 @@ int launch_const_fwd_f32(hipStream_t st, int out_dtype, const Problem &p, const 
 int launch_const_bwd_f64(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, int device, int shape);
 int launch_const_bwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, int device, int shape);
 
-namespace {
-constexpr int kConstNotResident = -1000;  // = cst::kNotResident (mlpg_const_impl.h)
-constexpr int kMaxStrips = 1024;          // strips of one utterance (32 frames each at the small shape)
-}  // namespace
+bool const_scratch_fresh(int device, hipStream_t stream, unsigned long long gen) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, unsigned long long> seen;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  // never trusted while the stream is being captured into a graph: a replay may follow launches this has not seen
+  const bool capturing = hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+  std::lock_guard<std::mutex> lk(mu);
+  unsigned long long &g = seen[{device, stream}];
+  const bool fresh = capturing || g != gen;
+  g = capturing ? 0ull : gen;
+  return fresh;
+}
 
 // Global (D,) or unit variances, windows of extent <= 1 with at least one dynamic window (mw == 1), two or three
 // windows, dense dims (no stream pieces).
@@ -25,38 +35,28 @@ bool const_supported(const Problem &p, const WinSet &ws) {
     if (ws.l[w] > 1 || ws.u[w] > 1) return false;
   if (p.pitch && p.pitch != p.sd) return false;
   if (p.Tmax < 1 || p.sd < 1 || p.B < 1) return false;
-  if ((p.Tmax + 31) / 32 > kMaxStrips) return false;
   return true;
 }
 
-// AUTO: lanes = static dims, so narrow streams (lf0: 1 dim, bap: 5) stay with the wave-per-system kernel.
+// AUTO (measured on MI355X, tools/dbg/const_time.py): one workgroup walks one (utterance, dim group) sequence, so the
+// launch needs about one sequence per CU to fill the chip (256 x 1000 x 60 float64: 0.148 ms against 0.205 ms for the
+// wave-per-system kernel and 0.190 ms for the strip kernel; 512 x 2000 x 60: 0.46 against 0.94 / 0.70 ms), and lanes are
+// static dims, so narrow streams (lf0: 1 dim, bap: 5) and small batches (64 x 500 x 60: 0.050 against 0.041 ms) stay
+// with the wave-per-system kernel.
 bool const_preferred(const Problem &p, const WinSet &ws) {
   if (!const_supported(p, ws)) return false;
   const int ndg = (p.sd + 63) / 64, dgw = (p.sd + ndg - 1) / ndg;
-  return dgw >= 16;
+  return dgw >= 32 && (long)p.B * ndg >= 192;
 }
 
 int launch_const(hipStream_t st, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &ws,
                  int device) {
-  // shape 0: 32-frame chunks, 4 per strip (128-frame strips); shape 1: 16-frame chunks, 2 per strip -- when the
-  // launch has too few 128-frame strips to fill the machine
-  const int ndg = (p.sd + 63) / 64;
-  const long big_items = (long)p.B * ndg * ((p.Tmax + 127) / 128);
-  int shape = big_items >= 1024 ? 0 : 1;
-  if (const char *e = getenv("MLPG_CONST_SHAPE")) shape = atoi(e);  // experiments: 0 = 32 x 4, 1 = 16 x 2, 2 = 16 x 8
-  int rc;
+  const int shape = 0;  // 16-frame chunks, 8 per super-step, one workgroup per CU (mlpg_const_impl.h: launch_t)
   if (!backward)
-    rc = dtype == MLPG_HIP_F32 ? launch_const_fwd_f32(st, out_dtype, p, ws, device, shape)
-                               : launch_const_fwd_f64(st, out_dtype, p, ws, device, shape);
-  else
-    rc = dtype == MLPG_HIP_F32 ? launch_const_bwd_f32(st, out_dtype, p, ws, device, shape)
+    return dtype == MLPG_HIP_F32 ? launch_const_fwd_f32(st, out_dtype, p, ws, device, shape)
+                                 : launch_const_fwd_f64(st, out_dtype, p, ws, device, shape);
+  return dtype == MLPG_HIP_F32 ? launch_const_bwd_f32(st, out_dtype, p, ws, device, shape)
                                : launch_const_bwd_f64(st, out_dtype, p, ws, device, shape);
-  if (rc == kConstNotResident) {
-    // fewer workgroups can be resident than an utterance has strips: nothing was enqueued
-    return wave_supported(p, ws) ? launch_wave(st, dtype, out_dtype, backward, p, ws, device)
-                                 : launch_generic(st, dtype, out_dtype, backward, p, ws, device);
-  }
-  return rc;
 }
 
 }  // namespace mlpg

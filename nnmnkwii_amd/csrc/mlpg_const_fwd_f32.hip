@@ -2,10 +2,13 @@
 #include "mlpg_const_impl.h"
 namespace mlpg {
 int launch_const_fwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, int device, int shape) {
-  const cst::Plan q = shape == 0 ? cst::make_plan(p, 32, 4) : shape == 2 ? cst::make_plan(p, 16, 8) : shape == 3 ? cst::make_plan(p, 16, 4) : cst::make_plan(p, 16, 2);
-  void *sc = scratch(device, st, 4, q.total);
+  const cst::Plan q = cst::make_plan(p, 16, 8);
+  (void)shape;
+  unsigned long long gen = 0;
+  void *sc = scratch(device, st, 4, q.total, &gen);
   if (!sc) return MLPG_HIP_ENOMEM;
+  const bool fresh = const_scratch_fresh(device, st, gen);
   (void)out_dtype;
-  return cst::launch_t<float, float, false>(st, p, ws, sc, q, true);
+  return cst::launch_t<float, float, false>(st, p, ws, sc, q, fresh);
 }
 }  // namespace mlpg

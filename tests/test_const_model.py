@@ -1,5 +1,6 @@
 """CPU: the numpy model of the constant-coefficient kernel (tools/const_model.py, the executable specification of
-csrc/mlpg_const_impl.h: factor once, second-order recurrences with chunk hand-overs of two numbers) against the oracle."""
+csrc/mlpg_const_impl.h: factor once, second-order recurrences, chunks aligned to the utterance's end, one-step lag with
+parked chunks, two-sweep fallback) against the oracle."""
 import os
 import sys
 
@@ -22,8 +23,8 @@ def rel_err(y, ref):
 @pytest.mark.parametrize("T", [1, 2, 3, 4, 15, 16, 17, 31, 32, 33, 34, 63, 64, 65, 66, 127, 129, 130, 200, 257, 600])
 def test_model_vs_oracle_global_variances(wname, T):
     m, _, vg = rand_case(wname, "f64", T, 3, salt=11)
-    for M, W in ((16, 2), (32, 4), (16, 1)):
-        if T > 300 and M != 32:
+    for M, W in ((16, 8), (16, 2), (8, 3)):
+        if T > 300 and W != 8:
             continue
         y, st = C.mlpg_const(m[None], vg, WINDOW_SETS[wname], M=M, W=W)
         assert not st.any()
@@ -43,17 +44,30 @@ def test_model_unit_variances_and_ragged_batch():
             assert not y[b, T:].any()
 
 
-def test_model_slow_decay_looks_back_over_many_strips():
-    """Dynamic features 100x / 10000x tighter than the static ones: the factor converges slowly and the
-    hand-over sums reach far -- same result."""
+def test_model_parks_chunks_and_falls_back_to_two_sweeps():
+    """Ordinary variances: the lowest chunks of a super-step wait for the next one (parked), nobody needs more.  Dynamic
+    features 100x / 10000x tighter than the static ones: the factor converges slowly, chunks far from the super-step's
+    bottom would have to wait too -- no slot -- and the utterance takes the two-sweep path.  Same result either way."""
     rng = np.random.RandomState(4)
-    var = np.array([1.0, 2.0, 1e-2, 3e-2, 1e-4, 2e-4])
     means = rng.randn(1, 700, 6)
     stats = {}
-    y, _ = C.mlpg_const(means, var, WINDOW_SETS["std3"], M=16, W=2, stats=stats)
+    var = rng.rand(6) + 0.1
+    y, _ = C.mlpg_const(means, var, WINDOW_SETS["std3"], stats=stats)
+    yo, _, rc = O.mlpg_batch(means, var, WINDOW_SETS["std3"])
+    assert rc == 0 and rel_err(y, yo) < 1e-12
+    assert stats["parked"] > 4 and stats["two_sweep"] == [False]
+    stats = {}
+    var = np.array([1.0, 2.0, 1e-2, 3e-2, 1e-4, 2e-4])
+    y, _ = C.mlpg_const(means, var, WINDOW_SETS["std3"], stats=stats)
     yo, _, rc = O.mlpg_batch(means, var, WINDOW_SETS["std3"])
     assert rc == 0 and rel_err(y, yo) < 1e-9
-    assert stats["i_s"] > 100 and max(stats["fwd_depth"]) > 4 and max(stats["bwd_depth"]) > 4
+    assert stats["i_s"] > 100 and stats["two_sweep"] == [True]
+    # few slots: the same happens with ordinary variances
+    stats = {}
+    var = rng.rand(6) + 0.1
+    y, _ = C.mlpg_const(means, var, WINDOW_SETS["std3"], stats=stats, slots=1)
+    yo, _, rc = O.mlpg_batch(means, var, WINDOW_SETS["std3"])
+    assert rc == 0 and rel_err(y, yo) < 1e-12 and stats["two_sweep"] == [True]
 
 
 def test_model_flags_negative_global_variance():

@@ -4,26 +4,21 @@ Global (D,) or unit variances: the precision matrix  P_d = sum_w W_w^T diag(tau_
 (d, T) only (/root/reference/nnmnkwii/paramgen/_mlpg.py:169-170 tiles the variances over the frames), not on the
 utterance.  The scheme:
 
-  setup (once per launch, or once per process for unit variances):
+  setup (once per set of variances):
     natural-order LDL^T of P_d for T = infinity, row by row, until the multipliers have converged to their steady
     state (row i_s); table[i] = (l1_i, l2_i, 1/d_i, d_i) for i <= i_s.  Rows T-2 and T-1 (the reference zeroes the
     dynamic precisions on the last frame, _mlpg.py:191-193) are re-derived per utterance from the table's state.
-  solve (lane = static dim, wavefront = chunk of M frames, workgroup = strip of W chunks):
+  solve (one workgroup walks one utterance; lane = static dim, wavefront = chunk of M frames, W chunks = a super-step):
     forward  z_i = b_i - l1_i z_{i-1} - l2_i z_{i-2}                  (L z = b)
     backward y_i = z_i / d_i - l1_{i+1} y_{i+1} - l2_{i+2} y_{i+2}    (L^T y = D^-1 z)
-    are second-order linear recurrences with data-independent coefficients.  A chunk runs them with zero incoming
-    state and hands over (g, A): its end state for zero input and the 2x2 transfer matrix of its rows; the true
-    incoming state of a chunk is  s = sum_k (A_{c-1} .. A_{c-k+1}) g_{c-k},  summed towards the utterance's start
-    until the product of transfer matrices is below `tol` (it decays geometrically: the depth depends on the
-    variances only, never on timing).  The same upwards for the backward recurrence (e, B).  Two exchange rounds per
-    strip, each with the nearest strips only for ordinary variances.
+    are second-order linear recurrences with data-independent coefficients.  See solve_utterance.
 
-The model mirrors the kernel's decomposition (chunks, strips, look-back) and is pinned against the oracle on the CPU
-(tests/test_const_model.py).  Test infrastructure only.
+The model mirrors the kernel's decomposition and is pinned against the oracle on the CPU (tests/test_const_model.py).
+Test infrastructure only.
 """
 import numpy as np
 
-TOL = 1e-22          # look-back stops once max|product of transfer matrices| is below this
+TOL = 2.0 ** -56          # a chunk waits for the next super-step unless the transfer from the super-step's bottom is below this
 CONV = 2.0 ** -50    # relative change below which the factor rows count as converged
 
 
@@ -140,7 +135,7 @@ def rhs_rows(mu, tau, wc, mw, T, a, M):
     b = np.zeros((M, sd))
     for k in range(M):
         i = a + k
-        if i >= T:
+        if i >= T or i < 0:
             continue
         for w in range(nw):
             cm, c0, cp = wc[w]
@@ -164,125 +159,139 @@ def amax(A):
     return max(float(np.max(np.abs(x))) for x in A)
 
 
-def solve_utterance(rhs_fn, T, co, M, W, tol=TOL, stats=None):
-    """y (T, sd) for one utterance.  rhs_fn(a, M) -> b rows (M, sd)."""
+def solve_utterance(rhs_fn, T, co, M, W, tol=TOL, stats=None, slots=None, lag_ok=True):
+    """y (T, sd) for one utterance, the way stream_kernel walks it.  rhs_fn(a, M) -> b rows (M, sd) of rows a .. a+M-1.
+
+    Chunks of M rows are aligned to the utterance's END (chunk j of NC covers rows T - (NC - j) M ..: the two tail rows
+    always are rows M-2, M-1 of the last chunk; chunk 0 may start above row 0, rows < 0 have a zero right-hand side and
+    stay zero).  W chunks side by side form a super-step.  The forward state is carried from super-step to super-step
+    (exact).  A chunk goes out at once if the chunks between it and its super-step's bottom damp whatever comes up from
+    below under `tol`; otherwise it is parked (at most `slots` chunks per super-step, the lowest ones) and goes out one
+    super-step later, with the upward state of the NEXT super-step solved with zero input from below.  A chunk that would
+    need a slot it does not have sends the utterance to the exact two-sweep path (forward sweep, then super-steps in
+    reverse order with the state from below carried exactly).  What the lag leaves out is the transfer matrix of a whole
+    steady super-step times the state below it: `lag_ok` (setup: that matrix is below `tol` for every dim and the
+    transient ends inside the first super-step) says whether the lag may be tried at all.
+    """
     sd = co(0)[0].shape[0]
-    S = M * W
-    R = (T + S - 1) // S
+    slots = W if slots is None else slots
+    NC = (T + M - 1) // M
+    K = (NC + W - 1) // W
     ident = (np.ones(sd), np.zeros(sd), np.zeros(sd), np.ones(sd))
     zero2 = (np.zeros(sd), np.zeros(sd))
-    # ---- pass 1 per chunk: local forward, transfer matrix
-    zhat, g, A = {}, {}, {}
-    for m in range(R):
-        for c in range(W):
-            a = (m * W + c) * M
-            b = rhs_fn(a, M)
-            z = np.zeros((M, sd))
-            h1 = [np.ones(sd), np.zeros(sd)]   # response to s = (1, 0): (h_{i-1}, h_{i-2})
-            h2 = [np.zeros(sd), np.ones(sd)]
-            zm1 = zm2 = np.zeros(sd)
-            for k in range(M):
-                l1, l2, _ = co(a + k)
-                z[k] = b[k] - l1 * zm1 - l2 * zm2
-                zm2, zm1 = zm1, z[k]
-                n1 = -l1 * h1[0] - l2 * h1[1]
-                n2 = -l1 * h2[0] - l2 * h2[1]
-                h1 = [n1, h1[0]]
-                h2 = [n2, h2[0]]
-            zhat[m, c] = z
-            g[m, c] = (zm1, zm2)
-            A[m, c] = (h1[0], h2[0], h1[1], h2[1])
-    # ---- strip level, forward: in-strip prefixes, strip totals
-    sl, Ap, G, As = {}, {}, {}, {}
-    for m in range(R):
-        s, P = zero2, ident
-        for c in range(W):
-            sl[m, c], Ap[m, c] = s, P
-            s = tuple(x + y for x, y in zip(g[m, c], mv(A[m, c], s)))
-            P = mm(A[m, c], P)
-        G[m], As[m] = s, P
-    # ---- look-back per strip, true z, local backward
-    yhat, e, B = {}, {}, {}
-    for m in range(R):
-        acc, depth = zero2, 0
-        if m > 0:
-            acc, P, k = G[m - 1], As[m - 1], 2
-            depth = 1
-            while m - k >= 0 and amax(P) >= tol:
-                acc = tuple(x + y for x, y in zip(acc, mv(P, G[m - k])))
-                P = mm(P, As[m - k])
-                k += 1
-                depth += 1
-        if stats is not None:
-            stats.setdefault("fwd_depth", []).append(depth)
-        for c in range(W):
-            a = (m * W + c) * M
-            s = tuple(x + y for x, y in zip(sl[m, c], mv(Ap[m, c], acc)))
-            z = zhat[m, c].copy()
-            dm1, dm2 = s
-            for k in range(M):
-                l1, l2, _ = co(a + k)
-                dl = -l1 * dm1 - l2 * dm2
-                z[k] += dl
-                dm2, dm1 = dm1, dl
-            # local backward over the true z
-            y = np.zeros((M, sd))
-            yp1 = yp2 = np.zeros(sd)
-            k1 = [np.ones(sd), np.zeros(sd)]   # response to t = (1, 0): (eps_{i+1}, eps_{i+2})
-            k2 = [np.zeros(sd), np.ones(sd)]
-            for k in range(M - 1, -1, -1):
-                i = a + k
-                dinv = co(i)[2]
-                l1n = co(i + 1)[0]
-                l2n = co(i + 2)[1]
-                y[k] = dinv * z[k] - l1n * yp1 - l2n * yp2
-                yp2, yp1 = yp1, y[k]
-                n1 = -l1n * k1[0] - l2n * k1[1]
-                n2 = -l1n * k2[0] - l2n * k2[1]
-                k1 = [n1, k1[0]]
-                k2 = [n2, k2[0]]
-            yhat[m, c] = y
-            e[m, c] = (yp1, yp2)                  # (y_a, y_{a+1})
-            B[m, c] = (k1[0], k2[0], k1[1], k2[1])
-    # ---- strip level, backward
-    tl, Bs, E, Bst = {}, {}, {}, {}
-    for m in range(R):
-        t, P = zero2, ident
-        for c in range(W - 1, -1, -1):
-            tl[m, c], Bs[m, c] = t, P
-            t = tuple(x + y for x, y in zip(e[m, c], mv(B[m, c], t)))
-            P = mm(B[m, c], P)
-        E[m], Bst[m] = t, P
-    out = np.zeros((R * S, sd))
-    for m in range(R):
-        acc, depth = zero2, 0
-        if m + 1 < R:
-            acc, P, k = E[m + 1], Bst[m + 1], 2
-            depth = 1
-            while m + k < R and amax(P) >= tol:
-                acc = tuple(x + y for x, y in zip(acc, mv(P, E[m + k])))
-                P = mm(P, Bst[m + k])
-                k += 1
-                depth += 1
-        if stats is not None:
-            stats.setdefault("bwd_depth", []).append(depth)
-        for c in range(W):
-            a = (m * W + c) * M
-            t = tuple(x + y for x, y in zip(tl[m, c], mv(Bs[m, c], acc)))
-            y = yhat[m, c].copy()
-            ep1, ep2 = t
-            for k in range(M - 1, -1, -1):
-                i = a + k
-                l1n = co(i + 1)[0]
-                l2n = co(i + 2)[1]
-                ep = -l1n * ep1 - l2n * ep2
-                y[k] += ep
-                ep2, ep1 = ep1, ep
-            out[a:a + M] = y
-    return out[:T]
+    out = np.zeros((NC * M, sd))     # row r of the utterance at index r - a00
+    a00 = T - NC * M
+
+    def coef(i):
+        if i < 0:
+            z = np.zeros(sd)
+            return z, z, z + 1.0
+        return co(i)
+
+    def local_forward(a, s):
+        b = rhs_fn(a, M)
+        z = np.zeros((M, sd))
+        zm1, zm2 = s
+        h1 = [np.ones(sd), np.zeros(sd)]
+        h2 = [np.zeros(sd), np.ones(sd)]
+        g1 = g2 = np.zeros(sd)
+        for k in range(M):
+            l1, l2, _ = coef(a + k)
+            z[k] = b[k] - l1 * zm1 - l2 * zm2
+            zm2, zm1 = zm1, z[k]
+            h1 = [-l1 * h1[0] - l2 * h1[1], h1[0]]
+            h2 = [-l1 * h2[0] - l2 * h2[1], h2[0]]
+        return z, (zm1, zm2), (h1[0], h2[0], h1[1], h2[1])
+
+    def local_backward(a, z, t):
+        y = np.zeros((M, sd))
+        yp1, yp2 = t
+        k1 = [np.ones(sd), np.zeros(sd)]
+        k2 = [np.zeros(sd), np.ones(sd)]
+        for k in range(M - 1, -1, -1):
+            i = a + k
+            dinv = coef(i)[2]
+            l1n = coef(i + 1)[0] if i + 1 < T else np.zeros(sd)
+            l2n = coef(i + 2)[1] if i + 2 < T else np.zeros(sd)
+            y[k] = dinv * z[k] - l1n * yp1 - l2n * yp2
+            yp2, yp1 = yp1, y[k]
+            k1 = [-l1n * k1[0] - l2n * k1[1], k1[0]]
+            k2 = [-l1n * k2[0] - l2n * k2[1], k2[0]]
+        return y, (yp1, yp2), (k1[0], k2[0], k1[1], k2[1])
+
+    def homog_up(a, t):
+        """response of the rows a .. a+M-1 to the state t below them"""
+        e = np.zeros((M, sd))
+        ep1, ep2 = t
+        for k in range(M - 1, -1, -1):
+            i = a + k
+            l1n = coef(i + 1)[0] if i + 1 < T else np.zeros(sd)
+            l2n = coef(i + 2)[1] if i + 2 < T else np.zeros(sd)
+            e[k] = -l1n * ep1 - l2n * ep2
+            ep2, ep1 = ep1, e[k]
+        return e
+
+    def sweep(lag):
+        """lag=True: the one-step lag with parking; returns False if some chunk found no slot.  lag=False: two sweeps."""
+        S = zero2
+        parked = []          # (j, y-hat, tl, Bs) of the previous super-step
+        zs = {}
+        for k in range(K):
+            js = [j for j in range(k * W, min(NC, (k + 1) * W))]
+            # local forward with the true incoming state (prefix through the super-step's chunks)
+            yh, e, B = {}, {}, {}
+            s = S
+            for j in js:
+                a = T - (NC - j) * M
+                z, s, _ = local_forward(a, s)
+                zs[j] = z
+                yh[j], e[j], B[j] = local_backward(a, z, zero2)
+            S = s
+            # suffixes: the state below chunk j = tl_j + Bs_j T for the state T below the super-step
+            tl, Bs = {}, {}
+            t, P = zero2, ident
+            for j in reversed(js):
+                tl[j], Bs[j] = t, P
+                t = tuple(x + y for x, y in zip(e[j], mv(B[j], t)))
+                P = mm(B[j], P)
+            Ehat = t
+            if lag:
+                for (j, y, tlj, Bsj) in parked:
+                    a = T - (NC - j) * M
+                    tt = tuple(x + y_ for x, y_ in zip(tlj, mv(Bsj, Ehat)))
+                    out[a - a00:a - a00 + M] = y + homog_up(a, tt)
+                parked = []
+                for j in js:
+                    a = T - (NC - j) * M
+                    need = k < K - 1 and not amax(Bs[j]) < tol
+                    if not need:
+                        out[a - a00:a - a00 + M] = yh[j] + homog_up(a, tl[j])
+                    elif (k + 1) * W - 1 - j < slots:
+                        parked.append((j, yh[j], tl[j], Bs[j]))
+                        if stats is not None:
+                            stats["parked"] = stats.get("parked", 0) + 1
+                    else:
+                        return False
+        if lag:
+            return True
+        # two sweeps: the second in reverse order, the state from below carried exactly
+        t = zero2
+        for k in range(K - 1, -1, -1):
+            for j in reversed(range(k * W, min(NC, (k + 1) * W))):
+                a = T - (NC - j) * M
+                y, t, _ = local_backward(a, zs[j], t)
+                out[a - a00:a - a00 + M] = y
+        return True
+
+    ok = (lag_ok or K <= 1) and sweep(True)
+    if stats is not None:
+        stats.setdefault("two_sweep", []).append(not ok)
+    if not ok:
+        sweep(False)
+    return out[-a00:-a00 + T]
 
 
-def mlpg_const(means, variances, windows, lengths=None, M=32, W=4, tol=TOL, stats=None):
+def mlpg_const(means, variances, windows, lengths=None, M=16, W=8, tol=TOL, stats=None, slots=None):
     """Forward MLPG for a (B, Tmax, D) batch with global (D,) variances (None: unit). Returns (out, status)."""
     means = np.asarray(means, dtype=np.float64)
     B, Tmax, D = means.shape
@@ -296,6 +305,12 @@ def mlpg_const(means, variances, windows, lengths=None, M=32, W=4, tol=TOL, stat
     rows, i_s, kfail = factor_table(tau, wc, mw, max(Tmax, 4))
     if stats is not None:
         stats["i_s"] = i_s
+    # the transfer matrix of a steady super-step (M W rows)
+    l1, l2 = rows[i_s][0], rows[i_s][1]
+    P = (np.ones(sd), np.zeros(sd), np.zeros(sd), np.ones(sd))
+    for _ in range(M * W):
+        P = (-l1 * P[0] - l2 * P[2], -l1 * P[1] - l2 * P[3], P[0], P[1])
+    lag_ok = amax(P) < tol and i_s + 2 < M * W and not (kfail > 0).any()
     out = np.zeros((B, Tmax, sd))
     status = np.zeros((B, sd), dtype=np.int64)
     for b in range(B):
@@ -304,14 +319,14 @@ def mlpg_const(means, variances, windows, lengths=None, M=32, W=4, tol=TOL, stat
             continue
         co = Coefs(rows, i_s, T, tau, wc, mw)
         mu = means[b, :T].reshape(T, nw, sd)
-        y = solve_utterance(lambda a, m_: rhs_rows(mu, tau, wc, mw, T, a, m_), T, co, M, W, tol, stats)
+        y = solve_utterance(lambda a, m_: rhs_rows(mu, tau, wc, mw, T, a, m_), T, co, M, W, tol, stats, slots, lag_ok)
         failed = ((kfail > 0) & (kfail - 1 < T - 2)) | co.tail_bad
         out[b, :T] = np.where(failed[None, :], 0.0, y)
         status[b] = np.where(failed, -1, 0)
     return out, status
 
 
-def mlpg_const_backward(variances, windows, grad_out, lengths=None, M=32, W=4, tol=TOL):
+def mlpg_const_backward(variances, windows, grad_out, lengths=None, M=16, W=8, tol=TOL):
     """grad wrt the means: grad[t, w*sd+d] = tau_w(t) (W_w z)[t], z = P^-1 grad_out[:, d]."""
     grad_out = np.asarray(grad_out, dtype=np.float64)
     B, Tmax, sd = grad_out.shape
@@ -332,9 +347,9 @@ def mlpg_const_backward(variances, windows, grad_out, lengths=None, M=32, W=4, t
 
         def rhs(a, m_):
             r = np.zeros((m_, sd))
-            hi = min(T, a + m_)
-            if hi > a:
-                r[:hi - a] = go[a:hi]
+            lo, hi = max(0, a), min(T, a + m_)
+            if hi > lo:
+                r[lo - a:hi - a] = go[lo:hi]
             return r
         z = solve_utterance(rhs, T, co, M, W, tol)
         zp = np.zeros((T + 2, sd))

@@ -7,9 +7,9 @@ sys.path.insert(0, ".")
 from nnmnkwii_amd import _hip
 
 W3 = [(0, 0, np.array([1.0])), (1, 1, np.array([-0.5, 0.0, 0.5])), (1, 1, np.array([1.0, -2.0, 1.0]))]
-NAMES = ["setup", "pass1a+1b", "B0+B1", "pre/pub/look", "B2", "pass2", "B3", "suf/pub/look", "B4", "pass3", "stores", "ticket",
-         "items", "edge", "lb", "la", "pub fwd", "flag wait fwd", "records fwd", "pub bwd", "flag wait bwd", "records bwd", "-", "-"]
-NT = 24
+NAMES = ["other", "pass1a", "B0", "halo+pass1b", "B1", "prefix+pass2", "B2+B3", "suffix", "parked out", "own out/park", "verdict",
+         "-", "super-steps", "parked", "sequences", "-"]
+NT = 16
 
 
 def main():
@@ -43,22 +43,18 @@ def main():
         ts.append(e0.elapsed_time(e1))
     print("B %d T %d sd %d %s %s %s: median %.4f ms, min %.4f" % (B, T, sd, dt, "unit" if unit else "global", "bwd" if bwd else "fwd", np.median(ts), np.min(ts)))
     st = st.cpu().numpy()
-    n = (len(st) // NT)
+    W = 8
+    n = len(st) // NT
     q = st[:n * NT].reshape(n, NT).astype(np.float64)
     q[:, :12] *= 16
-    q[:, 16:] *= 16
     q = q[q[:, 12] > 0]
+    print("waves with work: %d; cycles per super-step by phase (mean over waves | wave 0 | wave 7):" % len(q))
     wv = np.arange(len(q)) % W
-    print("waves with items: %d; cycles per item by phase (wave 0 | other waves):" % len(q))
-    for k in range(12):
-        a0 = q[wv == 0, k].sum() / q[wv == 0, 12].sum()
-        a1 = q[wv != 0, k].sum() / max(1.0, q[wv != 0, 12].sum())
-        print("  %-14s %9.0f | %9.0f" % (NAMES[k], a0, a1))
-    for k in range(16, 22):
-        print("  %-14s %9.0f |" % (NAMES[k], q[wv == 0, k].sum() / q[wv == 0, 12].sum()))
-    tot0 = q[wv == 0, :12].sum() / q[wv == 0, 12].sum()
-    print("  total per item %.0f cycles; items per wave %.1f; edge chunk share %.3f; look-back %.2f, look-ahead %.2f steps per item" % (
-        tot0, q[:, 12].mean(), q[:, 13].sum() / q[:, 12].sum(), q[wv == 0, 14].sum() / q[wv == 0, 12].sum(), q[wv == 0, 15].sum() / q[wv == 0, 12].sum()))
+    for k in range(11):
+        f = lambda sel: q[sel, k].sum() / max(1.0, q[sel, 12].sum())
+        print("  %-14s %9.0f | %9.0f | %9.0f" % (NAMES[k], f(slice(None)), f(wv == 0), f(wv == W - 1)))
+    print("  total per super-step %.0f cycles; super-steps per wave %.1f; parked share %.2f; sequences per wave %.1f" % (
+        q[:, :11].sum() / q[:, 12].sum(), q[:, 12].mean(), q[:, 13].sum() / q[:, 12].sum(), q[:, 14].mean()))
 
 
 if __name__ == "__main__":
