@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--static-dim", type=int, default=60)
-    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 generic, 2 wave-per-system, 3 strip, 4 pipelined strip")
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 generic, 2 wave-per-system, 3 strip, 5 constant-coefficient (global / unit variances)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing test only (no GPU, gloo): the launch / barrier / reduction / JSON path with a no-op step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -520,7 +520,7 @@ def main():
         frames = world * B * T * args.steps
         alg_bytes = 56.0 * sd * B * T            # 56 B per (frame, static dim) per launch
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms else None
-        algo_names = {0: "auto", 1: "generic", 2: "wave-per-system", 3: "strip", 4: "pipelined strip (mlpg::pipe::pipe_kernel)"}
+        algo_names = {0: "auto", 1: "generic", 2: "wave-per-system", 3: "strip", 4: "strip (algo 4 retired)", 5: "constant-coefficient"}
         res = {
             "metric": "MLPG frames/sec (batch, 60-dim mgc x3 windows)",
             "value": frames / elapsed,

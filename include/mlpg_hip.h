@@ -58,14 +58,18 @@ extern "C" {
 #define MLPG_HIP_ALGO_GENERIC 1 /* thread-per-system, factor in HBM scratch       */
 #define MLPG_HIP_ALGO_WAVE 2    /* wave-per-system, factor in registers           */
 #define MLPG_HIP_ALGO_STRIP 3   /* lane-per-static-dim, wavefront per 16-frame chunk, any T */
-#define MLPG_HIP_ALGO_PIPE 4    /* the strip scheme software-pipelined: 3 chunk wavefronts + 1 chain wavefront per CU,
-                                   level 1 of item s+1 runs under the level-2/3 latency chain of item s (3 windows) */
+#define MLPG_HIP_ALGO_PIPE 4    /* retired in ABI 11 (the software-pipelined strip kernel of round 3, now under
+                                   tools/experimental/pipe): selects the strip kernel */
 #define MLPG_HIP_ALGO_CONST 5   /* global (D,) / unit variances: the matrix of a static dim is the same for every
                                    utterance (_mlpg.py:169-170 tiles the variances) -- factorised once per launch, the
                                    solves are constant-coefficient recurrences, lane-per-static-dim, any T */
 
 int mlpg_hip_abi_version(void);
 const char *mlpg_hip_last_error(void);
+/* Test aid, not part of the reference's interface: launches per MLPG kernel family since the library was loaded --
+ * 0 natural-order, 1 wave-per-system, 2 strip, 3 strip with several streams merged, 4 constant-coefficient, 5 fused
+ * unit-variance step; -1 for any other `kind`.  (Tests use it to assert WHICH kernel a call took.) */
+long long mlpg_hip_launch_count(int kind);
 int mlpg_hip_device_count(void);
 /* Frees the per-device scratch caches. */
 void mlpg_hip_shutdown(void);
@@ -150,7 +154,7 @@ int mlpg_hip_forward_host(int device, int dtype, int algo, const void *mean_h,
  */
 int mlpg_hip_fastdtw_host(int device, int dtype, const void *X_h, const void *Y_h,
                           const int32_t *lenx_h, const int32_t *leny_h, int N, int Tx, int Ty, int D,
-                          int radius, int dist_kind, double dist_scale, double trim_eps,
+                          int radius, int dist_kind, double dist_scale, int tie_rule, double trim_eps,
                           int32_t *path_i_h, int32_t *path_j_h, int32_t *path_len_h, double *cost_h,
                           int32_t *lenx_out_h, int32_t *leny_out_h);
 /* Pinned host memory for arrays that are handed to mlpg_hip_forward_host repeatedly (transferred in place). */
@@ -305,13 +309,53 @@ int mlpg_hip_trim_lengths(int device, void *stream, int dtype, const void *X,
 #define MLPG_HIP_DIST_SCALED_SQL2_NP 3 /* dist_scale * ((x-y)**2).sum(): squared Euclidean, numpy's pairwise order
                                         (what DTWAligner(dist=...) callables of those forms resolve to; the reference
                                         accepts any Python callable, alignment.py:35 -- the kernel evaluates the cost) */
+/* tie rules of the DP recurrence D[i,j] = dt + min(D[i-1,j], D[i,j-1], D[i-1,j-1]) when candidates are EQUAL (after
+ * adding dt).  The reference does not pin fastdtw's version, and the package ships two implementations of the
+ * recurrence that differ only here; continuous data never tie, quantised or shifted-copy data
+ * (tests/test_preprocessing.py:441-456 aligns zero-shifted copies) do. */
+#define MLPG_HIP_TIE_FIRST_MIN 0 /* upstream's pure-Python __dtw: min(..., key=) keeps the FIRST minimum of
+                                    (up, left, diagonal) -- the rule every parity test of this repo is pinned on */
+#define MLPG_HIP_TIE_DIAG_LAST 1 /* the strict-less chain recalled for upstream's compiled _fastdtw: up only if it
+                                    beats both others, else left only if it beats the diagonal, else the diagonal.
+                                    UNVERIFIED: the package is absent from this image (and from /root/reference);
+                                    tests/test_dtw_gpu.py reports which rule an installed fastdtw follows */
 int mlpg_hip_fastdtw(int device, void *stream, const double *X,
                      const double *Y, const int32_t *lenx,
                      const int32_t *leny, int N, int Tx, int Ty, int D,
                      int radius, int dist_kind, double dist_scale,
-                     int32_t *path_i, int32_t *path_j,
+                     int tie_rule, int32_t *path_i, int32_t *path_j,
                      int32_t *path_len, double *cost);
-/* = mlpg_hip_fastdtw(..., MLPG_HIP_DIST_L2, 1.0, ...) */
+/*
+ * fastdtw for `dist` callables no device-side cost reproduces (preprocessing/alignment.py:35-38 accepts ANY Python
+ * callable): one resolution level at a time, the local costs evaluated on the host by the user's callable, the DP
+ * recurrence, the back-trace and the window expansion (upstream's __expand_window in interval form) on the device.
+ * The caller walks the levels from the coarsest to the finest (nnmnkwii_amd/preprocessing/alignment.py shows how):
+ *
+ *   mlpg_hip_dtw_level_windows   level_tx / level_ty: int32[N], the pair's lengths at THIS level (0: the pair's
+ *       recursion has not reached the level yet, it is skipped); full[n] != 0: the pair's recursion bottoms out here
+ *       (len < radius + 2: full window); otherwise the window comes from cpath_* = the pair's path at the level below
+ *       (coarser), as mlpg_hip_dtw_level_from_costs left it.  Out: row_lo / row_hi (N, row_stride) inclusive column
+ *       intervals, row_off (N, row_stride + 1) prefix sums of the widths (row_off[n, level_tx[n]] = cells of pair n).
+ *   mlpg_hip_dtw_level_from_costs   costs: float64, pair n's cells at costs[cost_base[n] + row_off[n, i] + j - row_lo[n, i]]
+ *       (total_cells doubles in all), max_ty >= every level_ty.  Out: path_i / path_j (N, path_stride), path_len[n]
+ *       (0: the corner is unreachable), cost[n] = D[len_x, len_y].  tie_rule: MLPG_HIP_TIE_*.
+ * All pointers are device pointers; both calls only enqueue work on `stream`.
+ */
+int mlpg_hip_dtw_level_windows(int device, void *stream, int N, int radius,
+                               const int32_t *level_tx, const int32_t *level_ty,
+                               const int32_t *full, const int32_t *cpath_i,
+                               const int32_t *cpath_j, const int32_t *cpath_len,
+                               int cpath_stride, int32_t *row_lo, int32_t *row_hi,
+                               int64_t *row_off, int row_stride);
+int mlpg_hip_dtw_level_from_costs(int device, void *stream, int N, int tie_rule,
+                                  const int32_t *level_tx, const int32_t *level_ty,
+                                  const int32_t *row_lo, const int32_t *row_hi,
+                                  const int64_t *row_off, int row_stride, int max_ty,
+                                  const double *costs, const int64_t *cost_base,
+                                  int64_t total_cells, int32_t *path_i,
+                                  int32_t *path_j, int32_t *path_len,
+                                  int path_stride, double *cost);
+/* = mlpg_hip_fastdtw(..., MLPG_HIP_DIST_L2, 1.0, MLPG_HIP_TIE_FIRST_MIN, ...) */
 int mlpg_hip_fastdtw_l2(int device, void *stream, const double *X,
                         const double *Y, const int32_t *lenx,
                         const int32_t *leny, int N, int Tx, int Ty, int D,

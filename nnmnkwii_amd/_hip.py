@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 F32, F64 = 0, 1
-ABI_VERSION = 10               # mlpg_hip_abi_version() of the library this binding was written for
+ABI_VERSION = 11               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE, ALGO_STRIP, ALGO_PIPE, ALGO_CONST = 0, 1, 2, 3, 4, 5
 
@@ -23,6 +23,7 @@ SO_PATH = os.environ.get("NNMNKWII_AMD_SO") or os.path.join(_HERE, "csrc", "libm
 
 EXPORTS = (
     "mlpg_hip_abi_version",
+    "mlpg_hip_launch_count",
     "mlpg_hip_last_error",
     "mlpg_hip_device_count",
     "mlpg_hip_shutdown",
@@ -41,6 +42,8 @@ EXPORTS = (
     "mlpg_hip_modspec_set_direct",
     "mlpg_hip_trim_lengths",
     "mlpg_hip_fastdtw",
+    "mlpg_hip_dtw_level_windows",
+    "mlpg_hip_dtw_level_from_costs",
     "mlpg_hip_fastdtw_l2",
     "mlpg_hip_gather_path",
     "mlpg_hip_gmm_convert",
@@ -77,6 +80,8 @@ def lib():
         vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
         L.mlpg_hip_abi_version.restype = ci
         L.mlpg_hip_abi_version.argtypes = []
+        L.mlpg_hip_launch_count.restype = ctypes.c_longlong
+        L.mlpg_hip_launch_count.argtypes = [ci]
         L.mlpg_hip_last_error.restype = ctypes.c_char_p
         L.mlpg_hip_last_error.argtypes = []
         L.mlpg_hip_device_count.restype = ci
@@ -88,7 +93,7 @@ def lib():
         L.mlpg_hip_forward_host.restype = ci
         L.mlpg_hip_forward_host.argtypes = [ci, ci, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
         L.mlpg_hip_fastdtw_host.restype = ci
-        L.mlpg_hip_fastdtw_host.argtypes = [ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_double, ctypes.c_double,
+        L.mlpg_hip_fastdtw_host.argtypes = [ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_double, ci, ctypes.c_double,
                                             vp, vp, vp, vp, vp, vp]
         L.mlpg_hip_host_alloc.restype = vp
         L.mlpg_hip_host_alloc.argtypes = [ctypes.c_size_t]
@@ -115,8 +120,13 @@ def lib():
         L.mlpg_hip_trim_lengths.argtypes = [ci, vp, ci, vp, ci, ci, ci, cd, vp]
         L.mlpg_hip_fastdtw_l2.restype = ci
         L.mlpg_hip_fastdtw_l2.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
+        L.mlpg_hip_dtw_level_windows.restype = ci
+        L.mlpg_hip_dtw_level_windows.argtypes = [ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci]
+        L.mlpg_hip_dtw_level_from_costs.restype = ci
+        L.mlpg_hip_dtw_level_from_costs.argtypes = [ci, vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, vp, ctypes.c_longlong, vp, vp, vp,
+                                                    ci, vp]
         L.mlpg_hip_fastdtw.restype = ci
-        L.mlpg_hip_fastdtw.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cd, vp, vp, vp, vp]
+        L.mlpg_hip_fastdtw.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cd, ci, vp, vp, vp, vp]
         L.mlpg_hip_gmm_convert.restype = ci
         L.mlpg_hip_gmm_convert.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
         L.mlpg_hip_gather_path.restype = ci
@@ -493,11 +503,12 @@ def trim_lengths(X, eps=1e-7):
 
 
 DIST_L2, DIST_SCALED_L2_NP, DIST_SCALED_L1_NP, DIST_SCALED_SQL2_NP = 0, 1, 2, 3
+TIE_FIRST_MIN, TIE_DIAG_LAST = 0, 1   # include/mlpg_hip.h MLPG_HIP_TIE_*
 
 
-def fastdtw_l2(X, Y, lenx, leny, radius=1, dist_kind=DIST_L2, dist_scale=1.0):
+def fastdtw_l2(X, Y, lenx, leny, radius=1, dist_kind=DIST_L2, dist_scale=1.0, tie_rule=TIE_FIRST_MIN):
     """fastdtw paths for N pairs. Returns (path_i, path_j (N, Tx+Ty) int32, path_len (N,), cost (N,)).
-    dist_kind / dist_scale: the local distance (include/mlpg_hip.h MLPG_HIP_DIST_*)."""
+    dist_kind / dist_scale: the local distance (include/mlpg_hip.h MLPG_HIP_DIST_*); tie_rule: MLPG_HIP_TIE_*."""
     torch = torch_mod()
     assert X.is_cuda and Y.is_cuda and X.dtype == torch.float64 and Y.dtype == torch.float64
     assert X.is_contiguous() and Y.is_contiguous() and X.dim() == 3 and Y.dim() == 3
@@ -510,13 +521,85 @@ def fastdtw_l2(X, Y, lenx, leny, radius=1, dist_kind=DIST_L2, dist_scale=1.0):
     path_len = torch.empty((N,), dtype=torch.int32, device=dev)
     cost = torch.empty((N,), dtype=torch.float64, device=dev)
     rc = lib().mlpg_hip_fastdtw(dev.index, _stream(dev), _p(X), _p(Y), _p(lenx), _p(leny), N, Tx, Ty, D,
-                                int(radius), int(dist_kind), float(dist_scale), _p(path_i), _p(path_j), _p(path_len),
-                                _p(cost))
+                                int(radius), int(dist_kind), float(dist_scale), int(tie_rule), _p(path_i), _p(path_j),
+                                _p(path_len), _p(cost))
     _check(rc, "mlpg_hip_fastdtw")
     return path_i, path_j, path_len, cost
 
 
-def fastdtw_host(X, Y, radius=1, dist_kind=DIST_L2, dist_scale=1.0, lenx=None, leny=None, eps=1e-7, device=None):
+def fastdtw_callable(xs, ys, radius, dist, tie_rule=TIE_FIRST_MIN, device=None):
+    """fastdtw of N pairs for an ARBITRARY Python ``dist`` (what the reference hands to fastdtw, alignment.py:35-50):
+    level by level from the coarsest, the local costs of each level's window cells evaluated HERE by ``dist`` -- one
+    call per cell, as upstream fastdtw does -- and the DP recurrence, the back-trace and the window expansion on the GPU
+    (mlpg_hip_dtw_level_windows / mlpg_hip_dtw_level_from_costs).  xs, ys: lists of (T, D) arrays (already trimmed).
+    Returns numpy (path_i, path_j (N, max(tx+ty)) int32, path_len (N,), cost (N,) float64)."""
+    torch = torch_mod()
+    dev = require_gpu(device)
+    N = len(xs)
+    r = int(radius)
+    # the halving pyramids, exactly upstream's __reduce_by_half (pairwise means, odd tail dropped), in float64
+    px, py, Kn = [], [], []
+    for x, y in zip(xs, ys):
+        lx, ly = [np.asanyarray(x, dtype="float")], [np.asanyarray(y, dtype="float")]
+        while not (len(lx[-1]) < r + 2 or len(ly[-1]) < r + 2):
+            for l in (lx, ly):
+                a = l[-1]
+                h = len(a) // 2
+                l.append((a[0:2 * h:2] + a[1:2 * h:2]) / 2)
+        px.append(lx)
+        py.append(ly)
+        Kn.append(len(lx) - 1)
+    tx0 = np.asarray([len(l[0]) for l in px], dtype=np.int64)
+    ty0 = np.asarray([len(l[0]) for l in py], dtype=np.int64)
+    row_stride = int(tx0.max())
+    max_ty = int(ty0.max())
+    path_stride = int((tx0 + ty0).max())
+    i32 = dict(dtype=torch.int32, device=dev)
+    path_i = torch.zeros((N, path_stride), **i32)
+    path_j = torch.zeros((N, path_stride), **i32)
+    path_len = torch.zeros((N,), **i32)
+    cost = torch.zeros((N,), dtype=torch.float64, device=dev)
+    row_lo = torch.zeros((N, row_stride), **i32)
+    row_hi = torch.zeros((N, row_stride), **i32)
+    row_off = torch.zeros((N, row_stride + 1), dtype=torch.int64, device=dev)
+    st = _stream(dev)
+    L = lib()
+    for k in range(max(Kn), -1, -1):
+        ltx = np.asarray([(int(tx0[n]) >> k) if k <= Kn[n] else 0 for n in range(N)], dtype=np.int32)
+        lty = np.asarray([(int(ty0[n]) >> k) if k <= Kn[n] else 0 for n in range(N)], dtype=np.int32)
+        full = np.asarray([1 if k == Kn[n] else 0 for n in range(N)], dtype=np.int32)
+        d_tx, d_ty, d_full = (torch.from_numpy(a).to(dev) for a in (ltx, lty, full))
+        _check(L.mlpg_hip_dtw_level_windows(dev.index, st, N, r, _p(d_tx), _p(d_ty), _p(d_full), _p(path_i), _p(path_j),
+                                            _p(path_len), path_stride, _p(row_lo), _p(row_hi), _p(row_off), row_stride),
+               "mlpg_hip_dtw_level_windows")
+        lo, hi, off = row_lo.cpu().numpy(), row_hi.cpu().numpy(), row_off.cpu().numpy()
+        ncell = np.asarray([int(off[n, ltx[n]]) if ltx[n] > 0 else 0 for n in range(N)], dtype=np.int64)
+        base = np.concatenate([[0], np.cumsum(ncell)]).astype(np.int64)
+        costs = np.empty(max(1, int(base[-1])), dtype=np.float64)
+        for n in range(N):
+            if ltx[n] <= 0:
+                continue
+            xk, yk = px[n][k], py[n][k]
+            q = int(base[n])
+            for i in range(int(ltx[n])):
+                xi = xk[i]
+                for j in range(int(lo[n, i]), int(hi[n, i]) + 1):
+                    costs[q] = dist(xi, yk[j])          # the user's callable, once per window cell
+                    q += 1
+        d_costs = torch.from_numpy(costs).to(dev)
+        d_base = torch.from_numpy(base[:N].copy()).to(dev)
+        _check(L.mlpg_hip_dtw_level_from_costs(dev.index, st, N, int(tie_rule), _p(d_tx), _p(d_ty), _p(row_lo), _p(row_hi),
+                                               _p(row_off), row_stride, max_ty, _p(d_costs), _p(d_base), int(base[-1]),
+                                               _p(path_i), _p(path_j), _p(path_len), path_stride, _p(cost)),
+               "mlpg_hip_dtw_level_from_costs")
+        torch.cuda.current_stream(dev).synchronize()     # the level's host buffers are released only now
+    pl = path_len.cpu().numpy()
+    pi, pj = path_i.cpu().numpy(), path_j.cpu().numpy()
+    return pi, pj, pl, cost.cpu().numpy()
+
+
+def fastdtw_host(X, Y, radius=1, dist_kind=DIST_L2, dist_scale=1.0, lenx=None, leny=None, eps=1e-7, device=None,
+                 tie_rule=TIE_FIRST_MIN):
     """fastdtw paths for N pairs held in numpy arrays (no framework tensor): mlpg_hip_fastdtw_host, chunked and
     overlapped with the transfers.  X (N, Tx, D), Y (N, Ty, D) float32 / float64.  Without lengths the trailing
     all-zero frames are trimmed on the device (eps as trim_zeros_frames).  Returns numpy
@@ -544,7 +627,7 @@ def fastdtw_host(X, Y, radius=1, dist_kind=DIST_L2, dist_scale=1.0, lenx=None, l
         leny = np.ascontiguousarray(leny, dtype=np.int32)
     rc = L.mlpg_hip_fastdtw_host(int(device), F32 if X.dtype == np.float32 else F64, _np(X), _np(Y),
                                  None if lenx is None else _np(lenx), None if leny is None else _np(leny), N, Tx, Ty, D,
-                                 int(radius), int(dist_kind), float(dist_scale), float(eps), _np(path_i), _np(path_j),
+                                 int(radius), int(dist_kind), float(dist_scale), int(tie_rule), float(eps), _np(path_i), _np(path_j),
                                  _np(path_len), _np(cost), _np(lx_out), _np(ly_out))
     _check(rc, "mlpg_hip_fastdtw_host")
     return path_i, path_j, path_len, cost, lx_out, ly_out

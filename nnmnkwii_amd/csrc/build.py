@@ -7,13 +7,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["capi.hip", "host_api.hip", "mlpg_generic.hip", "mlpg_wave.hip", "mlpg_wave_fwd_f64.hip", "mlpg_wave_fwd_f32.hip",
            "mlpg_wave_bwd_f64.hip", "mlpg_wave_bwd_f32.hip", "mlpg_wave_fused.hip", "mlpg_strip.hip", "mlpg_strip_fwd_f64.hip",
-           "mlpg_strip_fwd_f32.hip", "mlpg_strip_bwd_f64.hip", "mlpg_strip_bwd_f32.hip", "mlpg_strip_multi_f64.hip", "mlpg_strip_multi_f32.hip", "mlpg_const.hip", "mlpg_const_fwd_f64.hip", "mlpg_const_fwd_f32.hip", "mlpg_const_bwd_f64.hip", "mlpg_const_bwd_f32.hip", "mlpg_pipe.hip", "mlpg_pipe_fwd_f64.hip",
-           "mlpg_pipe_fwd_f32.hip", "mlpg_pipe_bwd_f64.hip", "mlpg_pipe_bwd_f32.hip", "dtw.hip", "dtw_fast.hip", "modspec.hip", "modspec_dft.hip"]
-HEADERS = ["common.h", "assemble.h", "mlpg_wave_impl.h", "mlpg_strip_impl.h", "mlpg_pipe_impl.h", "mlpg_const_impl.h", os.path.join("..", "..", "include", "mlpg_hip.h")]
+           "mlpg_strip_fwd_f32.hip", "mlpg_strip_bwd_f64.hip", "mlpg_strip_bwd_f32.hip", "mlpg_strip_multi_f64.hip", "mlpg_strip_multi_f32.hip", "mlpg_const.hip", "mlpg_const_fwd_f64.hip", "mlpg_const_fwd_f32.hip", "mlpg_const_bwd_f64.hip", "mlpg_const_bwd_f32.hip", "dtw.hip", "dtw_fast.hip", "dtw_costs.hip", "modspec.hip", "modspec_dft.hip"]
+HEADERS = ["common.h", "assemble.h", "mlpg_wave_impl.h", "mlpg_strip_impl.h", "mlpg_const_impl.h", os.path.join("..", "..", "include", "mlpg_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # The DTW kernels must round exactly like the CPU oracle (separate multiply and add); the MLPG
 # kernels are free to fuse multiply-adds.
-FILE_FLAGS = {"dtw_fast.hip": ["-ffp-contract=off"], "dtw.hip": ["-ffp-contract=off"], "modspec.hip": ["-ffp-contract=off"], "modspec_dft.hip": ["-ffp-contract=off"]}
+FILE_FLAGS = {"dtw_fast.hip": ["-ffp-contract=off"], "dtw.hip": ["-ffp-contract=off"], "dtw_costs.hip": ["-ffp-contract=off"], "modspec.hip": ["-ffp-contract=off"], "modspec_dft.hip": ["-ffp-contract=off"]}
 EXTRA = [f for f in os.environ.get("MLPG_HIP_EXTRA_FLAGS", "").split() if f]
 SO = os.path.join(HERE, "libmlpg_hip.so")
 
@@ -34,9 +33,7 @@ def _stale(target, deps):
 
 def _headers_of(src):
     """Headers a source depends on (the two big kernel headers only matter to their own instantiation files)."""
-    hs = [h for h in HEADERS if h not in ("mlpg_wave_impl.h", "mlpg_strip_impl.h", "mlpg_pipe_impl.h", "mlpg_const_impl.h")]
-    if src.startswith("mlpg_pipe_"):
-        hs += ["mlpg_strip_impl.h", "mlpg_pipe_impl.h"]
+    hs = [h for h in HEADERS if h not in ("mlpg_wave_impl.h", "mlpg_strip_impl.h", "mlpg_const_impl.h")]
     if src.startswith("mlpg_wave_"):
         hs.append("mlpg_wave_impl.h")
     if src.startswith("mlpg_strip_"):

@@ -23,6 +23,11 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+std::atomic<long long> g_launches[kCountKinds];
+void note_launch(int kind) {
+  if (kind >= 0 && kind < kCountKinds) g_launches[kind].fetch_add(1);
+}
+
 // ---- grow-only scratch, one set of buffers per (device, stream) ------------------------------
 // Launches on different streams of one device never share a buffer; a buffer is only ever
 // reused, grown or freed behind work of its own stream.
@@ -190,14 +195,9 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     set_error("MLPG_HIP_ALGO_CONST needs global or unit variances and 2-3 windows of extent <= 1 (var_mode %d, %d windows, T=%d)", p.var_mode, ws.nw, p.Tmax);
     return MLPG_HIP_EINVAL;
   }
-  if (algo == MLPG_HIP_ALGO_PIPE && !pipe_supported(p, ws)) {
-    // the pipelined kernel is the strip scheme for the usual three windows; other window sets of extent <= 1 run on
-    // the strip kernel itself
-    if (!strip_supported(p, ws)) {
-      set_error("MLPG_HIP_ALGO_PIPE does not support this problem (T=%d, %d windows, half-bandwidth %d)", p.Tmax, ws.nw, ws.q);
-      return MLPG_HIP_EINVAL;
-    }
-    algo = MLPG_HIP_ALGO_STRIP;
+  if (algo == MLPG_HIP_ALGO_PIPE) {
+    // retired (tools/experimental/pipe): the strip scheme it pipelined, or the kernel AUTO would take
+    algo = strip_supported(p, ws) ? MLPG_HIP_ALGO_STRIP : MLPG_HIP_ALGO_AUTO;
   }
   if (p.pitch && p.pitch != p.sd) {
     // a piece of a stream (window pitch != number of dims): the kernels that take the pitch separately
@@ -213,7 +213,6 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     else algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
   }
   if (algo == MLPG_HIP_ALGO_CONST) return launch_const(st, in_dtype, out_dtype, backward, p, ws, device);
-  if (algo == MLPG_HIP_ALGO_PIPE) return launch_pipe(st, in_dtype, out_dtype, backward, p, ws, device);
   if (algo == MLPG_HIP_ALGO_STRIP) return launch_strip(st, in_dtype, out_dtype, backward, p, ws, device);
   if (algo == MLPG_HIP_ALGO_WAVE) return launch_wave(st, in_dtype, out_dtype, backward, p, ws, device);
   return launch_generic(st, in_dtype, out_dtype, backward, p, ws, device);
@@ -312,7 +311,11 @@ using namespace mlpg;
 
 extern "C" {
 
-__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 10; }
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 11; }
+
+__attribute__((visibility("default"))) long long mlpg_hip_launch_count(int kind) {
+  return kind >= 0 && kind < kCountKinds ? g_launches[kind].load() : -1;
+}
 
 __attribute__((visibility("default"))) const char *mlpg_hip_last_error(void) { return g_err; }
 
@@ -818,8 +821,8 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw(int device, void *st
                                                             const double *Y, const int32_t *lenx,
                                                             const int32_t *leny, int N, int Tx, int Ty, int D,
                                                             int radius, int dist_kind, double dist_scale,
-                                                            int32_t *path_i, int32_t *path_j, int32_t *path_len,
-                                                            double *cost) {
+                                                            int tie_rule, int32_t *path_i, int32_t *path_j,
+                                                            int32_t *path_len, double *cost) {
   if (N < 0 || Tx < 1 || Ty < 1 || D < 1 || radius < 1) {
     set_error("fastdtw: need N >= 0, Tx, Ty, D >= 1 and radius >= 1");
     return MLPG_HIP_EINVAL;
@@ -835,7 +838,52 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw(int device, void *st
     return MLPG_HIP_ERUNTIME;
   }
   return launch_fastdtw((hipStream_t)stream, device, X, Y, lenx, leny, N, Tx, Ty, D, radius, dist_kind, dist_scale,
-                        path_i, path_j, path_len, cost);
+                        tie_rule, path_i, path_j, path_len, cost);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_dtw_level_windows(int device, void *stream, int N, int radius,
+                                                                      const int32_t *level_tx, const int32_t *level_ty,
+                                                                      const int32_t *full, const int32_t *cpath_i,
+                                                                      const int32_t *cpath_j, const int32_t *cpath_len,
+                                                                      int cpath_stride, int32_t *row_lo, int32_t *row_hi,
+                                                                      int64_t *row_off, int row_stride) {
+  if (N < 0 || radius < 1 || row_stride < 1 || (N > 0 && (!level_tx || !level_ty || !full || !row_lo || !row_hi || !row_off))) {
+    set_error("dtw_level_windows: bad argument");
+    return MLPG_HIP_EINVAL;
+  }
+  if (N == 0) return 0;
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  return launch_dtw_window((hipStream_t)stream, device, N, radius, level_tx, level_ty, full, cpath_i, cpath_j, cpath_len,
+                           cpath_stride, row_lo, row_hi, row_off, row_stride);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_dtw_level_from_costs(int device, void *stream, int N, int tie_rule,
+                                                                         const int32_t *level_tx, const int32_t *level_ty,
+                                                                         const int32_t *row_lo, const int32_t *row_hi,
+                                                                         const int64_t *row_off, int row_stride, int max_ty,
+                                                                         const double *costs, const int64_t *cost_base,
+                                                                         int64_t total_cells, int32_t *path_i,
+                                                                         int32_t *path_j, int32_t *path_len,
+                                                                         int path_stride, double *cost) {
+  if (N < 0 || row_stride < 1 || max_ty < 1 || path_stride < 1 || total_cells < 0 ||
+      (tie_rule != MLPG_HIP_TIE_FIRST_MIN && tie_rule != MLPG_HIP_TIE_DIAG_LAST) ||
+      (N > 0 && (!level_tx || !level_ty || !row_lo || !row_hi || !row_off || !costs || !cost_base || !path_i || !path_j ||
+                 !path_len || !cost))) {
+    set_error("dtw_level_from_costs: bad argument");
+    return MLPG_HIP_EINVAL;
+  }
+  if (N == 0) return 0;
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  return launch_dtw_costs((hipStream_t)stream, device, N, tie_rule, level_tx, level_ty, row_lo, row_hi, row_off, row_stride,
+                          max_ty, costs, cost_base, total_cells, path_i, path_j, path_len, path_stride, cost);
 }
 
 __attribute__((visibility("default"))) int mlpg_hip_fastdtw_l2(int device, void *stream, const double *X,
@@ -843,8 +891,8 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw_l2(int device, void 
                                                                const int32_t *leny, int N, int Tx, int Ty, int D,
                                                                int radius, int32_t *path_i, int32_t *path_j,
                                                                int32_t *path_len, double *cost) {
-  return mlpg_hip_fastdtw(device, stream, X, Y, lenx, leny, N, Tx, Ty, D, radius, MLPG_HIP_DIST_L2, 1.0, path_i, path_j,
-                          path_len, cost);
+  return mlpg_hip_fastdtw(device, stream, X, Y, lenx, leny, N, Tx, Ty, D, radius, MLPG_HIP_DIST_L2, 1.0,
+                          MLPG_HIP_TIE_FIRST_MIN, path_i, path_j, path_len, cost);
 }
 
 __attribute__((visibility("default"))) int mlpg_hip_gmm_convert(int device, void *stream, const double *x,

@@ -57,8 +57,11 @@ struct StreamMap {
 };
 
 void set_error(const char *fmt, ...);
+// launches per kernel family since the library was loaded (mlpg_hip_launch_count: a test aid)
+enum { kCountGeneric = 0, kCountWave, kCountStrip, kCountStripMulti, kCountConst, kCountFused, kCountKinds };
+void note_launch(int kind);
 // Grow-only scratch, cached per (device, stream, slot): slot 0 generic factor, 1 fastdtw pyramids,
-// 2 generic status, 3 strip records, 4 constant-coefficient kernel (control words, records, factor table).  Returns nullptr (and sets the error) on failure.
+// 2 generic status, 3 strip records, 4 constant-coefficient kernel (factor table), 5 fastdtw from host costs (D rows, back-pointers).  Returns nullptr (and sets the error) on failure.
 void *scratch(int device, hipStream_t stream, int slot, size_t bytes, unsigned long long *gen = nullptr);
 
 // launchers (one per translation unit)
@@ -84,8 +87,6 @@ bool const_supported(const Problem &p, const WinSet &w);
 bool const_scratch_fresh(int device, hipStream_t stream, unsigned long long gen);
 bool const_preferred(const Problem &p, const WinSet &w);
 int launch_const(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
-bool pipe_supported(const Problem &p, const WinSet &w);
-int launch_pipe(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
 int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,
                      int ncols, void *dst, long ld_dst);
 int launch_stream_copy(hipStream_t s, const void *src, void *dst, size_t nbytes);
@@ -100,7 +101,14 @@ int launch_delta(hipStream_t s, int dtype, const void *x, const int32_t *lengths
 int launch_trim(hipStream_t s, int dtype, const void *X, int N, int T, int D, double eps, int32_t *lengths);
 int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, const int32_t *lenx,
                    const int32_t *leny, int N, int Tx, int Ty, int D, int radius, int dist_kind, double dist_scale,
-                   int32_t *path_i, int32_t *path_j, int32_t *path_len, double *cost);
+                   int tie_rule, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *cost);
+int launch_dtw_window(hipStream_t s, int device, int N, int radius, const int32_t *ltx, const int32_t *lty,
+                      const int32_t *full, const int32_t *cpath_i, const int32_t *cpath_j, const int32_t *cpath_len,
+                      int cpath_stride, int32_t *row_lo, int32_t *row_hi, int64_t *row_off, int row_stride);
+int launch_dtw_costs(hipStream_t s, int device, int N, int tie_rule, const int32_t *ltx, const int32_t *lty,
+                     const int32_t *row_lo, const int32_t *row_hi, const int64_t *row_off, int row_stride, int max_ty,
+                     const double *costs, const int64_t *cost_base, int64_t total_cells, int32_t *path_i, int32_t *path_j,
+                     int32_t *path_len, int path_stride, double *cost_out);
 int launch_gmm_convert(hipStream_t s, const double *x, const double *post, const int32_t *mix, const double *mu_x,
                        const double *mu_y, const double *A, long N, int D, int Dy, int M, double *out);
 int launch_gather(hipStream_t s, int dtype, const void *src, const int32_t *path, const int32_t *path_len, int N,

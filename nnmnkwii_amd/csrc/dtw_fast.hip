@@ -41,6 +41,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -231,19 +232,26 @@ __device__ __forceinline__ int clamp_idx(int c, int hi) {  // median(c, -1, hi),
   return r;
 }
 
-// Back-pointer codes are packed two bits per step of the sweep (see the sweep below): the upper bit says "the diagonal
-// beats left", the lower one "the better of the two beats up".  rinfo[row] >> 32 is the row's cell-index base: cell (row, j) lives at
-// bit pair (base + j - lo) of the halfword stream, most significant pair first within a halfword.
+// Back-pointer codes are packed two bits per step of the sweep (see the sweep below).  rinfo[row] >> 32 is the row's
+// cell-index base: cell (row, j) lives at bit pair (base + j - lo) of the halfword stream, most significant pair first
+// within a halfword.
+// TIE = MLPG_HIP_TIE_FIRST_MIN (upstream's pure-Python __dtw: the FIRST minimum of up, left, diagonal): the upper bit says
+// "the diagonal beats left", the lower one "the better of the two beats up".
+// TIE = MLPG_HIP_TIE_DIAG_LAST (the strict-less chain recalled for upstream's compiled _fastdtw: up only if it beats both
+// others, else left only if it beats the diagonal, else the diagonal): upper bit "left beats the diagonal", lower bit
+// "up beats the better of the two".
+template <int TIE>
 __device__ __forceinline__ unsigned bp_code(const unsigned short *__restrict__ bp16, int cidx) {
   const unsigned hw = bp16[cidx >> 3];
   const unsigned pair = (hw >> (14 - 2 * (cidx & 7))) & 3u;
-  return (pair & 1u) ? 1u + (pair >> 1) : 0u;  // 0 up, 1 left, 2 diagonal
+  if (TIE == MLPG_HIP_TIE_FIRST_MIN) return (pair & 1u) ? 1u + (pair >> 1) : 0u;  // 0 up, 1 left, 2 diagonal
+  return (pair & 1u) ? 0u : 2u - (pair >> 1);
 }
 
 // One back-trace walk from cell (bi, bj) up to (excluding) row `top`: follows the back-pointer
 // codes, WRITE: stores the visited cells at positions wpos-1, wpos-2, ...  Returns the column
 // reached in row top-1 (-2 if the walk leaves the window); *ncells = cells visited.
-template <bool WRITE, typename PT>
+template <bool WRITE, int TIE, typename PT>
 __device__ __forceinline__ int dtw_walk(const unsigned long long *__restrict__ rinfo, const unsigned short *__restrict__ bp16,
                                         PT *__restrict__ pth_i, PT *__restrict__ pth_j, int bi,
                                         int bj, int top, int wpos, int *ncells) {
@@ -254,7 +262,7 @@ __device__ __forceinline__ int dtw_walk(const unsigned long long *__restrict__ r
   int cnt = 0;
   while (true) {
     ++cnt;
-    const unsigned code = bp_code(bp16, cb + bj);
+    const unsigned code = bp_code<TIE>(bp16, cb + bj);
     if (WRITE) {
       --wpos;
       pth_i[wpos] = (PT)bi;
@@ -295,7 +303,7 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c) {
   return r;
 }
 
-template <int kThreads>
+template <int kThreads, int TIE>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void fastdtw_kernel(DtwParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -708,8 +716,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       // compare + shift-in, one hand-over store, and half a cost-pair load.  The loop-carried chain is
       // DPP -> add -> min (the left / diagonal minimum is formed beside it).  The feeder receives +0.0 from the DPP
       // (bound_ctrl), which makes it replay its stored row: up + dt = diag + dt = dt exactly and left + dt >= dt (D >= 0).
-      // Codes: bit a = "diagonal < left", then bit b = "min(left, diagonal) < up": up unless b, else diagonal if a,
-      // else left -- the first minimum in the order up, left, diagonal, as the oracle's three compares.
+      // Codes (TIE_FIRST_MIN): bit a = "diagonal < left", then bit b = "min(left, diagonal) < up": up unless b, else
+      // diagonal if a, else left -- the first minimum in the order up, left, diagonal, as the oracle's three compares.
+      // (TIE_DIAG_LAST: the same two compares with their operands exchanged, see bp_code.)
       auto block = [&](const double (&dt)[8], auto store_tag) {
         constexpr bool STORE = decltype(store_tag)::value;
         const int dbase = ((unsigned)x_run < wlim) ? d_m8 + 8 * x_run : d_dummy;
@@ -719,10 +728,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
           const double up = wave_shr1z(pub);
           const double cl = __dadd_rn(pub, dt[k8]), cd = __dadd_rn(upp, dt[k8]);
           const double x = vmin_f64(cl, cd);  // off the cross-lane chain: both operands are a step old
-          acc = shift_in_lt(acc, cd, cl);
+          acc = TIE == MLPG_HIP_TIE_FIRST_MIN ? shift_in_lt(acc, cd, cl) : shift_in_lt(acc, cl, cd);
           const double cu = __dadd_rn(up, dt[k8]);
           const double best = vmin_f64(cu, x);
-          acc = shift_in_lt(acc, x, cu);
+          acc = TIE == MLPG_HIP_TIE_FIRST_MIN ? shift_in_lt(acc, x, cu) : shift_in_lt(acc, cu, x);
           if (STORE) dw[k8] = best;
           upp = up;
           pub = best;
@@ -797,7 +806,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
         }
         const int bot = ((a + 1) * kSeg < ltx ? (a + 1) * kSeg : ltx) - 1;
         int nc;
-        const int ex = dtw_walk<false>(rinfo, bp16, pth_i, pth_j, bot, LO(bot) + (task - segoff[a]), a * kSeg, 0, &nc);
+        const int ex = dtw_walk<false, TIE>(rinfo, bp16, pth_i, pth_j, bot, LO(bot) + (task - segoff[a]), a * kSeg, 0, &nc);
         cnts[task] = (unsigned short)nc;
         unsigned nx = kInvalid;
         if (a == 0) {
@@ -870,8 +879,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
         for (int g = tid; g < G; g += kThreads) {
           const int bot = ((g + 1) * kSeg < ltx ? (g + 1) * kSeg : ltx) - 1;
           int nc;
-          if (k == 0) (void)dtw_walk<true>(rinfo, bp16, out_i, out_j, bot, LO(bot) + segent[g], g * kSeg, segend[g], &nc);
-          else (void)dtw_walk<true>(rinfo, bp16, pth_i, pth_j, bot, LO(bot) + segent[g], g * kSeg, segend[g], &nc);
+          if (k == 0) (void)dtw_walk<true, TIE>(rinfo, bp16, out_i, out_j, bot, LO(bot) + segent[g], g * kSeg, segend[g], &nc);
+          else (void)dtw_walk<true, TIE>(rinfo, bp16, pth_i, pth_j, bot, LO(bot) + segent[g], g * kSeg, segend[g], &nc);
         }
       }
     } else if (w0) {
@@ -888,7 +897,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
           bool up = false;
           while (!up) {  // cells of this row on the path
             if (cnt >= wcap || bj < rl) { ok = 0; break; }
-            const int code = uni((int)bp_code(bp16, cb + bj - rl));
+            const int code = uni((int)bp_code<TIE>(bp16, cb + bj - rl));
             ++cnt;
             if (pass == 1) {
               --pos;
@@ -960,18 +969,20 @@ size_t lds_bytes(int Tx, int Ty, const DtwParams &p) {
   return (b + 15) & ~(size_t)15;
 }
 
-template <int kThreads>
+template <int kThreads, int TIE>
 int launch_one(hipStream_t s, const DtwParams &p, int N, size_t lds) {
   constexpr int kMaxDevices = 16;
   static size_t attr_set[kMaxDevices] = {};  // largest dynamic-LDS size the attribute was set to, per device
+  static std::mutex attr_mu;
+  std::lock_guard<std::mutex> attr_lk(attr_mu);
   int device = 0;
   MLPG_HIP_CHECK(hipGetDevice(&device));
   if (device < 0 || device >= kMaxDevices || attr_set[device] < lds) {
-    MLPG_HIP_CHECK(hipFuncSetAttribute((const void *)fastdtw_kernel<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    MLPG_HIP_CHECK(hipFuncSetAttribute((const void *)fastdtw_kernel<kThreads, TIE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds));
     if (device >= 0 && device < kMaxDevices) attr_set[device] = lds;
   }
-  hipLaunchKernelGGL(fastdtw_kernel<kThreads>, dim3(N), dim3(kThreads), lds, s, p);
+  hipLaunchKernelGGL((fastdtw_kernel<kThreads, TIE>), dim3(N), dim3(kThreads), lds, s, p);
   MLPG_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -980,7 +991,11 @@ int launch_one(hipStream_t s, const DtwParams &p, int N, size_t lds) {
 
 int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, const int32_t *lenx,
                    const int32_t *leny, int N, int Tx, int Ty, int D, int radius, int dist_kind, double dist_scale,
-                   int32_t *path_i, int32_t *path_j, int32_t *path_len, double *cost) {
+                   int tie_rule, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *cost) {
+  if (tie_rule != MLPG_HIP_TIE_FIRST_MIN && tie_rule != MLPG_HIP_TIE_DIAG_LAST) {
+    set_error("fastdtw: unknown tie rule %d", tie_rule);
+    return MLPG_HIP_EINVAL;
+  }
   if (dist_kind < MLPG_HIP_DIST_L2 || dist_kind > MLPG_HIP_DIST_SCALED_SQL2_NP) {
     set_error("fastdtw: unknown local distance %d", dist_kind);
     return MLPG_HIP_EINVAL;
@@ -1032,12 +1047,15 @@ int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, 
   const size_t lds_q = lds_bytes(Tx, Ty, q);
   static const int force = [] { const char *e = getenv("MLPG_HIP_DTW_FORCE"); return e ? atoi(e) : 0; }();  // measurement switch: 1 two launches, 2 one
   if (force != 2 && (N > 2 * cus || force == 1) && q.chunkcap < p.chunkcap && lds_q <= 40 * 1024) {
-    if (int rc = launch_one<256>(s, q, N, lds_q)) return rc;
+    if (int rc = tie_rule == MLPG_HIP_TIE_FIRST_MIN ? launch_one<256, MLPG_HIP_TIE_FIRST_MIN>(s, q, N, lds_q)
+                                                     : launch_one<256, MLPG_HIP_TIE_DIAG_LAST>(s, q, N, lds_q))
+      return rc;
     static const bool first_only = getenv("MLPG_HIP_DTW_FIRST_LAUNCH_ONLY") != nullptr;  // measurement switch
     if (first_only) return 0;
     p.tier = 2;
   }
-  return launch_one<512>(s, p, N, lds);
+  return tie_rule == MLPG_HIP_TIE_FIRST_MIN ? launch_one<512, MLPG_HIP_TIE_FIRST_MIN>(s, p, N, lds)
+                                            : launch_one<512, MLPG_HIP_TIE_DIAG_LAST>(s, p, N, lds);
 }
 
 }  // namespace mlpg

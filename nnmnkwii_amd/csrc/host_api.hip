@@ -281,7 +281,7 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_host(int device, int
 __attribute__((visibility("default"))) int mlpg_hip_fastdtw_host(int device, int dtype, const void *X_h, const void *Y_h,
                                                                  const int32_t *lenx_h, const int32_t *leny_h, int N,
                                                                  int Tx, int Ty, int D, int radius, int dist_kind,
-                                                                 double dist_scale, double trim_eps,
+                                                                 double dist_scale, int tie_rule, double trim_eps,
                                                                  int32_t *path_i_h, int32_t *path_j_h,
                                                                  int32_t *path_len_h, double *cost_h,
                                                                  int32_t *lenx_out_h, int32_t *leny_out_h) {
@@ -389,7 +389,7 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw_host(int device, int
       x64 = (const double *)(d + o_x64);
       y64 = (const double *)(d + o_y64);
     }
-    if (int rc = launch_fastdtw(st, device, x64, y64, lx, ly, (int)nb, Tx, Ty, D, radius, dist_kind, dist_scale,
+    if (int rc = launch_fastdtw(st, device, x64, y64, lx, ly, (int)nb, Tx, Ty, D, radius, dist_kind, dist_scale, tie_rule,
                                 (int32_t *)(d + o_pi), (int32_t *)(d + o_pj), (int32_t *)(d + o_pl), (double *)(d + o_c)))
       return rc;
     char *o = (char *)c.pin_out[slot];

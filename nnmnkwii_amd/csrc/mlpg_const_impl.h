@@ -1087,6 +1087,7 @@ int launch_cfg(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch
   hipLaunchKernelGGL((setup_kernel<TIN, VM, NW>), dim3((unsigned)q.ndg), dim3(64), 0, st, p, a, M, W, fresh ? 1 : 0);
   MLPG_HIP_CHECK(hipGetLastError());
   const int grid = q.nsg < resident ? q.nsg : resident;
+  note_launch(kCountConst);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W * 64), 0, st, p, ws, a);
   MLPG_HIP_CHECK(hipGetLastError());
   return 0;

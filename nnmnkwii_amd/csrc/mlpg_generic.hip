@@ -219,6 +219,7 @@ int launch_q(hipStream_t st, const Problem &p, const WinSet &w, int device) {
   }
   const long cells = S * p.Tmax;
   const unsigned gcells = (unsigned)((cells + 255) / 256);
+  note_launch(kCountGeneric);
   hipLaunchKernelGGL((generic_assemble_kernel<Q, TIN, BWD>), dim3(gcells), dim3(256), 0, st, q, w, sc, S);
   const unsigned grid = (unsigned)((S + 63) / 64);
   hipLaunchKernelGGL((generic_kernel<Q, TIN, TOUT, BWD>), dim3(grid), dim3(64), 0, st, q, w, sc, S);

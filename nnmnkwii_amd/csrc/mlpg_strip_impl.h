@@ -1906,6 +1906,7 @@ int launch_impl(hipStream_t st, const Problem &p, const WinSet &ws, void *scratc
     if (nitems > resident && R > resident / 2) return kNotResident;
     if (zero_ctrl) MLPG_HIP_CHECK(hipMemsetAsync(a.ctrl, 0, ctrl_ints(nsg, R) * sizeof(int), st));
     const long grid = nitems < resident ? nitems : resident;
+    note_launch(MULTI ? kCountStripMulti : kCountStrip);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kW * 64), kLdsBytes, st, p, ws, a);
     MLPG_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL((verdict_kernel<TIN, TOUT, BWD, MULTI>), dim3((unsigned)((nsg + 3) / 4)), dim3(256), 0, st, p, ws, a);

@@ -281,6 +281,7 @@ int launch_fused_k(hipStream_t st, const Problem &p, const WinSet &ws, const Fus
   constexpr size_t lds = 2 * (size_t)tile_bytes<M, TIN>();
   auto kern = wave_fused_kernel<M, TIN, DMA>;
   MLPG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  note_launch(kCountFused);
   hipLaunchKernelGGL(kern, dim3(nslots * 8), dim3(kG * 64), lds, st, p, ws, ngrp, nslots, fa);
   MLPG_HIP_CHECK(hipGetLastError());
   return 0;

@@ -769,6 +769,7 @@ int launch_k(hipStream_t st, const Problem &p, const WinSet &ws) {
   constexpr size_t lds = 2 * (size_t)tile_bytes<M, TIN>();
   auto kern = wave_kernel<M, MINW, TIN, TOUT, BWD, DMA, VM>;
   MLPG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  note_launch(kCountWave);
   hipLaunchKernelGGL(kern, dim3(nslots * 8), dim3(kG * 64), lds, st, p, ws, ngrp, nslots);
   MLPG_HIP_CHECK(hipGetLastError());
   return 0;

@@ -26,8 +26,10 @@ def _resolve_dist(dist):
     * a positive multiple of the city-block distance ``np.abs(x - y).sum()`` (``norm(x - y, 1)``,
       ``scipy.spatial.distance.cityblock``) or of the squared Euclidean distance ``((x - y) ** 2).sum()``
       (``sqeuclidean``) -> MLPG_HIP_DIST_SCALED_L1_NP / MLPG_HIP_DIST_SCALED_SQL2_NP;
-    * anything else cannot run on the GPU (there is no CPU fallback): NotImplementedError.
-    The callable is only probed on a few random frame pairs, never called per DP cell.
+    * anything else: ``None`` -- the caller then evaluates the local costs on the host with the callable itself, one
+      call per window cell as upstream fastdtw does, and runs the DP, the back-trace and the window expansion on the GPU
+      (``_hip.fastdtw_callable``).
+    A recognised callable is only probed on a few random frame pairs, never called per DP cell.
     """
     from .. import metrics
     if dist is _default_dist:
@@ -46,8 +48,8 @@ def _resolve_dist(dist):
     probes = [(rng.randn(D), rng.randn(D)) for D in (1, 5, 25) for _ in range(3)]
     try:
         vals = np.asarray([float(dist(x, y)) for x, y in probes])
-    except Exception as e:   # a callable that does not take two frames
-        raise NotImplementedError("DTWAligner: cannot evaluate `dist` on two frames (%s)" % e)
+    except Exception:        # a callable that does not like the probes: it is simply called per cell
+        return None
     for kind, form in forms:
         ratios = vals / np.asarray([form(x, y) for x, y in probes])
         c = float(np.median(ratios))
@@ -55,10 +57,7 @@ def _resolve_dist(dist):
             if kind == _hip.DIST_SCALED_L2_NP and abs(c - 1.0) <= 1e-12:
                 return _hip.DIST_L2, 1.0
             return kind, c
-    raise NotImplementedError(
-        "nnmnkwii_amd.DTWAligner evaluates the local cost on the GPU: the default Euclidean distance, metrics.melcd, or a "
-        "callable that is a positive multiple of the Euclidean, the city-block (np.abs(x - y).sum()) or the squared Euclidean "
-        "distance; an arbitrary Python `dist` cannot run there (and there is no CPU fallback)")
+    return None
 
 
 class DTWAligner(object):
@@ -67,12 +66,20 @@ class DTWAligner(object):
     Same constructor and ``transform`` contract as the reference class: inputs
     are zero-padded ``(N, Tx, D)`` / ``(N, Ty, D)`` arrays; outputs are two
     ``(N, max(T_longer, longest path), D)`` arrays with the dtype of the longer
-    input.  ``dist``: the HIP kernel evaluates the local cost itself, so the
-    callable is mapped onto a device-side cost (:func:`_resolve_dist`): the
-    default Euclidean ``norm(x - y)``, ``metrics.melcd`` (the reference's own
-    test passes it), or any positive multiple of the Euclidean distance.  An
-    arbitrary Python callable cannot run on the GPU and raises
-    ``NotImplementedError`` (there is no CPU fallback).
+    input.  ``dist``: where the callable is one the HIP kernel can evaluate
+    itself (:func:`_resolve_dist`: the default Euclidean ``norm(x - y)``,
+    ``metrics.melcd`` -- the reference's own test passes it --, positive
+    multiples of the Euclidean, city-block or squared Euclidean distance) the
+    whole alignment runs on the GPU; ANY other callable is evaluated on the
+    host, once per window cell as upstream fastdtw does, and only the DP,
+    back-trace and window expansion run on the GPU (reference speed: the
+    interpreter call per cell is the cost, as it is in the reference).
+
+    ``tie_rule`` (an extension, keyword only): which of equal DP candidates
+    wins -- ``"first"`` (upstream's pure-Python recurrence: first minimum of
+    up, left, diagonal; the rule all parity tests are pinned on) or
+    ``"diag_last"`` (the strict-less chain recalled for upstream's compiled
+    extension; UNVERIFIED, see include/mlpg_hip.h).  Continuous data never tie.
 
     Attributes:
         dist (function): Distance function (default L2).
@@ -80,10 +87,12 @@ class DTWAligner(object):
         verbose (int): Verbose flag.
     """
 
-    def __init__(self, dist=_default_dist, radius=1, verbose=0):
+    def __init__(self, dist=_default_dist, radius=1, verbose=0, *, tie_rule="first"):
         self.verbose = verbose
         self.dist = dist
         self.radius = radius
+        assert tie_rule in ("first", "diag_last")
+        self.tie_rule = tie_rule
 
     # Batches below this many input bytes go through device tensors (upload once, trim + fastdtw + gather on the GPU,
     # download the aligned arrays: 4-6 ms for 128 config-4 pairs); larger ones through the host-pointer entry point
@@ -93,10 +102,14 @@ class DTWAligner(object):
     def _paths(self, X, Y):
         """Trim + fastdtw of every pair.  Returns numpy (path_i, path_j, path_len, cost, lenx, leny) and a gather
         function ``(src_is_x, path, plen, T_out, dtype) -> aligned array``."""
-        dist_kind, dist_scale = _resolve_dist(self.dist)
+        resolved = _resolve_dist(self.dist)
+        tie = _hip.TIE_FIRST_MIN if getattr(self, "tie_rule", "first") == "first" else _hip.TIE_DIAG_LAST
         dev = _hip.require_gpu()
+        if resolved is None:
+            return self._paths_callable(X, Y, tie, dev)
+        dist_kind, dist_scale = resolved
         if X.nbytes + Y.nbytes >= self._HOST_ENTRY_BYTES:
-            out = _hip.fastdtw_host(X, Y, self.radius, dist_kind, dist_scale, device=dev.index)      # alignment.py:46-50
+            out = _hip.fastdtw_host(X, Y, self.radius, dist_kind, dist_scale, device=dev.index, tie_rule=tie)   # alignment.py:46-50
             return out + ((lambda is_x, path, plen, T_out, dtype: _gather(X if is_x else Y, path, plen, T_out, dtype)),)
         torch = _hip.torch_mod()
         Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
@@ -109,13 +122,41 @@ class DTWAligner(object):
         leny = _hip.trim_lengths(Yd)
         X64 = Xd if Xd.dtype == torch.float64 else Xd.to(torch.float64)   # fastdtw casts to float
         Y64 = Yd if Yd.dtype == torch.float64 else Yd.to(torch.float64)
-        path_i, path_j, path_len, cost = _hip.fastdtw_l2(X64, Y64, lenx, leny, self.radius, dist_kind, dist_scale)   # :50
+        path_i, path_j, path_len, cost = _hip.fastdtw_l2(X64, Y64, lenx, leny, self.radius, dist_kind, dist_scale, tie)   # :50
 
         def gather(is_x, path, plen, T_out, dtype):
             g = _hip.gather_path(Xd if is_x else Yd, path_i if is_x else path_j, path_len, T_out)   # :52-54,72-73
             return g.cpu().numpy().astype(dtype, copy=False)
         return (path_i.cpu().numpy(), path_j.cpu().numpy(), path_len.cpu().numpy(), cost.cpu().numpy(),
                 lenx.cpu().numpy(), leny.cpu().numpy(), gather)
+
+    def _paths_callable(self, X, Y, tie, dev):
+        """The same for a ``dist`` only Python can evaluate: trim on the GPU, the local costs of every level's window on
+        the host by ``self.dist`` (one call per cell: what upstream fastdtw does with the callable), DP + back-trace +
+        window expansion on the GPU."""
+        torch = _hip.torch_mod()
+        Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
+        Yd = torch.from_numpy(np.ascontiguousarray(Y)).to(dev)
+        if Xd.dtype not in (torch.float32, torch.float64):
+            Xd = Xd.to(torch.float64)
+        if Yd.dtype not in (torch.float32, torch.float64):
+            Yd = Yd.to(torch.float64)
+        lenx = _hip.trim_lengths(Xd).cpu().numpy()         # alignment.py:46-49
+        leny = _hip.trim_lengths(Yd).cpu().numpy()
+        N = X.shape[0]
+        if (lenx <= 0).any() or (leny <= 0).any():
+            plen = np.where((lenx > 0) & (leny > 0), 1, 0).astype(np.int32)
+            z = np.zeros((N, 1), dtype=np.int32)
+            return z, z, plen, np.zeros(N), lenx, leny, None
+        xs = [X[n, : int(lenx[n])] for n in range(N)]
+        ys = [Y[n, : int(leny[n])] for n in range(N)]
+        pi, pj, plen, cost = _hip.fastdtw_callable(xs, ys, self.radius, self.dist, tie, device=dev)   # :50
+        d_pi, d_pj, d_pl = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (pi, pj, plen))
+
+        def gather(is_x, path, plen_, T_out, dtype):
+            g = _hip.gather_path(Xd if is_x else Yd, d_pi if is_x else d_pj, d_pl, T_out)   # :52-54,72-73
+            return g.cpu().numpy().astype(dtype, copy=False)
+        return pi, pj, plen, cost, lenx, leny, gather
 
     def transform(self, XY):
         X, Y = XY
@@ -169,7 +210,9 @@ class IterativeDTWAligner(object):
         n_iter, dist, radius, verbose, max_iter_gmm, n_components_gmm: as in the reference.
     """
 
-    def __init__(self, n_iter=3, dist=_default_dist, radius=1, max_iter_gmm=100, n_components_gmm=16, verbose=0):
+    def __init__(self, n_iter=3, dist=_default_dist, radius=1, max_iter_gmm=100, n_components_gmm=16, verbose=0, *,
+                 tie_rule="first"):
+        self.tie_rule = tie_rule
         self.n_iter = n_iter
         self.dist = dist
         self.radius = radius
@@ -189,7 +232,7 @@ class IterativeDTWAligner(object):
         Xc = X.copy()                                          # converted X, updated every iteration (:129)
         X_aligned = np.zeros_like(longer)
         Y_aligned = np.zeros_like(longer)
-        aligner = DTWAligner(dist=self.dist, radius=self.radius)
+        aligner = DTWAligner(dist=self.dist, radius=self.radius, tie_rule=getattr(self, "tie_rule", "first"))
         path_x, plen = None, None
 
         for _ in range(self.n_iter):

@@ -36,7 +36,20 @@ def l2(a, b):
 
 # ------------------------------------------------------------ literal python
 
-def _dtw_py(x, y, window, dist):
+def _min_first(a, b, c):
+    """upstream's pure-Python rule: Python's min keeps the FIRST minimal candidate (up, left, diagonal)"""
+    return min(a, b, c, key=lambda t: t[0])
+
+
+def _min_diag_last(a, b, c):
+    """the strict-less chain recalled for upstream's compiled _fastdtw (UNVERIFIED): up only if it
+    beats both others, else left only if it beats the diagonal, else the diagonal"""
+    if a[0] < b[0] and a[0] < c[0]:
+        return a
+    return b if b[0] < c[0] else c
+
+
+def _dtw_py(x, y, window, dist, pick=_min_first):
     len_x, len_y = len(x), len(y)
     if window is None:
         window = [(i, j) for i in range(len_x) for j in range(len_y)]
@@ -45,11 +58,10 @@ def _dtw_py(x, y, window, dist):
     D[0, 0] = (0, 0, 0)
     for i, j in window:
         dt = dist(x[i - 1], y[j - 1])
-        D[i, j] = min(
+        D[i, j] = pick(
             (D[i - 1, j][0] + dt, i - 1, j),
             (D[i, j - 1][0] + dt, i, j - 1),
             (D[i - 1, j - 1][0] + dt, i - 1, j - 1),
-            key=lambda a: a[0],
         )
     path = []
     i, j = len_x, len_y
@@ -89,28 +101,28 @@ def _expand_window(path, len_x, len_y, radius):
     return window
 
 
-def _fastdtw_py(x, y, radius, dist):
+def _fastdtw_py(x, y, radius, dist, pick=_min_first):
     min_time_size = radius + 2
     if len(x) < min_time_size or len(y) < min_time_size:
-        return _dtw_py(x, y, None, dist)
+        return _dtw_py(x, y, None, dist, pick)
     x_shrinked = _reduce_by_half(x)
     y_shrinked = _reduce_by_half(y)
-    _, path = _fastdtw_py(x_shrinked, y_shrinked, radius, dist)
+    _, path = _fastdtw_py(x_shrinked, y_shrinked, radius, dist, pick)
     window = _expand_window(path, len(x), len(y), radius)
-    return _dtw_py(x, y, window, dist)
+    return _dtw_py(x, y, window, dist, pick)
 
 
-def fastdtw_py(x, y, radius=1, dist=l2):
-    """Literal pure-Python restatement (small cases only)."""
+def fastdtw_py(x, y, radius=1, dist=l2, tie=0):
+    """Literal pure-Python restatement (small cases only).  tie: 0 = first minimum (pure Python), 1 = diagonal last."""
     x = np.asanyarray(x, dtype="float")
     y = np.asanyarray(y, dtype="float")
-    return _fastdtw_py(x, y, radius, dist)
+    return _fastdtw_py(x, y, radius, dist, _min_first if tie == 0 else _min_diag_last)
 
 
 # ------------------------------------------------------------------- C path
 
-def fastdtw(x, y, radius=1):
-    """C restatement with the L2 local cost. Returns (distance, path (n, 2) int32)."""
+def fastdtw(x, y, radius=1, tie=0):
+    """C restatement with the L2 local cost. Returns (distance, path (n, 2) int32).  tie as fastdtw_py."""
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)
     if x.ndim == 1:
@@ -122,11 +134,11 @@ def fastdtw(x, y, radius=1):
     pj = np.zeros(tx + ty, dtype=np.int32)
     cost = ctypes.c_double(0.0)
     L = _lib()
-    L.oracle_fastdtw_l2.restype = ctypes.c_long
-    L.oracle_fastdtw_l2.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long,
-                                    ctypes.c_long, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p,
-                                    ctypes.POINTER(ctypes.c_double)]
-    n = L.oracle_fastdtw_l2(_ptr(x), tx, _ptr(y), ty, D, radius, _ptr(pi), _ptr(pj), ctypes.byref(cost))
+    L.oracle_fastdtw_l2_tie.restype = ctypes.c_long
+    L.oracle_fastdtw_l2_tie.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long,
+                                        ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.POINTER(ctypes.c_double)]
+    n = L.oracle_fastdtw_l2_tie(_ptr(x), tx, _ptr(y), ty, D, radius, int(tie), _ptr(pi), _ptr(pj), ctypes.byref(cost))
     if n < 0:
         raise RuntimeError("fastdtw oracle: unreachable window")
     return cost.value, np.stack([pi[:n], pj[:n]], axis=1)

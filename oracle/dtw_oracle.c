@@ -48,6 +48,12 @@ static double l2_cost(const double *a, const double *b, long D) {
 /* Windowed DTW over per-row column intervals [lo[i], hi[i]] (0-based, inclusive).
  * Returns path length; path written front-to-back.  pred codes: 0 up, 1 left,
  * 2 diag. */
+/* tie = 0: upstream's pure-Python __dtw (FIRST minimum of up, left, diagonal).
+ * tie = 1: the strict-less chain recalled for upstream's compiled _fastdtw -- up
+ * only if it beats both others, else left only if it beats the diagonal, else
+ * the diagonal.  UNVERIFIED: the package cannot be installed
+ * here; tests/test_dtw_gpu.py reports which rule an installed fastdtw follows. */
+static long g_tie = 0;
 static long dtw_windowed(const double *x, long tx, const double *y, long ty,
                          long D, const long *lo, const long *hi,
                          int32_t *path_i, int32_t *path_j, double *cost_out) {
@@ -72,8 +78,13 @@ static long dtw_windowed(const double *x, long tx, const double *y, long ty,
       const double diag = CELL(i - 1, j - 1) + dt;
       double best = up;
       uint8_t p = 0;
-      if (left < best) { best = left; p = 1; }
-      if (diag < best) { best = diag; p = 2; }
+      if (g_tie == 0) {
+        if (left < best) { best = left; p = 1; }
+        if (diag < best) { best = diag; p = 2; }
+      } else if (!(up < left && up < diag)) {
+        if (left < diag) { best = left; p = 1; }
+        else { best = diag; p = 2; }
+      }
       cost[off[i] + j - lo[i]] = best;
       pred[off[i] + j - lo[i]] = p;
     }
@@ -176,6 +187,18 @@ ORACLE_API long oracle_fastdtw_l2(const double *x, long tx, const double *y,
                                   double *cost) {
   if (tx <= 0 || ty <= 0) return -1;
   return fastdtw_rec(x, tx, y, ty, D, radius, path_i, path_j, cost);
+}
+
+/* the same with the tie rule selected (0 / 1, see dtw_windowed); not re-entrant */
+ORACLE_API long oracle_fastdtw_l2_tie(const double *x, long tx, const double *y,
+                                      long ty, long D, long radius, long tie,
+                                      int32_t *path_i, int32_t *path_j,
+                                      double *cost) {
+  if (tx <= 0 || ty <= 0) return -1;
+  g_tie = tie;
+  const long n = fastdtw_rec(x, tx, y, ty, D, radius, path_i, path_j, cost);
+  g_tie = 0;
+  return n;
 }
 
 /* The window (per-row [lo, hi]) fastdtw would use at the FINEST level -- lets

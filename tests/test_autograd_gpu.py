@@ -184,3 +184,37 @@ def test_fused_unit_variance_mse_step_equals_two_node_form(shape, dt):
         y = torch.einsum("tws,bswd->btd", Rd, means.detach().view(B, T, 3, sd))
         ref = ((y - target) ** 2).mean()
         assert abs(float(ref) - float(loss_b)) <= 1e-6 * float(ref)     # R itself is a float32 matrix
+
+
+@pytest.mark.parametrize("shape", [(64, 500, 60), (3, 211, 7)])
+def test_fused_step_gradient_against_the_dense_float64_definition(shape):
+    """mlpg_hip_unit_mse_step's GRADIENT against the definition itself, not against the two-launch HIP form:
+    y = R mu (R = the float64 matrix P^-1 W~^T built densely on the CPU from the oracle's window matrices),
+    loss = mean((y - target)^2), d loss / d mu = R^T 2 (y - target) / N, all in float64."""
+    import torch
+    from nnmnkwii_amd import autograd as AF
+    from oracle import mlpg as O
+    B, T, sd = shape
+    windows = WINDOW_SETS["std3"]
+    nw = len(windows)
+    torch.manual_seed(7 * T)
+    means = torch.rand(B, T, nw * sd, dtype=torch.float64, device="cuda", requires_grad=True)
+    target = torch.rand(B, T, sd, dtype=torch.float64, device="cuda")
+    loss = AF.unit_variance_mlpg_mse_loss(windows, means, target)
+    loss.backward()
+    # the dense definition on the CPU (paramgen/_mlpg.py:297-373 without the float32 cast)
+    mask = O._edge_mask(T, 1)
+    Ws = [O.window_matrix(l, u, c, T) for (l, u, c) in windows]
+    Wt = [W if w == 0 else mask[:, None] * W for w, W in enumerate(Ws)]
+    P = sum(Wt[w].T @ Ws[w] for w in range(nw))
+    Rd = np.linalg.solve(P, np.concatenate([Wt[w].T for w in range(nw)], axis=1))       # (T, nw*T)
+    mu = means.detach().cpu().numpy().reshape(B, T, nw, sd).transpose(0, 2, 1, 3).reshape(B, nw * T, sd)
+    y = np.einsum("tk,bkd->btd", Rd, mu)
+    tg = target.cpu().numpy()
+    N = B * T * sd
+    ref_loss = ((y - tg) ** 2).sum() / N
+    gy = 2.0 * (y - tg) / N
+    gmu = np.einsum("tk,btd->bkd", Rd, gy).reshape(B, nw, T, sd).transpose(0, 2, 1, 3).reshape(B, T, nw * sd)
+    assert abs(float(loss) - ref_loss) <= 1e-11 * ref_loss
+    g = means.grad.cpu().numpy()
+    assert np.abs(g - gmu).max() <= 1e-10 * np.abs(gmu).max()

@@ -29,7 +29,7 @@ def test_exports_match_header(L):
     assert declared == set(_hip.EXPORTS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.mlpg_hip_abi_version() == _hip.ABI_VERSION == 10
+    assert L.mlpg_hip_abi_version() == _hip.ABI_VERSION == 11
 
 
 def test_argument_validation_without_gpu(L):
@@ -124,13 +124,18 @@ def test_product_never_imports_oracle():
                 assert "liboracle" not in src, fn
 
 
-def test_dtw_custom_dist_rejected():
-    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
-    a = DTWAligner(dist=lambda x, y: 0.0)
-    with pytest.raises(NotImplementedError):
-        a.transform((np.zeros((1, 3, 2)), np.zeros((1, 3, 2))))
+def test_dtw_custom_dist_is_evaluated_on_the_host_and_needs_the_gpu_for_the_rest():
+    from nnmnkwii_amd import HipExtensionError
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner, _resolve_dist
+    assert _resolve_dist(lambda x, y: 1.0 - float(x @ y)) is None
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    a = DTWAligner(dist=lambda x, y: 1.0 - float(x @ y))
+    with pytest.raises(HipExtensionError):       # no CPU fallback for the DP either
+        a.transform((np.ones((1, 3, 2)), np.ones((1, 3, 2))))
     d = DTWAligner()
-    assert d.radius == 1 and d.verbose == 0 and callable(d.dist)
+    assert d.radius == 1 and d.verbose == 0 and callable(d.dist) and d.tie_rule == "first"
 
 
 def test_compat_install_provides_the_reference_names():
@@ -173,7 +178,7 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
         '#include <stdio.h>\n#include "mlpg_hip.h"\n'
         "int main(void) {\n"
         "  mlpg_hip_stream_t s; s.in_col = 0; s.out_col = 0; s.static_dim = 1; s.num_windows = 0; s.win_first = 0; (void)s;\n"
-        '  printf("%d %d %d\\n", mlpg_hip_abi_version(), MLPG_HIP_ALGO_PIPE, MLPG_HIP_DIST_SCALED_SQL2_NP);\n'
+        '  printf("%d %d %d\\n", mlpg_hip_abi_version(), MLPG_HIP_ALGO_CONST, MLPG_HIP_DIST_SCALED_SQL2_NP);\n'
         "  return 0;\n}\n")
     exe = tmp_path / "demo"
     cmd = [gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), so,
@@ -183,4 +188,4 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, env=env)
     assert out.returncode == 0, out.stdout
-    assert out.stdout.split() == ["10", "4", "3"], out.stdout
+    assert out.stdout.split() == ["11", "5", "3"], out.stdout

@@ -179,17 +179,24 @@ def test_against_the_real_fastdtw_package_when_installed():
             x[:] = 1.0
             y[:] = 1.0                                       # every path costs the same
         cases.append((x, y))
+    # which tie rule the installed build follows (pure Python: first minimum; the compiled extension is recalled to
+    # use a strict-less chain): one rule must reproduce EVERY case
+    rules = [t for t in (0, 1) if all(
+        [tuple(p) for p in fastdtw_mod.fastdtw(x, y, radius=r, dist=lambda u, v: norm(u - v))[1]]
+        == [tuple(p) for p in OD.fastdtw(x, y, r, tie=t)[1]] for r in (1, 2) for x, y in cases)]
+    assert rules, "neither tie rule reproduces the installed fastdtw"
+    tie = rules[0]
     for radius in (1, 2):
         for x, y in cases:
             d_ref, p_ref = fastdtw_mod.fastdtw(x, y, radius=radius, dist=lambda u, v: norm(u - v))
-            d_o, p_o = OD.fastdtw(x, y, radius)
+            d_o, p_o = OD.fastdtw(x, y, radius, tie=tie)
             assert [tuple(p) for p in p_ref] == [tuple(p) for p in p_o]
             assert abs(d_ref - d_o) <= 1e-12 * max(1.0, abs(d_ref))
             X = torch.from_numpy(x[None].copy()).cuda()
             Y = torch.from_numpy(y[None].copy()).cuda()
             lx = torch.tensor([len(x)], dtype=torch.int32, device="cuda")
             ly = torch.tensor([len(y)], dtype=torch.int32, device="cuda")
-            pi, pj, pl, cost = _hip.fastdtw_l2(X, Y, lx, ly, radius)
+            pi, pj, pl, cost = _hip.fastdtw_l2(X, Y, lx, ly, radius, tie_rule=tie)
             n = int(pl[0])
             assert list(zip(pi[0, :n].tolist(), pj[0, :n].tolist())) == [tuple(p) for p in p_ref]
 
@@ -222,3 +229,126 @@ def test_many_pairs_take_the_two_launch_form_and_wide_windows_are_retried(radius
         assert pl[n] == len(path), n
         assert np.array_equal(pi[n, :pl[n]], path[:, 0]) and np.array_equal(pj[n, :pl[n]], path[:, 1]), n
         assert abs(cost[n] - d) <= 1e-12 * max(d, 1e-300), n
+
+
+def _quantised_pairs(seed=77):
+    rng = np.random.RandomState(seed)
+    pairs = []
+    for tx, ty in [(60, 60), (130, 97), (200, 230), (64, 64), (33, 90)]:
+        pairs.append((np.round(_tracks(rng, tx, 2) * 4) / 4, np.round(_tracks(rng, ty, 2) * 4) / 4))
+    pairs.append((np.zeros((50, 2)) + 1.0, np.zeros((70, 2)) + 1.0))     # all costs zero
+    x = np.round(_tracks(rng, 120, 3) * 2) / 2
+    pairs.append((x, np.concatenate([x[:1].repeat(7, 0), x])[:120]))     # shifted copy
+    return pairs
+
+
+@pytest.mark.parametrize("radius", [1, 2])
+def test_second_tie_rule_against_the_oracle(radius):
+    """tie_rule = MLPG_HIP_TIE_DIAG_LAST (the strict-less chain recalled for upstream's compiled extension) on inputs
+    full of exactly equal candidates: the kernel's paths equal the oracle's under the SAME rule, for both rules, and the
+    two rules really differ on these inputs."""
+    from nnmnkwii_amd import _hip
+    pairs = _quantised_pairs()
+    N = len(pairs)
+    Tx = max(len(x) for x, _ in pairs)
+    Ty = max(len(y) for _, y in pairs)
+    X = np.zeros((N, Tx, 3))
+    Y = np.zeros((N, Ty, 3))
+    for n, (x, y) in enumerate(pairs):
+        X[n, :len(x), :x.shape[1]] = x
+        Y[n, :len(y), :y.shape[1]] = y
+    lenx = torch.tensor([len(x) for x, _ in pairs], dtype=torch.int32, device="cuda")
+    leny = torch.tensor([len(y) for _, y in pairs], dtype=torch.int32, device="cuda")
+    got = {}
+    for tie in (_hip.TIE_FIRST_MIN, _hip.TIE_DIAG_LAST):
+        pi, pj, pl, cost = _hip.fastdtw_l2(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), lenx, leny, radius,
+                                           tie_rule=tie)
+        pi, pj, pl, cost = pi.cpu().numpy(), pj.cpu().numpy(), pl.cpu().numpy(), cost.cpu().numpy()
+        got[tie] = []
+        for n in range(N):
+            xs, ys = X[n, :len(pairs[n][0])], Y[n, :len(pairs[n][1])]
+            d, path = OD.fastdtw(xs, ys, radius, tie=tie)
+            assert pl[n] == len(path), (tie, n)
+            assert np.array_equal(pi[n, :pl[n]], path[:, 0]) and np.array_equal(pj[n, :pl[n]], path[:, 1]), (tie, n)
+            assert cost[n] == d
+            got[tie].append(list(zip(pi[n, :pl[n]].tolist(), pj[n, :pl[n]].tolist())))
+    assert sum(a != b for a, b in zip(got[0], got[1])) >= 3
+
+
+def test_second_tie_rule_through_the_host_entry_point_and_the_aligner():
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    pairs = _quantised_pairs(5)
+    N = len(pairs)
+    Tx = max(max(len(x), len(y)) for x, y in pairs)
+    X = np.zeros((N, Tx, 3))
+    Y = np.zeros((N, Tx, 3))
+    for n, (x, y) in enumerate(pairs):
+        X[n, :len(x), :x.shape[1]] = x + 3.0        # no all-zero frames inside
+        Y[n, :len(y), :y.shape[1]] = y + 3.0
+    for tie, name in ((_hip.TIE_FIRST_MIN, "first"), (_hip.TIE_DIAG_LAST, "diag_last")):
+        pi, pj, pl, cost, lenx, leny = _hip.fastdtw_host(X, Y, 1, tie_rule=tie)
+        Xa, Ya = DTWAligner(tie_rule=name).transform((X, Y))
+        for n in range(N):
+            xs, ys = X[n, :lenx[n]], Y[n, :leny[n]]
+            d, path = OD.fastdtw(xs, ys, 1, tie=tie)
+            assert pl[n] == len(path)
+            assert np.array_equal(pi[n, :pl[n]], path[:, 0]) and np.array_equal(pj[n, :pl[n]], path[:, 1]), (tie, n)
+            assert np.array_equal(Xa[n, :len(path)], xs[path[:, 0]]) and np.array_equal(Ya[n, :len(path)], ys[path[:, 1]])
+            assert not Xa[n, len(path):].any()
+
+
+def _cosine(u, v):
+    return 1.0 - float(u @ v) / (float(np.sqrt(u @ u)) * float(np.sqrt(v @ v)) + 1e-12)
+
+
+@pytest.mark.parametrize("radius", [1, 2, 4])
+def test_arbitrary_python_dist_runs_with_host_costs_and_gives_the_literal_restatements_paths(radius):
+    """A cosine distance (nothing the kernel's cost table knows): the aligner evaluates it on the host, cell by cell, and
+    the GPU does DP + back-trace + window expansion from the cost buffer.  Paths and costs equal the pure-Python
+    restatement of fastdtw called with the SAME callable; ragged lengths, pairs whose recursion depths differ, pairs
+    below the recursion threshold (one full-window level)."""
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    rng = np.random.RandomState(21 + radius)
+    sizes = [(90, 70), (33, 64), (5, 4), (2, 9), (1, 1), (140, 141), (17, 3)]
+    xs = [np.abs(_tracks(rng, a, 6)) + 0.1 for a, _ in sizes]
+    ys = [np.abs(_tracks(rng, b, 6)) + 0.1 for _, b in sizes]
+    for tie in (_hip.TIE_FIRST_MIN, _hip.TIE_DIAG_LAST):
+        pi, pj, pl, cost = _hip.fastdtw_callable(xs, ys, radius, _cosine, tie)
+        for n in range(len(xs)):
+            d, path = OD.fastdtw_py(xs[n], ys[n], radius, _cosine, tie=tie)
+            path = np.asarray(path)
+            assert pl[n] == len(path), (radius, tie, n)
+            assert np.array_equal(pi[n, :pl[n]], path[:, 0]) and np.array_equal(pj[n, :pl[n]], path[:, 1]), (radius, tie, n)
+            assert abs(cost[n] - d) <= 1e-12 * max(1.0, abs(d))
+    # through the aligner (zero padded batch, float32 input)
+    N = len(xs)
+    Tm = 150
+    X = np.zeros((N, Tm, 6), dtype=np.float32)
+    Y = np.zeros((N, Tm - 5, 6), dtype=np.float32)
+    for n in range(N):
+        X[n, :len(xs[n])] = xs[n]
+        Y[n, :len(ys[n])] = ys[n]
+    Xa, Ya = DTWAligner(dist=_cosine, radius=radius).transform((X, Y))
+    assert Xa.dtype == np.float32 and Xa.shape == Ya.shape and Xa.shape[1] >= Tm
+    for n in range(N):
+        x, y = X[n, :len(xs[n])], Y[n, :len(ys[n])]
+        _, path = OD.fastdtw_py(x.astype(np.float64), y.astype(np.float64), radius, _cosine)
+        path = np.asarray(path)
+        assert np.array_equal(Xa[n, :len(path)], x[path[:, 0]]) and np.array_equal(Ya[n, :len(path)], y[path[:, 1]]), n
+        assert not Xa[n, len(path):].any() and not Ya[n, len(path):].any()
+
+
+def test_host_cost_route_equals_the_in_kernel_route_for_the_euclidean_distance():
+    """The same pairs through both routes (costs in the kernel / costs from the host callable): identical paths."""
+    from numpy.linalg import norm
+    from nnmnkwii_amd import _hip
+    rng = np.random.RandomState(8)
+    pairs = [(_tracks(rng, a, 4), _tracks(rng, b, 4)) for a, b in [(200, 180), (64, 300), (31, 31)]]
+    pi, pj, pl, cost = _run_pairs(pairs, 1)
+    qi, qj, ql, qcost = _hip.fastdtw_callable([p[0] for p in pairs], [p[1] for p in pairs], 1, lambda u, v: norm(u - v))
+    for n in range(len(pairs)):
+        assert pl[n] == ql[n]
+        assert np.array_equal(pi[n, :pl[n]], qi[n, :pl[n]]) and np.array_equal(pj[n, :pl[n]], qj[n, :pl[n]])
+        assert abs(cost[n] - qcost[n]) <= 1e-12 * cost[n]

@@ -180,3 +180,71 @@ def test_streams_merged_launch_really_is_one_kernel():
         ref, _, rc = O.mlpg_batch(np.ascontiguousarray(m[:, :, c0:c0 + 6]), np.ascontiguousarray(v[:, :, c0:c0 + 6]), win, None)
         assert rc == 0
         assert np.abs(out[:, :, 2 * k:2 * k + 2] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_merged_stream_launch_against_the_oracle_directly(dt):
+    """The merged multi-stream launch (strip_kernel<..., MULTI>) against the CPU oracle per stream -- not against
+    another HIP launch: 40 x 1100 x 198 ragged (>= 512 strips: AUTO merges), and the same batch with ALGO_STRIP forced.
+    mlpg_hip_launch_count shows that the merged instantiation really ran."""
+    import torch
+    from nnmnkwii_amd import _hip
+    from oracle import mlpg as O
+    rng = np.random.RandomState(23)
+    B, T = 40, 1100
+    D = 180 + 3 + 15
+    m = rng.randn(B, T, D).astype(dt)
+    v = (rng.rand(B, T, D) + 0.1).astype(dt)
+    lengths = rng.randint(1, T + 1, B).astype(np.int32)
+    lengths[:3] = (T, 1, 65)
+    for b in range(B):
+        m[b, lengths[b]:] = 0
+    md, vd, Ld = torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(lengths).cuda()
+    streams = [(0, 60, STD3), (180, 1, STD3), (183, 5, STD3)]
+    tol = 1e-9 if dt == np.float64 else 2e-6
+    sel = [0, 1, 2, 7, 21, 39]
+    for algo in (_hip.ALGO_AUTO, _hip.ALGO_STRIP):
+        n0 = _hip.lib().mlpg_hip_launch_count(3)
+        out, st = _hip.forward_streams(md, vd, streams, Ld, algo=algo)
+        torch.cuda.synchronize()
+        assert _hip.lib().mlpg_hip_launch_count(3) == n0 + 1, "the streams were not merged into one strip launch"
+        assert int(st.abs().max()) == 0
+        out = out.cpu().numpy()
+        o0 = 0
+        for in_col, sd, _ in streams:
+            ref, _, rc = O.mlpg_batch(np.ascontiguousarray(m[sel][:, :, in_col:in_col + 3 * sd]),
+                                      np.ascontiguousarray(v[sel][:, :, in_col:in_col + 3 * sd]), STD3, lengths[sel])
+            assert rc == 0
+            got = out[sel][:, :, o0:o0 + sd]
+            scale = np.abs(ref).max()
+            assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() <= tol * scale, (algo, in_col)
+            for i, b in enumerate(sel):
+                assert not got[i, lengths[b]:].any()
+            o0 += sd
+
+
+def test_merged_stream_launch_against_the_reference_itself_config5_utterance():
+    """One config-5 shaped utterance (T = 2000, mgc 180 | lf0 3 | bap 15 of 198 columns, float64) inside a batch large
+    enough to merge: every stream against the reference's own paramgen.mlpg (compiled into oracle/_ref), or against the
+    oracle restatement (pinned on the reference's goldens) where /root/reference was not available to build it."""
+    import torch
+    from nnmnkwii_amd import _hip
+    from oracle import mlpg as O
+    from oracle import ref as R
+    rng = np.random.RandomState(29)
+    B, T, D = 20, 2000, 198
+    m = rng.randn(B, T, D)
+    v = rng.rand(B, T, D) + 0.1
+    streams = [(0, 60, STD3), (180, 1, STD3), (183, 5, STD3)]
+    n0 = _hip.lib().mlpg_hip_launch_count(3)
+    out, st = _hip.forward_streams(torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), streams)
+    torch.cuda.synchronize()
+    assert _hip.lib().mlpg_hip_launch_count(3) == n0 + 1
+    out = out.cpu().numpy()
+    ref_mlpg = R.load().mlpg if R.available() else O.mlpg
+    o0 = 0
+    for in_col, sd, _ in streams:
+        for b in (0, 13):
+            y = ref_mlpg(np.ascontiguousarray(m[b, :, in_col:in_col + 3 * sd]), np.ascontiguousarray(v[b, :, in_col:in_col + 3 * sd]), STD3)
+            assert np.abs(out[b, :, o0:o0 + sd] - y).max() <= 1e-9 * np.abs(y).max(), (in_col, b)
+        o0 += sd

@@ -26,7 +26,7 @@ def main():
             v = torch.rand(B, T, 3 * sd, dtype=dt, device="cuda") + 0.5
             pw = _hip.prepack_windows(WINDOWS)
             row = []
-            for algo in (_hip.ALGO_WAVE, _hip.ALGO_STRIP, _hip.ALGO_GENERIC, _hip.ALGO_PIPE):
+            for algo in (_hip.ALGO_WAVE, _hip.ALGO_STRIP, _hip.ALGO_GENERIC, _hip.ALGO_CONST):
                 try:
                     if backward:
                         go = m[:, :, :sd].contiguous()
@@ -36,8 +36,8 @@ def main():
                 except Exception as e:  # unsupported shape for that kernel
                     ms = float("nan")
                 row.append(ms)
-            best = ["wave", "strip", "generic", "pipe"][int(np.nanargmin(row))]
-            print(("bwd " if backward else "fwd ") + "%s B=%4d T=%4d sd=%3d  wave %.4f  strip %.4f  generic %.4f  pipe %.4f  -> %s" % (str(dt)[6:], B, T, sd, row[0], row[1], row[2], row[3], best), flush=True)
+            best = ["wave", "strip", "generic", "const"][int(np.nanargmin(row))]
+            print(("bwd " if backward else "fwd ") + "%s B=%4d T=%4d sd=%3d  wave %.4f  strip %.4f  generic %.4f  const %.4f  -> %s" % (str(dt)[6:], B, T, sd, row[0], row[1], row[2], row[3], best), flush=True)
             del m, v
 
 

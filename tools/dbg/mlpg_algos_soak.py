@@ -1,4 +1,4 @@
-"""Random soak of every MLPG kernel (natural-order, wave-per-system, strip, pipelined strip) against the C oracle (forward)
+"""Random soak of every MLPG kernel (natural-order, wave-per-system, strip, constant-coefficient) against the C oracle (forward)
 and against each other (backward: the natural-order kernel is the reference, itself pinned by tests/): random batch sizes,
 lengths (ragged), static dims 1..130, the three variance modes, float32 / float64, window sets of extent <= 1 (all kernels) and
 wider ones (natural-order kernel vs the oracle only).   usage: python tools/dbg/mlpg_algos_soak.py [seconds]"""
@@ -22,7 +22,7 @@ def soak(budget=40.0, seed=99):
     t0 = time.time()
     n = 0
     bad = None
-    names = {1: "generic", 2: "wave", 3: "strip", 4: "pipe"}
+    names = {1: "generic", 2: "wave", 3: "strip", 5: "const"}
     while time.time() - t0 < budget and bad is None:
         dt = [np.float64, np.float32][rng.randint(2)]
         tol = 2e-9 if dt == np.float64 else 3e-6
@@ -56,7 +56,7 @@ def soak(budget=40.0, seed=99):
         Ld = torch.from_numpy(lengths).cuda()
         scale = max(1.0, float(np.abs(ref).max()))
         slack = 1.0 if spread < 3.0 else 1e4              # ill-conditioned systems: the kernels agree with each other to ~1e-6
-        for algo in (1, 2, 3, 4):
+        for algo in (1, 2, 3, 5):
             try:
                 out, status = _hip.forward(md, vd, win, Ld, algo=algo)
             except _hip.HipExtensionError:
@@ -69,7 +69,7 @@ def soak(budget=40.0, seed=99):
             g = torch.from_numpy(rng.randn(B, T, sd).astype(dt)).cuda()
             gref, _ = _hip.backward(vd, g, win, nw * sd, lengths=Ld, out_dtype=md.dtype, algo=1)
             gs = max(1e-30, float(gref.abs().max()))
-            for algo in (2, 3, 4):
+            for algo in (2, 3, 5):
                 try:
                     go, status = _hip.backward(vd, g, win, nw * sd, lengths=Ld, out_dtype=md.dtype, algo=algo)
                 except _hip.HipExtensionError:
