@@ -157,6 +157,33 @@ int mlpg_hip_fastdtw_host(int device, int dtype, const void *X_h, const void *Y_
                           int radius, int dist_kind, double dist_scale, int tie_rule, double trim_eps,
                           int32_t *path_i_h, int32_t *path_j_h, int32_t *path_len_h, double *cost_h,
                           int32_t *lenx_out_h, int32_t *leny_out_h);
+/*
+ * The two host-memory calls over SEVERAL devices from one process (the reference's batch loops --
+ * util/__init__.py:44-66 over utterances, preprocessing/alignment.py:45 over pairs -- have no dependence between
+ * items, so the batch shards with no exchange).  devices[0 .. num_devices): HIP device indices; NULL / 0: every visible
+ * device.  Chunk c of the batch runs on list entry c % n, on that entry's stream pair slot (c / n) % 2; per device the
+ * behaviour is the single-device call's, results and verdicts land at the chunk's own offset of the caller's arrays.
+ * A device may be listed up to 4 times (each occurrence has its own staging buffers and streams).  On an error every
+ * stream that was used is drained before the call returns.  mlpg_hip_forward_host(d, ...) == _multi(&d, 1, ...).
+ */
+int mlpg_hip_forward_host_multi(const int32_t *devices, int num_devices, int dtype, int algo, const void *mean_h,
+                                const void *var_h, int var_mode, const int32_t *lengths_h, int B, int Tmax, int D,
+                                int num_windows, const int32_t *win_l_h, const int32_t *win_u_h,
+                                const double *win_coef_h, void *out_h, int32_t *status_h);
+int mlpg_hip_fastdtw_host_multi(const int32_t *devices, int num_devices, int dtype, const void *X_h, const void *Y_h,
+                                const int32_t *lenx_h, const int32_t *leny_h, int N, int Tx, int Ty, int D,
+                                int radius, int dist_kind, double dist_scale, int tie_rule, double trim_eps,
+                                int32_t *path_i_h, int32_t *path_j_h, int32_t *path_len_h, double *cost_h,
+                                int32_t *lenx_out_h, int32_t *leny_out_h);
+/*
+ * The chunk dealing of the host-memory calls, as a pure function (no device needed): n_items utterances / pairs in
+ * chunks of min(target_items, ceil(n_items / (4 * num_devices))) items (at least 4 chunks per device when the batch
+ * allows).  Fills, for the first max_chunks chunks, the device-list entry, the stream slot, the first item and the
+ * item count (any array may be NULL); returns the number of chunks, negative on bad arguments.
+ */
+long long mlpg_hip_host_chunk_plan(long long n_items, long long target_items, int num_devices, long long max_chunks,
+                                   int32_t *entry, int32_t *slot, int64_t *first, int64_t *count);
+
 /* Pinned host memory for arrays that are handed to mlpg_hip_forward_host repeatedly (transferred in place). */
 void *mlpg_hip_host_alloc(size_t bytes);
 void mlpg_hip_host_free(void *p);
@@ -191,6 +218,8 @@ void mlpg_hip_host_free(void *p);
  * (no host synchronisation; capturable): when the call returns, everything is
  * ordered on `stream`.  Which kernel solves a dim depends on the grouping, the
  * results agree to rounding (every kernel is held to the same parity bar).
+ * Limits: 1 <= num_streams <= 64 (MLPG_HIP_EINVAL beyond), at most 4 streams
+ * share one merged launch.
  */
 typedef struct {
   int32_t in_col;      /* first column of the stream in mean / var rows  */

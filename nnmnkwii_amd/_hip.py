@@ -42,6 +42,9 @@ EXPORTS = (
     "mlpg_hip_modspec_set_direct",
     "mlpg_hip_trim_lengths",
     "mlpg_hip_fastdtw",
+    "mlpg_hip_forward_host_multi",
+    "mlpg_hip_fastdtw_host_multi",
+    "mlpg_hip_host_chunk_plan",
     "mlpg_hip_dtw_level_windows",
     "mlpg_hip_dtw_level_from_costs",
     "mlpg_hip_fastdtw_l2",
@@ -95,6 +98,13 @@ def lib():
         L.mlpg_hip_fastdtw_host.restype = ci
         L.mlpg_hip_fastdtw_host.argtypes = [ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_double, ci, ctypes.c_double,
                                             vp, vp, vp, vp, vp, vp]
+        L.mlpg_hip_forward_host_multi.restype = ci
+        L.mlpg_hip_forward_host_multi.argtypes = [vp, ci, ci, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
+        L.mlpg_hip_fastdtw_host_multi.restype = ci
+        L.mlpg_hip_fastdtw_host_multi.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_double, ci,
+                                                  ctypes.c_double, vp, vp, vp, vp, vp, vp]
+        L.mlpg_hip_host_chunk_plan.restype = ctypes.c_longlong
+        L.mlpg_hip_host_chunk_plan.argtypes = [ctypes.c_longlong, ctypes.c_longlong, ci, ctypes.c_longlong, vp, vp, vp, vp]
         L.mlpg_hip_host_alloc.restype = vp
         L.mlpg_hip_host_alloc.argtypes = [ctypes.c_size_t]
         L.mlpg_hip_host_free.restype = None
@@ -264,7 +274,7 @@ def current_device_index(device=None):
     process's current device (what torch.cuda.set_device(local_rank) selected in a one-process-per-GPU job; 0 when
     torch has not been imported -- the entry points themselves need no torch)."""
     if device is not None:
-        idx = getattr(device, "index", device)
+        idx = device if isinstance(device, str) else getattr(device, "index", device)
         if isinstance(idx, str):
             idx = idx.split(":")[-1] if ":" in idx else None
         if idx is not None:
@@ -275,13 +285,38 @@ def current_device_index(device=None):
     return 0
 
 
+def device_list(device=None):
+    """The int32 device list of the *_host_multi entry points: ``"all"`` -> empty (= every visible device), a list /
+    tuple of indices as given (an index may repeat: each occurrence gets its own streams and staging buffers), anything
+    else -> the one device current_device_index picks."""
+    if isinstance(device, str) and device == "all":
+        return np.zeros((0,), dtype=np.int32)
+    if isinstance(device, (list, tuple, np.ndarray)):
+        return np.ascontiguousarray([current_device_index(d) for d in device], dtype=np.int32)
+    return np.asarray([current_device_index(device)], dtype=np.int32)
+
+
+def host_chunk_plan(n_items, target_items, num_devices):
+    """mlpg_hip_host_chunk_plan (pure host logic, no GPU needed): how the host-memory calls deal a batch to the devices.
+    Returns int arrays (entry, slot, first, count), one element per chunk."""
+    L = lib()
+    n = int(L.mlpg_hip_host_chunk_plan(int(n_items), int(target_items), int(num_devices), 0, None, None, None, None))
+    if n < 0:
+        _check(n, "mlpg_hip_host_chunk_plan")
+    entry, slot = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    first, count = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    L.mlpg_hip_host_chunk_plan(int(n_items), int(target_items), int(num_devices), n, _np(entry), _np(slot), _np(first), _np(count))
+    return entry, slot, first, count
+
+
 def forward_host(mean, var, windows, lengths=None, algo=ALGO_AUTO, device=None):
-    """Batched MLPG, numpy in -> numpy out through mlpg_hip_forward_host (no torch involved): mean (B, T, D)
+    """Batched MLPG, numpy in -> numpy out through mlpg_hip_forward_host_multi (no torch involved): mean (B, T, D)
     float32/float64 C-contiguous, var same shape / (D,) / None, lengths int32 (B,) or None; device: GPU index
-    (default: the current device, see current_device_index).
+    (default: the current device, see current_device_index), a list of indices, or "all" (every visible device; the
+    utterance chunks are dealt round-robin, see device_list).
     Returns (out (B, T, sd) ndarray, status int32 (B, sd))."""
     L = lib()
-    device = current_device_index(device)
+    devs = device_list(device)
     if L.mlpg_hip_device_count() <= 0:
         raise HipExtensionError("nnmnkwii_amd needs an AMD GPU (none visible to the HIP runtime); there is no CPU fallback")
     assert mean.ndim == 3 and mean.flags.c_contiguous and mean.dtype in (np.float32, np.float64)
@@ -300,10 +335,10 @@ def forward_host(mean, var, windows, lengths=None, algo=ALGO_AUTO, device=None):
         assert lengths.shape == (B,)
     out = np.empty((B, T, D // nw), dtype=mean.dtype)
     status = np.zeros((B, D // nw), dtype=np.int32)
-    rc = L.mlpg_hip_forward_host(int(device), dt, algo, _np(mean), None if var is None else _np(var), mode,
-                                 None if lengths is None else _np(lengths), B, T, D, nw, _np(wl), _np(wu), _np(wc),
-                                 _np(out), _np(status))
-    _check(rc, "mlpg_hip_forward_host")
+    rc = L.mlpg_hip_forward_host_multi(_np(devs) if len(devs) else None, len(devs), dt, algo, _np(mean),
+                                       None if var is None else _np(var), mode, None if lengths is None else _np(lengths),
+                                       B, T, D, nw, _np(wl), _np(wu), _np(wc), _np(out), _np(status))
+    _check(rc, "mlpg_hip_forward_host_multi")
     return out, status
 
 
@@ -605,7 +640,7 @@ def fastdtw_host(X, Y, radius=1, dist_kind=DIST_L2, dist_scale=1.0, lenx=None, l
     all-zero frames are trimmed on the device (eps as trim_zeros_frames).  Returns numpy
     (path_i, path_j (N, Tx+Ty) int32, path_len (N,), cost (N,), lenx, leny)."""
     L = lib()
-    device = current_device_index(device)
+    devs = device_list(device)
     X = np.ascontiguousarray(X)
     Y = np.ascontiguousarray(Y)
     # one dtype for the C entry point; mixed or non-float inputs are WIDENED to float64 (each array from its own
@@ -625,11 +660,11 @@ def fastdtw_host(X, Y, radius=1, dist_kind=DIST_L2, dist_scale=1.0, lenx=None, l
     if lenx is not None:
         lenx = np.ascontiguousarray(lenx, dtype=np.int32)
         leny = np.ascontiguousarray(leny, dtype=np.int32)
-    rc = L.mlpg_hip_fastdtw_host(int(device), F32 if X.dtype == np.float32 else F64, _np(X), _np(Y),
-                                 None if lenx is None else _np(lenx), None if leny is None else _np(leny), N, Tx, Ty, D,
-                                 int(radius), int(dist_kind), float(dist_scale), int(tie_rule), float(eps), _np(path_i), _np(path_j),
-                                 _np(path_len), _np(cost), _np(lx_out), _np(ly_out))
-    _check(rc, "mlpg_hip_fastdtw_host")
+    rc = L.mlpg_hip_fastdtw_host_multi(_np(devs) if len(devs) else None, len(devs), F32 if X.dtype == np.float32 else F64,
+                                       _np(X), _np(Y), None if lenx is None else _np(lenx), None if leny is None else _np(leny),
+                                       N, Tx, Ty, D, int(radius), int(dist_kind), float(dist_scale), int(tie_rule), float(eps),
+                                       _np(path_i), _np(path_j), _np(path_len), _np(cost), _np(lx_out), _np(ly_out))
+    _check(rc, "mlpg_hip_fastdtw_host_multi")
     return path_i, path_j, path_len, cost, lx_out, ly_out
 
 
@@ -646,6 +681,7 @@ def gather_path(src, path, path_len, Tout):
 
 
 _MSE_WORKSPACE = {}
+_MSE_WORKSPACE_RETIRED = []   # outgrown workspaces stay allocated: a captured graph may still replay kernels that use them
 
 
 def unit_mse_step(mean, target, windows, lengths=None, n_elems=None, want_y=False, want_status=False):
@@ -673,6 +709,8 @@ def unit_mse_step(mean, target, windows, lengths=None, n_elems=None, want_y=Fals
     if ws is None or ws.numel() < need:
         # zeroed once; the kernel leaves its arrival counter zero.  One per (device, stream): concurrent streams do not share
         # it; allocated on first use outside any capture (warm up a step before capturing it into a graph).
+        if ws is not None:
+            _MSE_WORKSPACE_RETIRED.append(ws)
         ws = torch.zeros((need + 4095) // 4096 * 4096, dtype=torch.uint8, device=mean.device)
         _MSE_WORKSPACE[key] = ws
     rc = lib().mlpg_hip_unit_mse_step(mean.device.index, _stream(mean.device), _dt(mean), _p(mean), _p(target), _p(lengths),

@@ -252,11 +252,51 @@ class UnitVarianceMLPGMSELoss(Function):
         return _back(g.reshape(ctx.shape), ctx.like), None, None
 
 
+class _UnitVarianceMLPGWindows(Function):
+    """Unit-variance MLPG from the window list (no ``R``): the banded solves of :class:`UnitVarianceMLPG` for
+    frame-major ``means`` ``(B, T, D)`` / ``(T, D)``.  The two-node form :func:`unit_variance_mlpg_mse_loss` falls back
+    to where the fused kernel does not apply."""
+
+    @staticmethod
+    def forward(ctx, means, windows):
+        dev = _hip.require_gpu(means.device if means.is_cuda else None)
+        m = _to_gpu(means, dev)
+        if m.dtype not in (torch.float32, torch.float64):
+            m = m.to(torch.float32)
+        ctx.windows, ctx.like, ctx.dim, ctx.D = windows, means, means.dim(), means.shape[-1]
+        out, _ = _hip.forward(m[None] if m.dim() == 2 else m.contiguous(), None, windows, want_status=False)
+        return _back(out[0] if means.dim() == 2 else out, means)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        dev = _hip.require_gpu(grad_output.device if grad_output.is_cuda else None)
+        go = _to_gpu(grad_output, dev)
+        if go.dtype not in (torch.float32, torch.float64):
+            go = go.to(torch.float32)
+        go = (go[None] if ctx.dim == 2 else go).contiguous()
+        grad, _ = _hip.backward(None, go, ctx.windows, ctx.D, out_dtype=go.dtype, want_status=False)
+        return _back(grad[0] if ctx.dim == 2 else grad, ctx.like), None
+
+
+def _fused_step_applies(windows, means, target):
+    """What mlpg_hip_unit_mse_step accepts (csrc/mlpg_wave_fused.hip unit_mse_supported) and what the fused node can
+    differentiate: T <= 1024, window extents <= 1, no gradient wanted for the target."""
+    if torch.is_tensor(target) and target.requires_grad:
+        return False
+    if means.shape[-2] > 1024:
+        return False
+    if isinstance(windows, _hip.PackedWindows):          # (l[], u[], coeff[], nw): what _identify_R hands back
+        return bool((np.asarray(windows[0]) <= 1).all() and (np.asarray(windows[1]) <= 1).all())
+    return all(int(l) <= 1 and int(u) <= 1 for l, u, _ in windows)
+
+
 def unit_variance_mlpg_mse_loss(R_or_windows, means, target):
     """``torch.nn.functional.mse_loss(unit_variance_mlpg(R, means), target)`` in one fused launch
     (:class:`UnitVarianceMLPGMSELoss`).  The first argument is either the matrix ``R`` from
     :func:`nnmnkwii_amd.paramgen.unit_variance_mlpg_matrix` (recognised by content, as in
-    :func:`unit_variance_mlpg`) or the window list itself.  A foreign ``R`` falls back to the two-node form."""
+    :func:`unit_variance_mlpg`) or the window list itself.  Falls back to the two-node form -- same value, same
+    gradients -- for a foreign ``R``, for T > 1024 or window extents > 1 (the fused kernel's limits) and when
+    ``target`` wants a gradient.  The loss lives on ``means.device`` (as in the eager form)."""
     if torch.is_tensor(R_or_windows):
         ident = _identify_R(R_or_windows)
         if ident is None or means.shape[-2] != R_or_windows.shape[0]:
@@ -264,4 +304,7 @@ def unit_variance_mlpg_mse_loss(R_or_windows, means, target):
         windows = ident[0]
     else:
         windows = R_or_windows
-    return UnitVarianceMLPGMSELoss.apply(means, target, windows)
+    if not _fused_step_applies(windows, means, target):
+        y = _UnitVarianceMLPGWindows.apply(means, windows)
+        return torch.nn.functional.mse_loss(y, target.to(device=y.device, dtype=y.dtype) if torch.is_tensor(target) else target)
+    return UnitVarianceMLPGMSELoss.apply(means, target, windows).to(means.device)

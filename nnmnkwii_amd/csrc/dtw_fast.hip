@@ -495,7 +495,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       if (lane == 0) {
         rw[2 * ltx] = 0u;
         rw[2 * ltx + 1] = (unsigned)total;
-        bcast[3] = total > p.cellcap ? 1 : 0;
+        bcast[3] = total > p.cellcap ? 1 : 0;  // (one flag word per check: [3] cells, [4] chunk table, [7] back-pointer
+        bcast[7] = 0;                           //  words -- a reused word could be rewritten by wavefront 0 before a slow
+                                                //  wavefront has read the previous verdict after its barrier)
         // virtual row -1 of the level: D[-1][-1] = 0, nothing else -- the row "handed over" to chunk 0
         dchunk[kSlack - 2] = INFINITY;
         dchunk[kSlack - 1] = INFINITY;
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       if (lane == 0) {
         cstart[nc] = (unsigned short)ltx;
         bcast[2] = nc;
-        bcast[3] = bad;
+        bcast[4] = bad;
       }
     } else {
       // meanwhile the other wavefronts compute the local costs of chunk 0 -- its rows follow from the same rule (at
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       if (R0 >= 1) chunk_costs_rows(0, R0, dchunk, 64, kThreads - 64);
     }
     __syncthreads();
-    if (bcast[3]) fail = true;
+    if (bcast[4]) fail = true;
     if (fail) break;
     const int nchunk = bcast[2];
 
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       const int H = hw_next + wave_excl_scan(nhw, lane, &hw_total);
       hw_next += hw_total;
       if (hw_next > p.hwcap) {  // uniform: the level does not fit (optimistic capacities); nothing is written
-        if (lane == 0) bcast[3] = 1;
+        if (lane == 0) bcast[7] = 1;
       } else {
       const int hw_dummy = lds_addr(bp16 + bp_dummy + lane);
       int hw_run = lds_addr(bp16) + 2 * H;  // halfword of block q_rel = 0
@@ -776,9 +778,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       DTW_TICK(4);
       __syncthreads();
       DTW_TICK(2);  // the sweeper waiting for the next chunk's costs
-      if (bcast[3]) break;
+      if (bcast[7]) break;
     }
-    if (bcast[3]) fail = true;
+    if (bcast[7]) fail = true;
     if (fail) break;
     last_val = *(const double *)(bcast + 12);  // (written before the last chunk's barrier)
     level_cost = (prevhi == lty - 1) ? last_val : INFINITY;
@@ -1045,13 +1047,19 @@ int launch_fastdtw(hipStream_t s, int device, const double *X, const double *Y, 
   q.hwcap = (int)(2.5 * Tx) + 64;
   if (q.hwcap > p.hwcap) q.hwcap = p.hwcap;
   const size_t lds_q = lds_bytes(Tx, Ty, q);
-  static const int force = [] { const char *e = getenv("MLPG_HIP_DTW_FORCE"); return e ? atoi(e) : 0; }();  // measurement switch: 1 two launches, 2 one
+#ifdef MLPG_DTW_MEASURE  // measurement builds only (tools/dbg/dtw_scaling.py, dtw_tiers.py): 1 two launches, 2 one
+  static const int force = [] { const char *e = getenv("MLPG_HIP_DTW_FORCE"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int force = 0;
+#endif
   if (force != 2 && (N > 2 * cus || force == 1) && q.chunkcap < p.chunkcap && lds_q <= 40 * 1024) {
     if (int rc = tie_rule == MLPG_HIP_TIE_FIRST_MIN ? launch_one<256, MLPG_HIP_TIE_FIRST_MIN>(s, q, N, lds_q)
                                                      : launch_one<256, MLPG_HIP_TIE_DIAG_LAST>(s, q, N, lds_q))
       return rc;
-    static const bool first_only = getenv("MLPG_HIP_DTW_FIRST_LAUNCH_ONLY") != nullptr;  // measurement switch
+#ifdef MLPG_DTW_MEASURE  // leaves the pairs that overflowed the optimistic capacities at path_len = -1
+    static const bool first_only = getenv("MLPG_HIP_DTW_FIRST_LAUNCH_ONLY") != nullptr;
     if (first_only) return 0;
+#endif
     p.tier = 2;
   }
   return tie_rule == MLPG_HIP_TIE_FIRST_MIN ? launch_one<512, MLPG_HIP_TIE_FIRST_MIN>(s, p, N, lds)

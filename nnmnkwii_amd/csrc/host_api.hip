@@ -7,7 +7,21 @@
 // and under the CPU-side staging of the next.  Pageable host memory is staged through pinned buffers by a few copy
 // threads (a single-threaded memcpy is slower than PCIe Gen5); memory that is already pinned (mlpg_hip_host_alloc,
 // hipHostMalloc, hipHostRegister) is transferred in place.
+//
+// The *_multi forms take a LIST of devices (utterances / pairs are independent, so a batch shards
+// with no exchange at all): chunk c goes to list entry c % n, on that entry's stream pair slot (c / n) % 2
+// (host_chunk_plan below -- the whole dealing logic, exported for the CPU tests as mlpg_hip_host_chunk_plan).  One host
+// thread drives every device; per device the behaviour is exactly the single-device one, and results land in the
+// caller's arrays at the chunk's own offset, so the merge of outputs and verdicts is positional.  A device may appear
+// several times in the list (each occurrence gets its own staging context): that is how the GPU tests exercise the
+// dealing on a one-GPU box.
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -34,8 +48,90 @@ struct HostCtx {
   size_t dev_bytes = 0;
   bool ok = false;
 };
-HostCtx g_host[16];
+constexpr int kMaxHostDevices = 16;  // device indices the host entry points accept
+constexpr int kMaxRep = 4;           // staging contexts per device (occurrences of one device in a device list)
+constexpr int kMaxList = 32;         // entries of a device list
+HostCtx g_host[kMaxHostDevices][kMaxRep];
 std::mutex g_host_mu;
+
+// A resolved device list: entry k runs on device dev[k] with staging context ctx[k].
+struct DevList {
+  int n = 0;
+  int dev[kMaxList];
+  HostCtx *ctx[kMaxList];
+};
+
+// devices == NULL or num_devices <= 0: every visible device once.
+int resolve_devices(const int32_t *devices, int num_devices, DevList *dl) {
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess) {
+    (void)hipGetLastError();
+    visible = 0;
+  }
+  if (visible <= 0) {
+    set_error("no HIP device is visible");
+    return MLPG_HIP_EINVAL;
+  }
+  if (visible > kMaxHostDevices) visible = kMaxHostDevices;
+  int used[kMaxHostDevices] = {};
+  dl->n = 0;
+  if (!devices || num_devices <= 0) {
+    for (int d = 0; d < visible; ++d) {
+      dl->dev[dl->n] = d;
+      dl->ctx[dl->n++] = &g_host[d][0];
+    }
+    return 0;
+  }
+  if (num_devices > kMaxList) {
+    set_error("device list longer than %d", kMaxList);
+    return MLPG_HIP_EINVAL;
+  }
+  for (int k = 0; k < num_devices; ++k) {
+    const int d = devices[k];
+    if (d < 0 || d >= visible) {
+      set_error("bad device %d (%d visible)", d, visible);
+      return MLPG_HIP_EINVAL;
+    }
+    if (used[d] >= kMaxRep) {
+      set_error("device %d appears more than %d times in the device list", d, kMaxRep);
+      return MLPG_HIP_EINVAL;
+    }
+    dl->dev[dl->n] = d;
+    dl->ctx[dl->n++] = &g_host[d][used[d]++];
+  }
+  return 0;
+}
+
+// Chunk c of a batch cut into chunks of `chunk` items, dealt over n list entries.
+inline void host_chunk_owner(long c, int n, int *entry, int *slot) {
+  *entry = (int)(c % n);
+  *slot = (int)((c / n) & 1);
+}
+
+// Items per chunk: about `target` items, but at least 4 chunks per device when the batch allows (so that the transfers of
+// one chunk run under the kernels of another on every device).
+inline long host_chunk_items(long n_items, long target, int n) {
+  return std::max<long>(1, std::min<long>(target, (n_items + 4L * n - 1) / (4L * n)));
+}
+
+// Populate the page tables of a pageable output array in the background (its first touch otherwise happens inside the
+// final host copy: 6 ms of page faults for config 2's 123 MB).  MADV_POPULATE_WRITE leaves the content alone, so it
+// needs no ordering against the copies; where the kernel does not know it nothing happens.
+struct Prefault {
+  std::thread th;
+  void start(void *p, size_t bytes) {
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    if (bytes < (8u << 20) || page == 0) return;
+    const uintptr_t lo = ((uintptr_t)p + page - 1) & ~(uintptr_t)(page - 1), hi = ((uintptr_t)p + bytes) & ~(uintptr_t)(page - 1);
+    if (hi <= lo) return;
+    th = std::thread([lo, hi] {
+      const size_t step = 8u << 20;
+      for (uintptr_t a = lo; a < hi; a += step)
+        if (madvise((void *)a, std::min<size_t>(step, hi - a), 23 /* MADV_POPULATE_WRITE */) != 0) return;
+    });
+  }
+  ~Prefault() { if (th.joinable()) th.join(); }
+};
 
 bool is_pinned(const void *p) {
   hipPointerAttribute_t a;
@@ -48,7 +144,12 @@ bool is_pinned(const void *p) {
 
 void parallel_copy(void *dst, const void *src, size_t bytes) {
   const size_t kMin = 4u << 20;
-  unsigned nt = std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
+  static const unsigned max_threads = [] {
+    const char *e = getenv("MLPG_HIP_HOST_COPY_THREADS");
+    const long v = e ? atol(e) : 0;
+    return (unsigned)(v > 0 ? std::min<long>(v, 64) : 16);
+  }();
+  unsigned nt = std::min<unsigned>(max_threads, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
   if (bytes < 2 * kMin || nt == 1) {
     memcpy(dst, src, bytes);
     return;
@@ -107,8 +208,9 @@ __global__ void widen_f32(const float *__restrict__ src, double *__restrict__ ds
 
 void host_api_shutdown() {
   std::lock_guard<std::mutex> lk(g_host_mu);
-  for (int d = 0; d < 16; ++d) {
-    HostCtx &c = g_host[d];
+  for (int dr = 0; dr < kMaxHostDevices * kMaxRep; ++dr) {
+    const int d = dr / kMaxRep;
+    HostCtx &c = g_host[d][dr % kMaxRep];
     if (!c.ok && !c.dev[0] && !c.pin_in[0] && !c.pin_out[0]) continue;
     (void)hipSetDevice(d);
     for (int k = 0; k < 2; ++k) {
@@ -128,6 +230,156 @@ void host_api_shutdown() {
 
 using namespace mlpg;
 
+extern "C" const char *mlpg_hip_last_error(void);
+
+namespace {
+
+// MLPG_HIP_HOST_TRACE=1: where the host thread of a host-memory call spends its time (stderr, one line per call).
+struct HostTrace {
+  bool on;
+  double t_wait = 0, t_submit = 0, t_collect = 0, t0;
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  HostTrace() {
+    static const bool env = [] { const char *e = getenv("MLPG_HIP_HOST_TRACE"); return e && atoi(e) > 0; }();
+    on = env;
+    t0 = on ? now() : 0.0;
+  }
+  void report(long nchunks, int n) const {
+    if (on)
+      fprintf(stderr, "[mlpg_hip host] %ld chunks over %d list entries: %.2f ms total = %.2f waiting for the collector + %.2f staging/enqueue; collector thread: %.2f copying results\n",
+              nchunks, n, 1e3 * (now() - t0), 1e3 * t_wait, 1e3 * t_submit, 1e3 * t_collect);
+  }
+};
+
+// Runs `nchunks` chunks over the device list: submit(entry, slot, c) enqueues chunk c on dl.ctx[entry]->st[slot] (the
+// device is current), collect(entry, slot, c) hands the finished chunk's staged results to the caller (on the collector
+// thread, in chunk order).  A slot is collected before it is reused and everything is collected before the call
+// returns.  After an error nothing is left in flight: every stream that was used is drained before it is returned.
+template <class Submit, class Collect>
+int run_chunks(const DevList &dl, long nchunks, Submit submit, Collect collect) {
+  HostTrace tr;
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess) {
+    (void)hipGetLastError();
+    prev = -1;
+  }
+  // The collector thread waits for each chunk's event (in chunk order) and moves its staged results into the caller's
+  // arrays while this thread stages the next chunks: with pageable inputs the calling thread is the critical path.
+  struct {
+    std::mutex mu;
+    std::condition_variable cv;
+    long submitted = 0, collected = 0;
+    int rc = 0;
+    bool stop = false;
+    double t_collect = 0;
+    char msg[512] = "";  // the collector's error text (the library's last-error string is per thread)
+  } col;
+  std::thread collector([&] {
+    for (long c = 0;; ++c) {
+      {
+        std::unique_lock<std::mutex> lk(col.mu);
+        col.cv.wait(lk, [&] { return col.submitted > c || col.stop; });
+        if (col.submitted <= c) return;
+      }
+      int e, slot;
+      host_chunk_owner(c, dl.n, &e, &slot);
+      int rc = 0;
+      if (hipSetDevice(dl.dev[e]) != hipSuccess || hipEventSynchronize(dl.ctx[e]->done[slot]) != hipSuccess) {
+        set_error("host call: waiting for chunk %ld on device %d failed: %s", c, dl.dev[e], hipGetErrorString(hipGetLastError()));
+        rc = MLPG_HIP_ERUNTIME;
+      }
+      const double ta = tr.on ? HostTrace::now() : 0.0;
+      if (!rc) rc = collect(e, slot, c);
+      {
+        std::lock_guard<std::mutex> lk(col.mu);
+        col.collected = c + 1;
+        if (rc && !col.rc) {
+          col.rc = rc;
+          snprintf(col.msg, sizeof(col.msg), "%s", mlpg_hip_last_error());
+        }
+        if (tr.on) col.t_collect += HostTrace::now() - ta;
+      }
+      col.cv.notify_all();
+    }
+  });
+  auto wait_collected = [&](long c) -> int {  // chunk c's results are with the caller, its slot is free again
+    const double ta = tr.on ? HostTrace::now() : 0.0;
+    std::unique_lock<std::mutex> lk(col.mu);
+    col.cv.wait(lk, [&] { return col.collected > c; });
+    if (tr.on) tr.t_wait += HostTrace::now() - ta;
+    if (col.rc) set_error("%s", col.msg);
+    return col.rc;
+  };
+  int cur = -1, rc = 0;
+  long done = 0;  // chunks handed to the collector
+  for (long c = 0; c < nchunks && !rc; ++c) {
+    int e, slot;
+    host_chunk_owner(c, dl.n, &e, &slot);
+    if (c >= 2L * dl.n && (rc = wait_collected(c - 2L * dl.n))) break;
+    if (cur != dl.dev[e]) {
+      if (hipSetDevice(dl.dev[e]) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed: %s", dl.dev[e], hipGetErrorString(hipGetLastError()));
+        rc = MLPG_HIP_ERUNTIME;
+        break;
+      }
+      cur = dl.dev[e];
+    }
+    const double ts = tr.on ? HostTrace::now() : 0.0;
+    if ((rc = submit(e, slot, c))) break;
+    if (hipEventRecord(dl.ctx[e]->done[slot], dl.ctx[e]->st[slot]) != hipSuccess) {
+      set_error("hipEventRecord failed: %s", hipGetErrorString(hipGetLastError()));
+      rc = MLPG_HIP_ERUNTIME;
+      break;
+    }
+    if (tr.on) tr.t_submit += HostTrace::now() - ts;
+    {
+      std::lock_guard<std::mutex> lk(col.mu);
+      col.submitted = done = c + 1;
+    }
+    col.cv.notify_all();
+  }
+  if (done > 0) {
+    const int rc2 = wait_collected(done - 1);  // everything that was enqueued is collected (also after an error)
+    if (!rc) rc = rc2;
+  }
+  {
+    std::lock_guard<std::mutex> lk(col.mu);
+    col.stop = true;
+  }
+  col.cv.notify_all();
+  collector.join();
+  if (rc) {  // nothing is left in flight
+    for (int e = 0; e < dl.n; ++e) {
+      if (hipSetDevice(dl.dev[e]) != hipSuccess) continue;
+      for (int k = 0; k < 2; ++k)
+        if (dl.ctx[e]->st[k]) (void)hipStreamSynchronize(dl.ctx[e]->st[k]);
+    }
+    (void)hipGetLastError();
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  tr.t_collect = col.t_collect;
+  tr.report(nchunks, dl.n);
+  return rc;
+}
+
+int ensure_all(const DevList &dl, size_t in_bytes, size_t out_bytes, size_t dev_bytes) {
+  int prev = -1;
+  MLPG_HIP_CHECK(hipGetDevice(&prev));
+  int rc = 0;
+  for (int e = 0; e < dl.n && !rc; ++e) {
+    if (hipSetDevice(dl.dev[e]) != hipSuccess) {
+      set_error("hipSetDevice(%d) failed: %s", dl.dev[e], hipGetErrorString(hipGetLastError()));
+      rc = MLPG_HIP_ERUNTIME;
+      break;
+    }
+    rc = ensure(*dl.ctx[e], in_bytes, out_bytes, dev_bytes);
+  }
+  (void)hipSetDevice(prev);
+  return rc;
+}
+
+}  // namespace
+
 extern "C" {
 
 __attribute__((visibility("default"))) void *mlpg_hip_host_alloc(size_t bytes) {
@@ -144,12 +396,34 @@ __attribute__((visibility("default"))) void mlpg_hip_host_free(void *p) {
   if (p) (void)hipHostFree(p);
 }
 
-__attribute__((visibility("default"))) int mlpg_hip_forward_host(int device, int dtype, int algo, const void *mean_h,
-                                                                 const void *var_h, int var_mode,
-                                                                 const int32_t *lengths_h, int B, int Tmax, int D,
-                                                                 int num_windows, const int32_t *win_l_h,
-                                                                 const int32_t *win_u_h, const double *win_coef_h,
-                                                                 void *out_h, int32_t *status_h) {
+__attribute__((visibility("default"))) long long mlpg_hip_host_chunk_plan(long long n_items, long long target_items,
+                                                                         int num_devices, long long max_chunks,
+                                                                         int32_t *entry, int32_t *slot, int64_t *first,
+                                                                         int64_t *count) {
+  if (n_items < 0 || target_items < 1 || num_devices < 1 || num_devices > kMaxList) {
+    set_error("host_chunk_plan: bad arguments");
+    return MLPG_HIP_EINVAL;
+  }
+  const long cb = host_chunk_items((long)n_items, (long)target_items, num_devices);
+  const long long nchunks = (n_items + cb - 1) / cb;
+  for (long long c = 0; c < nchunks && c < max_chunks; ++c) {
+    int e, s_;
+    host_chunk_owner((long)c, num_devices, &e, &s_);
+    if (entry) entry[c] = e;
+    if (slot) slot[c] = s_;
+    if (first) first[c] = c * cb;
+    if (count) count[c] = std::min<long long>(cb, n_items - c * cb);
+  }
+  return nchunks;
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_forward_host_multi(const int32_t *devices, int num_devices, int dtype,
+                                                                       int algo, const void *mean_h, const void *var_h,
+                                                                       int var_mode, const int32_t *lengths_h, int B,
+                                                                       int Tmax, int D, int num_windows,
+                                                                       const int32_t *win_l_h, const int32_t *win_u_h,
+                                                                       const double *win_coef_h, void *out_h,
+                                                                       int32_t *status_h) {
   if (B < 0 || Tmax < 0 || D < 0 || num_windows < 1 || D % num_windows != 0) {
     set_error("forward_host: bad sizes (B=%d, Tmax=%d, D=%d, num_windows=%d)", B, Tmax, D, num_windows);
     return MLPG_HIP_EINVAL;
@@ -169,62 +443,38 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_host(int device, int
     set_error("NULL data pointer");
     return MLPG_HIP_EINVAL;
   }
-  if (device < 0 || device >= 16) {
-    set_error("bad device %d", device);
-    return MLPG_HIP_EINVAL;
-  }
-  int prev = -1;
-  MLPG_HIP_CHECK(hipGetDevice(&prev));
-  if (prev != device) MLPG_HIP_CHECK(hipSetDevice(device));
-  struct Restore {
-    int prev, dev;
-    ~Restore() { if (prev != dev) (void)hipSetDevice(prev); }
-  } restore{prev, device};
+  std::lock_guard<std::mutex> lk(g_host_mu);  // one host call at a time per process (the staging buffers are shared)
+  DevList dl;
+  if (int rc = resolve_devices(devices, num_devices, &dl)) return rc;
+  const bool fvar = var_mode == MLPG_HIP_VAR_FRAME;
+  const bool mean_pinned = is_pinned(mean_h), var_pinned = fvar && is_pinned(var_h), out_pinned = is_pinned(out_h);
 
   const size_t esz = dtype == MLPG_HIP_F32 ? 4 : 8;
   const int sd = D / num_windows;
   const size_t utt_in = (size_t)Tmax * D * esz, utt_out = (size_t)Tmax * sd * esz;
-  const bool fvar = var_mode == MLPG_HIP_VAR_FRAME;
-  // ~64 MB of input per chunk, at least 4 chunks when the batch allows (so that transfers and kernels overlap)
+  // ~64 MB of input per chunk
   static const long chunk_mb = [] { const char *e = getenv("MLPG_HIP_HOST_CHUNK_MB"); const long v = e ? atol(e) : 0; return v > 0 ? v : 64; }();
-  long cb = (long)(((size_t)chunk_mb << 20) / (utt_in * (fvar ? 2 : 1)));
-  cb = std::max<long>(1, std::min<long>(cb, (B + 3) / 4));
+  const long cb = host_chunk_items(B, (long)(((size_t)chunk_mb << 20) / (utt_in * (fvar ? 2 : 1))), dl.n);
+  const long nchunks = (B + cb - 1) / cb;
   const size_t in_bytes = (size_t)cb * utt_in * (fvar ? 2 : 1);
   const size_t out_bytes = up256((size_t)cb * utt_out) + (size_t)cb * sd * sizeof(int32_t);
   const size_t o_mean = 0, o_var = up256((size_t)cb * utt_in), o_out = o_var + (fvar ? up256((size_t)cb * utt_in) : up256((size_t)D * esz)),
                o_status = o_out + up256((size_t)cb * utt_out), o_len = o_status + up256((size_t)cb * sd * sizeof(int32_t)),
                dev_bytes = o_len + up256((size_t)cb * sizeof(int32_t));
+  if (int rc = ensure_all(dl, in_bytes, out_bytes, dev_bytes)) return rc;
+  Prefault prefault;
+  if (!out_pinned) prefault.start(out_h, (size_t)B * utt_out);
 
-  std::lock_guard<std::mutex> lk(g_host_mu);  // one host call at a time per process (the staging buffers are shared)
-  HostCtx &c = g_host[device];
-  if (int rc = ensure(c, in_bytes, out_bytes, dev_bytes)) return rc;
-  const bool mean_pinned = is_pinned(mean_h), var_pinned = fvar && is_pinned(var_h), out_pinned = is_pinned(out_h);
-
-  struct Pending {
-    bool active = false;
-    long b0 = 0, nb = 0;
-  } pend[2];
-  auto finish = [&](int slot) -> int {  // wait for the slot's chunk, hand its staged results to the caller
-    if (!pend[slot].active) return 0;
-    MLPG_HIP_CHECK(hipEventSynchronize(c.done[slot]));
-    const long b0 = pend[slot].b0, nb = pend[slot].nb;
-    if (!out_pinned) parallel_copy((char *)out_h + (size_t)b0 * utt_out, c.pin_out[slot], (size_t)nb * utt_out);
-    if (status_h) memcpy(status_h + (size_t)b0 * sd, (char *)c.pin_out[slot] + up256((size_t)cb * utt_out), (size_t)nb * sd * sizeof(int32_t));
-    pend[slot].active = false;
-    return 0;
-  };
-
-  if (var_mode == MLPG_HIP_VAR_GLOBAL) {
-    for (int k = 0; k < 2; ++k)
-      MLPG_HIP_CHECK(hipMemcpyAsync((char *)c.dev[k] + o_var, var_h, (size_t)D * esz, hipMemcpyHostToDevice, c.st[k]));
-  }
-  int chunk = 0;
-  for (long b0 = 0; b0 < B; b0 += cb, ++chunk) {
-    const int slot = chunk & 1;
-    const long nb = std::min<long>(cb, B - b0);
-    if (int rc = finish(slot)) return rc;  // the slot's buffers are free again
+  bool var_sent[kMaxList][2] = {};
+  auto submit = [&](int e, int slot, long chunk) -> int {
+    HostCtx &c = *dl.ctx[e];
+    const long b0 = chunk * cb, nb = std::min<long>(cb, B - b0);
     hipStream_t st = c.st[slot];
     char *d = (char *)c.dev[slot];
+    if (var_mode == MLPG_HIP_VAR_GLOBAL && !var_sent[e][slot]) {
+      MLPG_HIP_CHECK(hipMemcpyAsync(d + o_var, var_h, (size_t)D * esz, hipMemcpyHostToDevice, st));
+      var_sent[e][slot] = true;
+    }
     const char *msrc = (const char *)mean_h + (size_t)b0 * utt_in;
     if (!mean_pinned) {
       parallel_copy(c.pin_in[slot], msrc, (size_t)nb * utt_in);
@@ -257,19 +507,36 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_host(int device, int
     p.ld_gout = 0;
     p.ld_out = sd;
     p.ld_status = sd;
-    if (int rc = dispatch_solve(st, dtype, dtype, algo, false, p, ws, device)) return rc;
+    if (int rc = dispatch_solve(st, dtype, dtype, algo, false, p, ws, dl.dev[e])) return rc;
     void *odst = out_pinned ? (void *)((char *)out_h + (size_t)b0 * utt_out) : c.pin_out[slot];
     MLPG_HIP_CHECK(hipMemcpyAsync(odst, d + o_out, (size_t)nb * utt_out, hipMemcpyDeviceToHost, st));
     MLPG_HIP_CHECK(hipMemcpyAsync((char *)c.pin_out[slot] + up256((size_t)cb * utt_out), d + o_status,
                                   (size_t)nb * sd * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    MLPG_HIP_CHECK(hipEventRecord(c.done[slot], st));
-    pend[slot].active = true;
-    pend[slot].b0 = b0;
-    pend[slot].nb = nb;
+    return 0;
+  };
+  auto collect = [&](int e, int slot, long chunk) -> int {  // the chunk's staged results go to the caller's arrays
+    HostCtx &c = *dl.ctx[e];
+    const long b0 = chunk * cb, nb = std::min<long>(cb, B - b0);
+    if (!out_pinned) parallel_copy((char *)out_h + (size_t)b0 * utt_out, c.pin_out[slot], (size_t)nb * utt_out);
+    if (status_h) memcpy(status_h + (size_t)b0 * sd, (char *)c.pin_out[slot] + up256((size_t)cb * utt_out), (size_t)nb * sd * sizeof(int32_t));
+    return 0;
+  };
+  return run_chunks(dl, nchunks, submit, collect);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_forward_host(int device, int dtype, int algo, const void *mean_h,
+                                                                 const void *var_h, int var_mode,
+                                                                 const int32_t *lengths_h, int B, int Tmax, int D,
+                                                                 int num_windows, const int32_t *win_l_h,
+                                                                 const int32_t *win_u_h, const double *win_coef_h,
+                                                                 void *out_h, int32_t *status_h) {
+  if (device < 0 || device >= kMaxHostDevices) {
+    set_error("bad device %d", device);
+    return MLPG_HIP_EINVAL;
   }
-  if (int rc = finish(chunk & 1)) return rc;
-  if (int rc = finish((chunk + 1) & 1)) return rc;
-  return 0;
+  const int32_t one = device;
+  return mlpg_hip_forward_host_multi(&one, 1, dtype, algo, mean_h, var_h, var_mode, lengths_h, B, Tmax, D, num_windows, win_l_h,
+                                     win_u_h, win_coef_h, out_h, status_h);
 }
 
 // fastdtw for N utterance pairs held in HOST memory: what DTWAligner.transform (preprocessing/alignment.py:41-76) does
@@ -278,13 +545,14 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_host(int device, int
 // transfers of one chunk under the kernels of the other.  X_h (N, Tx, D), Y_h (N, Ty, D) float32 or float64 (float32
 // is widened on the device: the distances are computed in float64 either way).  Outputs as mlpg_hip_fastdtw;
 // lenx_out_h / leny_out_h (may be NULL) receive the lengths that were used.
-__attribute__((visibility("default"))) int mlpg_hip_fastdtw_host(int device, int dtype, const void *X_h, const void *Y_h,
-                                                                 const int32_t *lenx_h, const int32_t *leny_h, int N,
-                                                                 int Tx, int Ty, int D, int radius, int dist_kind,
-                                                                 double dist_scale, int tie_rule, double trim_eps,
-                                                                 int32_t *path_i_h, int32_t *path_j_h,
-                                                                 int32_t *path_len_h, double *cost_h,
-                                                                 int32_t *lenx_out_h, int32_t *leny_out_h) {
+__attribute__((visibility("default"))) int mlpg_hip_fastdtw_host_multi(const int32_t *devices, int num_devices, int dtype,
+                                                                       const void *X_h, const void *Y_h,
+                                                                       const int32_t *lenx_h, const int32_t *leny_h, int N,
+                                                                       int Tx, int Ty, int D, int radius, int dist_kind,
+                                                                       double dist_scale, int tie_rule, double trim_eps,
+                                                                       int32_t *path_i_h, int32_t *path_j_h,
+                                                                       int32_t *path_len_h, double *cost_h,
+                                                                       int32_t *lenx_out_h, int32_t *leny_out_h) {
   if (N < 0 || Tx < 1 || Ty < 1 || D < 1 || radius < 1) {
     set_error("fastdtw_host: need N >= 0, Tx, Ty, D >= 1 and radius >= 1");
     return MLPG_HIP_EINVAL;
@@ -302,22 +570,14 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw_host(int device, int
     set_error("fastdtw_host: NULL pointer");
     return MLPG_HIP_EINVAL;
   }
-  if (device < 0 || device >= 16) {
-    set_error("bad device %d", device);
-    return MLPG_HIP_EINVAL;
-  }
-  int prev = -1;
-  MLPG_HIP_CHECK(hipGetDevice(&prev));
-  if (prev != device) MLPG_HIP_CHECK(hipSetDevice(device));
-  struct Restore {
-    int prev, dev;
-    ~Restore() { if (prev != dev) (void)hipSetDevice(prev); }
-  } restore{prev, device};
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  DevList dl;
+  if (int rc = resolve_devices(devices, num_devices, &dl)) return rc;
 
   const size_t esz = dtype == MLPG_HIP_F32 ? 4 : 8;
   const size_t px = (size_t)Tx * D, py = (size_t)Ty * D, pl = (size_t)Tx + Ty;  // elements per pair: X, Y, path slots
-  long cb = (long)((64u << 20) / ((px + py) * esz));
-  cb = std::max<long>(1, std::min<long>(cb, (N + 3) / 4));
+  const long cb = host_chunk_items(N, (long)((64u << 20) / ((px + py) * esz)), dl.n);
+  const long nchunks = (N + cb - 1) / cb;
   // pinned staging: in = X | Y;  out = path_i | path_j | path_len | lenx | leny | cost
   const size_t in_bytes = up256((size_t)cb * px * esz) + (size_t)cb * py * esz;
   const size_t so_pj = up256((size_t)cb * pl * 4), so_pl = 2 * so_pj, so_lx = so_pl + up256((size_t)cb * 4),
@@ -329,36 +589,12 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw_host(int device, int
                o_lx = o_y64 + (dtype == MLPG_HIP_F32 ? up256((size_t)cb * py * 8) : 0), o_ly = o_lx + up256((size_t)cb * 4),
                o_pi = o_ly + up256((size_t)cb * 4), o_pj = o_pi + so_pj, o_pl = o_pj + so_pj,
                o_c = o_pl + up256((size_t)cb * 4), dev_bytes = o_c + up256((size_t)cb * 8);
-
-  std::lock_guard<std::mutex> lk(g_host_mu);
-  HostCtx &c = g_host[device];
-  if (int rc = ensure(c, in_bytes, out_bytes, dev_bytes)) return rc;
+  if (int rc = ensure_all(dl, in_bytes, out_bytes, dev_bytes)) return rc;
   const bool x_pinned = is_pinned(X_h), y_pinned = is_pinned(Y_h);
 
-  struct Pending {
-    bool active = false;
-    long b0 = 0, nb = 0;
-  } pend[2];
-  auto finish = [&](int slot) -> int {
-    if (!pend[slot].active) return 0;
-    MLPG_HIP_CHECK(hipEventSynchronize(c.done[slot]));
-    const long b0 = pend[slot].b0, nb = pend[slot].nb;
-    const char *o = (const char *)c.pin_out[slot];
-    memcpy(path_i_h + (size_t)b0 * pl, o, (size_t)nb * pl * 4);
-    memcpy(path_j_h + (size_t)b0 * pl, o + so_pj, (size_t)nb * pl * 4);
-    memcpy(path_len_h + b0, o + so_pl, (size_t)nb * 4);
-    if (lenx_out_h) memcpy(lenx_out_h + b0, o + so_lx, (size_t)nb * 4);
-    if (leny_out_h) memcpy(leny_out_h + b0, o + so_ly, (size_t)nb * 4);
-    memcpy(cost_h + b0, o + so_c, (size_t)nb * 8);
-    pend[slot].active = false;
-    return 0;
-  };
-
-  int chunk = 0;
-  for (long b0 = 0; b0 < N; b0 += cb, ++chunk) {
-    const int slot = chunk & 1;
-    const long nb = std::min<long>(cb, N - b0);
-    if (int rc = finish(slot)) return rc;
+  auto submit = [&](int e, int slot, long chunk) -> int {
+    HostCtx &c = *dl.ctx[e];
+    const long b0 = chunk * cb, nb = std::min<long>(cb, N - b0);
     hipStream_t st = c.st[slot];
     char *d = (char *)c.dev[slot];
     const char *xs = (const char *)X_h + (size_t)b0 * px * esz, *ys = (const char *)Y_h + (size_t)b0 * py * esz;
@@ -389,7 +625,7 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw_host(int device, int
       x64 = (const double *)(d + o_x64);
       y64 = (const double *)(d + o_y64);
     }
-    if (int rc = launch_fastdtw(st, device, x64, y64, lx, ly, (int)nb, Tx, Ty, D, radius, dist_kind, dist_scale, tie_rule,
+    if (int rc = launch_fastdtw(st, dl.dev[e], x64, y64, lx, ly, (int)nb, Tx, Ty, D, radius, dist_kind, dist_scale, tie_rule,
                                 (int32_t *)(d + o_pi), (int32_t *)(d + o_pj), (int32_t *)(d + o_pl), (double *)(d + o_c)))
       return rc;
     char *o = (char *)c.pin_out[slot];
@@ -399,14 +635,36 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw_host(int device, int
     MLPG_HIP_CHECK(hipMemcpyAsync(o + so_lx, lx, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
     MLPG_HIP_CHECK(hipMemcpyAsync(o + so_ly, ly, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
     MLPG_HIP_CHECK(hipMemcpyAsync(o + so_c, d + o_c, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
-    MLPG_HIP_CHECK(hipEventRecord(c.done[slot], st));
-    pend[slot].active = true;
-    pend[slot].b0 = b0;
-    pend[slot].nb = nb;
+    return 0;
+  };
+  auto collect = [&](int e, int slot, long chunk) -> int {
+    const long b0 = chunk * cb, nb = std::min<long>(cb, N - b0);
+    const char *o = (const char *)dl.ctx[e]->pin_out[slot];
+    memcpy(path_i_h + (size_t)b0 * pl, o, (size_t)nb * pl * 4);
+    memcpy(path_j_h + (size_t)b0 * pl, o + so_pj, (size_t)nb * pl * 4);
+    memcpy(path_len_h + b0, o + so_pl, (size_t)nb * 4);
+    if (lenx_out_h) memcpy(lenx_out_h + b0, o + so_lx, (size_t)nb * 4);
+    if (leny_out_h) memcpy(leny_out_h + b0, o + so_ly, (size_t)nb * 4);
+    memcpy(cost_h + b0, o + so_c, (size_t)nb * 8);
+    return 0;
+  };
+  return run_chunks(dl, nchunks, submit, collect);
+}
+
+__attribute__((visibility("default"))) int mlpg_hip_fastdtw_host(int device, int dtype, const void *X_h, const void *Y_h,
+                                                                 const int32_t *lenx_h, const int32_t *leny_h, int N,
+                                                                 int Tx, int Ty, int D, int radius, int dist_kind,
+                                                                 double dist_scale, int tie_rule, double trim_eps,
+                                                                 int32_t *path_i_h, int32_t *path_j_h,
+                                                                 int32_t *path_len_h, double *cost_h,
+                                                                 int32_t *lenx_out_h, int32_t *leny_out_h) {
+  if (device < 0 || device >= kMaxHostDevices) {
+    set_error("bad device %d", device);
+    return MLPG_HIP_EINVAL;
   }
-  if (int rc = finish(chunk & 1)) return rc;
-  if (int rc = finish((chunk + 1) & 1)) return rc;
-  return 0;
+  const int32_t one = device;
+  return mlpg_hip_fastdtw_host_multi(&one, 1, dtype, X_h, Y_h, lenx_h, leny_h, N, Tx, Ty, D, radius, dist_kind, dist_scale,
+                                     tie_rule, trim_eps, path_i_h, path_j_h, path_len_h, cost_h, lenx_out_h, leny_out_h);
 }
 
 }  // extern "C"

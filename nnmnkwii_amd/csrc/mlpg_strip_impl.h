@@ -168,10 +168,29 @@ struct Args {
   double one;                 // 1.0, from the host: the unit-variance precision as a run-time value (see assemble_eliminate)
   double wc[kMaxWindows][9];  // per window: W[t,t-1], W[t,t], W[t,t+1] and their six products (host-computed, so
                               // that the kernel holds them in scalar registers)
-  int nlists;    // work lists: 8 (system group g belongs to list g % 8, drawn first by the workgroups that run on
-                 // XCD g % 8, so that an utterance's strips share one L2) or 1 (small launches)
+  int nlists;    // work lists: 8 (drawn first by the workgroups that run on XCD list % 8, so that neighbouring strips share
+                 // one L2) or 1 (small launches)
+  int nb, bs;    // an utterance's R strips are dealt to the lists in nb blocks of bs consecutive strips (nb * bs >= R;
+                 // block j of system group g is "virtual group" g * nb + j, virtual group v belongs to list v % nlists):
+                 // nb = 1, bs = R while an utterance fits into a list's share of the grid, more blocks for long ones
   StreamMap sm;  // MULTI kernels only: the streams whose static dims sit side by side on the lanes
 };
+
+// Ticket tk of work list lst -> (system group, strip).  The lists hold whole blocks of consecutive strips in the order of
+// the virtual groups, i.e. every list runs through the utterances in the same order (see launch(): what the route-0 wait
+// relies on).  MULTI: the lists are dealt by UTTERANCE (all its dim groups in one list, a full group and the narrow last
+// one alternating; nb == 1 there).
+template <bool MULTI = false>
+__device__ __forceinline__ void ticket_item(const Args &a, int tk, int lst, int &g, int &r) {
+  if (MULTI) {
+    g = (((tk / a.R) / a.ndg) * a.nlists + lst) * a.ndg + (tk / a.R) % a.ndg;
+    r = tk % a.R;
+  } else {
+    const int v = (tk / a.bs) * a.nlists + lst;
+    g = v / a.nb;
+    r = (v - g * a.nb) * a.bs + tk % a.bs;
+  }
+}
 
 // MULTI kernels: the stream a merged static-dim index belongs to (at most 4 streams, begin[] ascending, unused
 // entries = INT_MAX) and the dim's columns there
@@ -1525,12 +1544,13 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
     // travel from HBM while this item back-substitutes and stores
     // (issued AFTER this item's last LDS reads: the compiler orders every LDS access behind outstanding LDS-DMA loads)
     if (ntk < cur_lim) {
-      const int g2 = (ntk / R) * a.nlists + cur_lst, r2 = ntk % R;
+      int g2, r2;
+      ticket_item<MULTI>(a, ntk, cur_lst, g2, r2);
       const int b2 = g2 / a.ndg, dg2 = g2 - b2 * a.ndg;
       int T2 = p.lengths ? p.lengths[b2] : Tmax;
       T2 = T2 < 0 ? 0 : (T2 > Tmax ? Tmax : T2);
       const int fn = (r2 * kW + wv) * kM;
-      if (fn < T2) {
+      if (r2 < R && fn < T2) {
         const int dn0 = dg2 * a.dgw;
         const int nd2 = sd - dn0 < a.dgw ? sd - dn0 : a.dgw;
         const unsigned loff2 = (unsigned)(lane < nd2 ? lane : nd2 - 1) * (unsigned)sizeof(TIN);
@@ -1746,7 +1766,7 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
     // the narrow last one alternating) -- by system group, the full groups of 66 = 64 + 2 dims would all land in
     // the even lists and the XCDs behind the odd ones would idle
     const int lim = MULTI ? ((a.nsg / a.ndg - lst + a.nlists - 1) / a.nlists) * a.ndg * R
-                          : ((a.nsg - lst + a.nlists - 1) / a.nlists) * R;
+                          : ((a.nsg * a.nb - lst + a.nlists - 1) / a.nlists) * a.bs;
     int *ticket = a.ctrl + (1 + lst) * kCtrlLine;
     cur_lst = lst;
     cur_lim = lim;
@@ -1770,8 +1790,9 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
       t_prev = (long long)__builtin_readcyclecounter();
       for (int q = 0; q < 16; ++q) tq[q] = 0;
 #endif
-      if (MULTI) body((((tk / R) / a.ndg) * a.nlists + lst) * a.ndg + (tk / R) % a.ndg, tk % R);
-      else body((tk / R) * a.nlists + lst, tk % R);
+      int g_it, r_it;
+      ticket_item<MULTI>(a, tk, lst, g_it, r_it);
+      if (r_it < R) body(g_it, r_it);  // (the last block of a long utterance may be short: tickets past its end are nobody's)
       __syncthreads();
     }
     __syncthreads();
@@ -1898,11 +1919,23 @@ int launch_impl(hipStream_t st, const Problem &p, const WinSet &ws, void *scratc
     // device), each draws items until the lists are empty
     int resident = 0;
     if (int rc = resident_grid((const void *)kern, kW * 64, kLdsBytes, &resident)) return rc;
-    // Co-residency the protocol relies on: a strip may wait for every strip of its utterance (route 0), and those
-    // are only ever held by workgroups that draw from the same list.  One list per XCD (system group g in list g % 8,
-    // locality) only while an utterance's strips fit twice into an XCD's share of the grid; otherwise one list, and
-    // then the whole grid must be able to hold an utterance twice over -- if not, the caller takes another kernel.
-    a.nlists = (nitems >= 512 && R <= resident / (2 * kMaxLists)) ? kMaxLists : 1;
+    // Co-residency the protocol relies on: a strip may wait for every strip of its utterance (route 0).  One list per
+    // XCD (locality: neighbouring strips exchange their records through one L2), and of one utterance a list holds at
+    // most cap = half an XCD's share of the grid in consecutive tickets; small launches: one list, and then the whole
+    // grid must be able to hold an utterance twice over -- if not, the caller takes another kernel.
+    // Longer utterances are dealt to the lists in blocks of consecutive strips that do fit: every list runs through
+    // the utterances in the same order, so the oldest unfinished utterance has, in every list, all its strips drawn
+    // (a list's first unfinished ticket is one of its strips and the >= 2 * cap workgroups of that XCD hold distinct
+    // tickets from there on) -- it completes, then the next one.  Only the block ends talk across XCDs.
+    const int cap = resident / (2 * kMaxLists);
+    a.nb = 1;
+    a.bs = R;
+    a.nlists = 1;
+    if (nitems >= 512 && cap >= 1 && (R <= cap || !MULTI)) {
+      a.nlists = kMaxLists;
+      a.nb = (R + cap - 1) / cap;
+      a.bs = (R + a.nb - 1) / a.nb;
+    }
     if (nitems > resident && R > resident / 2) return kNotResident;
     if (zero_ctrl) MLPG_HIP_CHECK(hipMemsetAsync(a.ctrl, 0, ctrl_ints(nsg, R) * sizeof(int), st));
     const long grid = nitems < resident ? nitems : resident;

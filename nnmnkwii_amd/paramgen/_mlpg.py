@@ -107,7 +107,9 @@ def mlpg_batch(means, variances, windows, lengths=None, algo=_hip.ALGO_AUTO, che
     ``variances`` may be ``(B, Tmax, D)``, a global ``(D,)`` or ``None`` (unit
     variances).  ``lengths`` (B,) gives the valid frames per utterance; output
     frames beyond it are zero.  Returns the same kind of object as ``means``,
-    shape ``(B, Tmax, D // len(windows))``.
+    shape ``(B, Tmax, D // len(windows))``.  numpy input: ``device`` may also be
+    a list of GPU indices or ``"all"`` -- the utterance chunks are then dealt
+    round-robin over those devices from this one process (mlpg_hip_forward_host_multi).
     """
     if isinstance(means, np.ndarray) or not hasattr(means, "is_cuda"):
         return _mlpg_batch_host(means, variances, windows, lengths, algo, check, device)
@@ -152,8 +154,8 @@ def _mlpg_batch_host(means, variances, windows, lengths, algo, check, device):
                 v = 1.0 / (np.float32(1.0) / v).astype(np.float64)
             else:
                 m = m.astype(np.float64)
-    dev_index = _hip.current_device_index(device)          # default: the process's current GPU, not GPU 0
-    out, status = _hip.forward_host(m, v, windows, lengths, algo=algo, device=dev_index)
+    # default: the process's current GPU, not GPU 0; a list of indices or "all": the chunks dealt over those devices
+    out, status = _hip.forward_host(m, v, windows, lengths, algo=algo, device=device)
     if check:
         st = status.ravel()
         bad = np.flatnonzero(st)

@@ -80,6 +80,9 @@ class DTWAligner(object):
     up, left, diagonal; the rule all parity tests are pinned on) or
     ``"diag_last"`` (the strict-less chain recalled for upstream's compiled
     extension; UNVERIFIED, see include/mlpg_hip.h).  Continuous data never tie.
+    ``devices`` (extension, keyword only): a list of GPU indices or ``"all"``
+    -- the pairs are dealt in chunks over those devices from this one process
+    (mlpg_hip_fastdtw_host_multi); default: the process's current GPU.
 
     Attributes:
         dist (function): Distance function (default L2).
@@ -87,12 +90,13 @@ class DTWAligner(object):
         verbose (int): Verbose flag.
     """
 
-    def __init__(self, dist=_default_dist, radius=1, verbose=0, *, tie_rule="first"):
+    def __init__(self, dist=_default_dist, radius=1, verbose=0, *, tie_rule="first", devices=None):
         self.verbose = verbose
         self.dist = dist
         self.radius = radius
         assert tie_rule in ("first", "diag_last")
         self.tie_rule = tie_rule
+        self.devices = devices     # None: the current GPU; a list of GPU indices or "all": pairs dealt over them
 
     # Batches below this many input bytes go through device tensors (upload once, trim + fastdtw + gather on the GPU,
     # download the aligned arrays: 4-6 ms for 128 config-4 pairs); larger ones through the host-pointer entry point
@@ -108,8 +112,10 @@ class DTWAligner(object):
         if resolved is None:
             return self._paths_callable(X, Y, tie, dev)
         dist_kind, dist_scale = resolved
-        if X.nbytes + Y.nbytes >= self._HOST_ENTRY_BYTES:
-            out = _hip.fastdtw_host(X, Y, self.radius, dist_kind, dist_scale, device=dev.index, tie_rule=tie)   # alignment.py:46-50
+        devices = getattr(self, "devices", None)
+        if devices is not None or X.nbytes + Y.nbytes >= self._HOST_ENTRY_BYTES:
+            out = _hip.fastdtw_host(X, Y, self.radius, dist_kind, dist_scale, tie_rule=tie,
+                                    device=dev.index if devices is None else devices)   # alignment.py:46-50
             return out + ((lambda is_x, path, plen, T_out, dtype: _gather(X if is_x else Y, path, plen, T_out, dtype)),)
         torch = _hip.torch_mod()
         Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)

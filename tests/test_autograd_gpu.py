@@ -218,3 +218,49 @@ def test_fused_step_gradient_against_the_dense_float64_definition(shape):
     assert abs(float(loss) - ref_loss) <= 1e-11 * ref_loss
     g = means.grad.cpu().numpy()
     assert np.abs(g - gmu).max() <= 1e-10 * np.abs(gmu).max()
+
+
+def test_fused_mse_loss_falls_back_where_the_fused_kernel_does_not_apply():
+    """unit_variance_mlpg_mse_loss == mse_loss(unit_variance_mlpg(...), target) also for T > 1024, for window extents
+    > 1, when the target wants a gradient and for CPU tensors (loss on means.device) -- against the dense float64
+    definition from the oracle's window matrices."""
+    import torch
+    from nnmnkwii_amd import autograd as AF
+    from oracle import mlpg as O
+
+    def dense(windows, m, t):
+        """paramgen/_mlpg.py:297-373 without the float32 cast: R = P^-1 [mask W_w]^T, y = R mu."""
+        T = m.shape[-2]
+        nw = len(windows)
+        sd = m.shape[-1] // nw
+        mw = int(max(max(l, u) for l, u, _ in windows))
+        mask = O._edge_mask(T, mw)
+        Ws = [O.window_matrix(l, u, np.asarray(c, dtype=np.float64), T) for (l, u, c) in windows]
+        Wt = [W if w == 0 else mask[:, None] * W for w, W in enumerate(Ws)]
+        P = sum(Wt[w].T @ Ws[w] for w in range(nw))
+        R = np.linalg.solve(P, np.concatenate([Wt[w].T for w in range(nw)], axis=1))       # (T, nw*T)
+        mm = m.reshape(-1, T, nw, sd).transpose(0, 2, 1, 3).reshape(-1, nw * T, sd)
+        y = np.einsum("tk,bkd->btd", R, mm)
+        r = y - t.reshape(-1, T, sd)
+        loss = (r ** 2).mean()
+        g = np.einsum("tk,btd->bkd", R, 2.0 * r / r.size).reshape(-1, nw, T, sd).transpose(0, 2, 1, 3).reshape(m.shape)
+        return loss, g, (-2.0 * r / r.size).reshape(t.shape)
+
+    cases = [("std3", (2, 1100, 3), False, "cuda"),      # T > 1024
+             ("wide3", (2, 90, 4), False, "cuda"),        # extents 2
+             ("std3", (3, 50, 5), True, "cuda"),          # target.requires_grad
+             ("std3", (40, 6), False, "cpu")]             # CPU tensors, 2-D
+    for wname, shape, tgrad, dev in cases:
+        windows = WINDOW_SETS[wname]
+        nw = len(windows)
+        torch.manual_seed(len(shape) + shape[-2])
+        means = torch.rand(*shape[:-1], nw * shape[-1], dtype=torch.float64, device=dev, requires_grad=True)
+        target = torch.rand(*shape, dtype=torch.float64, device=dev, requires_grad=tgrad)
+        loss = AF.unit_variance_mlpg_mse_loss(windows, means, target)
+        assert loss.device == means.device
+        loss.backward()
+        lo, go, gt = dense(windows, means.detach().cpu().numpy(), target.detach().cpu().numpy())
+        assert abs(float(loss) - lo) <= 1e-9 * lo, wname
+        assert np.abs(means.grad.cpu().numpy() - go).max() <= 1e-9 * np.abs(go).max(), wname
+        if tgrad:
+            assert np.abs(target.grad.cpu().numpy() - gt).max() <= 1e-12 * np.abs(gt).max()

@@ -189,3 +189,28 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, env=env)
     assert out.returncode == 0, out.stdout
     assert out.stdout.split() == ["11", "5", "3"], out.stdout
+
+
+def test_host_chunk_plan_deals_round_robin_and_covers_the_batch():
+    """mlpg_hip_host_chunk_plan: the dealing logic of the host-memory entry points over a device list (pure host code).
+    Chunks tile the batch in order without gaps; chunk c runs on list entry c % n, stream slot (c // n) % 2; at least
+    four chunks per device when the batch allows; never an empty chunk."""
+    from nnmnkwii_amd import _hip
+    for n_items, target, ndev in [(256, 10, 1), (256, 10, 8), (37, 10, 1), (37, 1000, 3), (1, 5, 8), (1024, 90, 8), (5, 2, 4),
+                                  (0, 4, 2)]:
+        entry, slot, first, count = _hip.host_chunk_plan(n_items, target, ndev)
+        assert count.sum() == n_items and (count > 0).all()
+        assert (first == np.concatenate([[0], np.cumsum(count)[:-1]])).all()
+        c = np.arange(len(entry))
+        assert (entry == c % ndev).all() and (slot == (c // ndev) % 2).all()
+        if len(count):
+            assert count.max() <= target
+            assert count[0] == max(1, min(target, -(-n_items // (4 * ndev))))      # about four chunks per device
+            assert (count[:-1] == count[0]).all()
+    # one device: exactly the two-slot alternation of the single-device call
+    entry, slot, first, count = _hip.host_chunk_plan(37, 10, 1)
+    assert entry.tolist() == [0, 0, 0, 0] and slot.tolist() == [0, 1, 0, 1] and count.tolist() == [10, 10, 10, 7]
+    with pytest.raises(_hip.HipExtensionError):
+        _hip.host_chunk_plan(10, 0, 1)
+    assert _hip.device_list("all").size == 0 and _hip.device_list([1, 1, 0]).tolist() == [1, 1, 0]
+    assert _hip.device_list(3).tolist() == [3] and _hip.device_list("cuda:2").tolist() == [2]

@@ -1,0 +1,88 @@
+"""GPU tests (-m gpu) of the host-memory entry points over a device LIST (mlpg_hip_forward_host_multi,
+mlpg_hip_fastdtw_host_multi): one process deals the utterance / pair chunks round-robin over the listed devices.  A
+one-GPU box lists its device several times -- each occurrence has its own streams and staging buffers, so the dealing,
+the slot reuse and the positional merge of outputs and verdicts run exactly as they do over distinct GPUs."""
+import numpy as np
+import pytest
+
+from cases import WINDOW_SETS
+from oracle import dtw as OD
+from oracle import mlpg as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0], "all"])
+def test_forward_host_over_a_device_list_against_the_oracle(devices):
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd import paramgen as G
+    windows = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(31)
+    B, T, sd = 53, 200, 40           # 53 utterances: 4 n chunks, the last one short
+    M_ = rng.randn(B, T, 3 * sd)
+    V_ = rng.rand(B, T, 3 * sd) + 0.1
+    lengths = rng.randint(1, T + 1, size=B).astype(np.int32)
+    y1, st1 = _hip.forward_host(M_, V_, windows, lengths)                 # the single-device call
+    y, st = _hip.forward_host(M_, V_, windows, lengths, device=devices)
+    assert np.array_equal(y, y1) and np.array_equal(st, st1) and not st.any()
+    yo, _, rc = O.mlpg_batch(M_, V_, windows, lengths)
+    assert rc == 0
+    sc = np.abs(yo).max(axis=1, keepdims=True) + 1e-300
+    assert (np.abs(y - yo) / sc).max() <= 1e-9
+    # global variances (sent once per stream slot), unit variances, float32, through the drop-in batch call
+    vg = V_[0, 0].copy()
+    yg = G.mlpg_batch(M_, vg, windows, lengths, device=devices)
+    ygo, _, _ = O.mlpg_batch(M_, vg, windows, lengths)
+    assert (np.abs(yg - ygo) / (np.abs(ygo).max(axis=1, keepdims=True) + 1e-300)).max() <= 1e-9
+    yu = G.mlpg_batch(M_.astype(np.float32), None, windows, lengths, device=devices)
+    yuo, _, _ = O.mlpg_batch(M_.astype(np.float32), np.ones(3 * sd, dtype=np.float32), windows, lengths)
+    assert (np.abs(yu - yuo) / (np.abs(yuo).max(axis=1, keepdims=True) + 1e-300)).max() <= 5e-6
+    # verdicts merge by position: a bad system in a chunk that another list entry ran
+    Vb = V_.copy()
+    Vb[41, 0, 7] = -1e-3
+    _, stb = _hip.forward_host(M_, Vb, windows, None, device=devices)
+    _, sto, _ = O.mlpg_batch(M_[41:42], Vb[41:42], windows)
+    bad = np.argwhere(stb != 0)
+    assert bad.tolist() == [[41, 7]] and stb[41, 7] == sto[0, 7]
+
+
+def test_fastdtw_host_over_a_device_list_against_the_oracle():
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    rng = np.random.RandomState(32)
+    N, Tx, Ty, D = 21, 90, 110, 5
+    X = np.zeros((N, Tx, D))
+    Y = np.zeros((N, Ty, D))
+    lx = rng.randint(20, Tx + 1, N)
+    ly = rng.randint(20, Ty + 1, N)
+    for n in range(N):
+        X[n, :lx[n]] = np.cumsum(rng.randn(lx[n], D), 0) * 0.1 + 2.0
+        Y[n, :ly[n]] = np.cumsum(rng.randn(ly[n], D), 0) * 0.1 + 2.0
+    one = _hip.fastdtw_host(X, Y, 1)
+    for devices in ([0, 0], [0, 0, 0, 0], "all"):
+        many = _hip.fastdtw_host(X, Y, 1, device=devices)
+        for a, b in zip(one[2:], many[2:]):                     # path_len, cost, lenx, leny
+            assert np.array_equal(a, b)
+        for n in range(N):                                      # (path slots past path_len are unspecified)
+            k = one[2][n]
+            assert np.array_equal(one[0][n, :k], many[0][n, :k]) and np.array_equal(one[1][n, :k], many[1][n, :k])
+    pi, pj, pl, cost, hx, hy = one
+    assert hx.tolist() == lx.tolist() and hy.tolist() == ly.tolist()
+    for n in range(N):
+        d, path = OD.fastdtw(X[n, :lx[n]], Y[n, :ly[n]], 1)
+        assert pl[n] == len(path) and np.array_equal(pi[n, :pl[n]], path[:, 0]) and np.array_equal(pj[n, :pl[n]], path[:, 1])
+    Xa, Ya = DTWAligner().transform((X, Y))
+    Xb, Yb = DTWAligner(devices=[0, 0]).transform((X, Y))
+    assert np.array_equal(Xa, Xb) and np.array_equal(Ya, Yb)
+
+
+def test_device_list_errors():
+    from nnmnkwii_amd import _hip
+    windows = WINDOW_SETS["std3"]
+    M_ = np.zeros((4, 10, 6))
+    with pytest.raises(_hip.HipExtensionError):
+        _hip.forward_host(M_, None, windows, device=[0, 99])
+    with pytest.raises(_hip.HipExtensionError):
+        _hip.forward_host(M_, None, windows, device=[0] * 5)        # at most 4 occurrences of one device
+    y, st = _hip.forward_host(M_, None, windows, device=[0])         # and the library is usable afterwards
+    assert not y.any() and not st.any()

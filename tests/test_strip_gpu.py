@@ -363,9 +363,10 @@ def test_strip_kernel_inside_a_hip_graph():
 def test_strip_whole_utterance_route_many_groups_long_utterances():
     """Round-2 advisor scenario: >= 8 system groups, T = 8000 (125 strips > the 64 workgroups of one XCD) and
     variances whose dynamic features are 1e3 / 1e4 x tighter than the static ones, so that every strip takes the
-    whole-utterance route.  With one ticket list per XCD each XCD's workgroups would hold the first strips of their
-    own utterance and starve; the launcher must pick a single list there.  No time-out, same numbers as the
-    natural-order kernel."""
+    whole-utterance route.  With a whole utterance per XCD list each XCD's workgroups would hold the first strips of
+    their own utterance and starve; the launcher deals such an utterance to the lists in blocks of at most 32
+    consecutive strips (every list running through the utterances in the same order), so the oldest unfinished
+    utterance always has all its strips drawn.  No time-out, same numbers as the natural-order kernel."""
     import torch
     from nnmnkwii_amd import _hip
     STD3 = WINDOW_SETS["std3"]
@@ -381,6 +382,34 @@ def test_strip_whole_utterance_route_many_groups_long_utterances():
     scale = gen.abs().amax(dim=1, keepdim=True)
     assert float(((out - gen).abs() / scale).max()) <= 1e-7
     out2, _ = _hip.forward(m, v, STD3, algo=_hip.ALGO_STRIP)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("tight", [False, True])
+def test_strip_long_ragged_utterances_dealt_in_blocks(tight):
+    """T = 4000: 63 strips = two blocks of 32 per utterance (the second one a strip short: a ticket that is nobody's),
+    ragged lengths down to one frame, 20 utterances in two dim groups; ordinary variances (narrow level-3 windows that
+    cross the block ends) and tight dynamic ones (whole-utterance route across the lists)."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    g = torch.Generator(device="cuda").manual_seed(15)
+    B, T, sd = 20, 4000, 70
+    m = torch.randn(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=g)
+    v = torch.rand(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=g) + 0.1
+    if tight:
+        v[:, :, sd:2 * sd] *= 1e-3
+        v[:, :, 2 * sd:] *= 1e-4
+    lengths = torch.tensor([4000, 3999, 2049, 2048, 2047, 1, 65, 3000] + [4000 - 97 * k for k in range(12)],
+                           dtype=torch.int32, device="cuda")
+    out, status = _hip.forward(m, v, STD3, lengths, algo=_hip.ALGO_STRIP)
+    assert int(status.abs().max().item()) == 0
+    gen, _ = _hip.forward(m, v, STD3, lengths, algo=_hip.ALGO_GENERIC)
+    scale = gen.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+    assert float(((out - gen).abs() / scale).max()) <= 1e-7
+    for b_ in range(B):
+        assert not bool(out[b_, int(lengths[b_]):].any())
+    out2, _ = _hip.forward(m, v, STD3, lengths, algo=_hip.ALGO_STRIP)
     assert torch.equal(out, out2)
 
 

@@ -1,4 +1,5 @@
-"""fastdtw kernel time against the number of config-4 pairs (MLPG_HIP_DTW_FORCE=1: 256 threads + retry launch, 2: 512 threads)."""
+"""(Needs a library built with MLPG_HIP_EXTRA_FLAGS=-DMLPG_DTW_MEASURE: the switches below are not in the shipping build.)
+fastdtw kernel time against the number of config-4 pairs (MLPG_HIP_DTW_FORCE=1: 256 threads + retry launch, 2: 512 threads)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))

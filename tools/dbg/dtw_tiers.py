@@ -1,4 +1,5 @@
-"""1024 config-4 pairs: time of the two-launch form, and how many pairs the optimistic first launch gives up on
+"""(Needs a library built with MLPG_HIP_EXTRA_FLAGS=-DMLPG_DTW_MEASURE: the switches below are not in the shipping build.)
+1024 config-4 pairs: time of the two-launch form, and how many pairs the optimistic first launch gives up on
 (run with MLPG_HIP_DTW_FIRST_LAUNCH_ONLY=1 for the latter: path_len == -1 stays visible)."""
 import os, sys
 import numpy as np, torch
