@@ -502,11 +502,25 @@ struct Lds {
   double carry[2][3][64];  // by super-step parity: the forward state entering it (2), the row-below sum of the one before (1)
   double park[SLOTS][M][64];  // chunks that wait for the next super-step (the SLOTS lowest of a super-step)
   int bad[2];                 // lanes (systems) of the sequence that met a failing pivot
+  int sink[W][64];            // where the touch loads land (touch_lines); never read
 };
 #ifndef MLPG_CONST_RING
 #define MLPG_CONST_RING 6
 #endif
 constexpr int kRing = MLPG_CONST_RING;  // frames of loads in flight per wavefront
+
+#ifndef MLPG_CONST_TOUCH
+#define MLPG_CONST_TOUCH 0  // (measured: 0.146 -> 0.157 ms on config 2 with global variances -- the loads are not what the kernel waits for) request the rest of the next chunk's cache lines while the current super-step is worked on
+#endif
+// One dword per lane, fetched straight into LDS (no destination register, nothing ever waits for it): the lines it
+// names travel from HBM to the L2 while the wavefront computes, so that the ring's real loads -- 6 frames deep, all
+// the registers allow -- find them there.  Written as assembly on purpose: the compiler orders every LDS access
+// behind an LDS-DMA load it knows about (a full memory round trip in front of the next ds_read); one it does not
+// know about only makes the s_waitcnt vmcnt(n) it places for its own loads wait for a few more (older or as old)
+// operations, never for fewer.
+__device__ __forceinline__ void touch_lines(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dword %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(lds_addr) : "memory");
+}
 
 template <typename TIN, typename TOUT, bool BWD, int VM, int NW, int M, int W, int WPS, int SLOTS>
 __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet ws, Args a) {
@@ -527,6 +541,24 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
   long long t_prev = (long long)__builtin_readcyclecounter();
 #endif
 
+  // Workgroups that start together load, wait and compute in lockstep: the memory system is idle while they all compute
+  // and saturated while they all load.  Every other group of 8 consecutive workgroups (the 8 XCDs take consecutive
+  // workgroups in turn: every other workgroup of an XCD) starts 2 x 8128 cycles late, and since the periods are equal
+  // the offset persists.  Measured (config 2 shape, global variances, float64): forward 0.143 -> 0.126 ms, backward
+  // 0.140 -> 0.134; 512 x 2000 x 60: 0.460 -> 0.425.  A launch that does not fill the chip has nothing to gain (config 3
+  // shape: 0.039 -> 0.045 ms with the delay), so only full grids do it.
+#ifndef MLPG_CONST_STAGGER
+#define MLPG_CONST_STAGGER 2
+#endif
+#ifndef MLPG_CONST_STAGGER_SHIFT
+#define MLPG_CONST_STAGGER_SHIFT 3
+#endif
+#ifndef MLPG_CONST_STAGGER_MASK
+#define MLPG_CONST_STAGGER_MASK 1
+#endif
+  if (gridDim.x >= 128)
+    for (int q = 0; q < MLPG_CONST_STAGGER * (int)((blockIdx.x >> MLPG_CONST_STAGGER_SHIFT) & MLPG_CONST_STAGGER_MASK); ++q)
+      __builtin_amdgcn_s_sleep(127);
   for (int q = blockIdx.x; q < a.nsg; q += gridDim.x) {
     const int b = q / a.ndg, dg = q - b * a.ndg;
     const int Tmax = p.Tmax;
@@ -548,6 +580,22 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
         make_rsrc(BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * p.ld_gout + d0 : (const TIN *)p.mean + (size_t)b * Tmax * p.ld_in + d0);
     const unsigned ld_bytes = (unsigned)(BWD ? p.ld_gout : p.ld_in) * (unsigned)sizeof(TIN);
     const unsigned win_bytes = (unsigned)p.sd * (unsigned)sizeof(TIN);
+    // touch_lines geometry: a frame's rows of this dim group span `span` bytes (window-major columns), lpf lines of
+    // 128 bytes cover them wherever they start; lane L names line L % lpf of frame L / lpf of a batch of fpi frames
+    const unsigned span = (unsigned)(NL - 1) * win_bytes + (unsigned)nd * (unsigned)sizeof(TIN);
+    const int lpf = (int)((span + 127u) / 128u) + 1, fpi = 64 / lpf;
+    const int t_fi = lane / lpf < fpi ? lane / lpf : 0;
+    const unsigned t_off = (unsigned)(lane % lpf) * 128u < span - 4u ? (unsigned)(lane % lpf) * 128u : span - 4u;
+    const unsigned sink_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) int *)lds.sink[wv]);
+    auto touch_frames = [&](const int t0, const int n) __attribute__((always_inline)) {  // frames t0 .. t0+n-1 (clamped into the utterance)
+      if (!MLPG_CONST_TOUCH) return;
+      for (int i = 0; i < n; i += fpi) {
+        int t = t0 + i + t_fi;
+        t = t > t0 + n - 1 ? t0 + n - 1 : t;
+        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+        touch_lines(irs, (unsigned)t * ld_bytes + t_off, sink_addr);
+      }
+    };
 
     // this wavefront's first chunk: its frames are requested before anything else
     TIN ring[kRing][NL];
@@ -555,6 +603,7 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
       const int a0 = T - (NC - wv) * M;
 #pragma unroll
       for (int f = 0; f < kRing; ++f) ring_issue<TIN, BWD, NW, kRing>(ring, f, f, irs, loff, ld_bytes, win_bytes, a0);
+      touch_frames(a0 + kRing, M - kRing);
     }
     // the table's head
     const int i_s_v = a.tabi[dg * 128], ok_v = a.tabi[dg * 128 + 1];
@@ -687,6 +736,7 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
         if (j + W < NC) {
 #pragma unroll
           for (int f = 0; f < kRing; ++f) ring_issue<TIN, BWD, NW, kRing>(ring, f, f, irs, loff, ld_bytes, win_bytes, a0 + S);
+          touch_frames(a0 + S + kRing, M - kRing);
         }
         if (!BWD) {
           lds.halo[wv][0][lane] = up;

@@ -13,14 +13,15 @@ def timeit(fn, reps=30, warm=5):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
+    evs = []
+    for _ in range(reps):      # queued ahead: the host's launch latency must not sit between the events
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        e1.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ts = [e0.elapsed_time(e1) for e0, e1 in evs]
     return float(np.median(ts)), float(np.min(ts))
 
 
