@@ -182,7 +182,28 @@ def _run(only, quick, device_index):
             ms = gpu_time(lambda: _hip.forward(m, var, WINDOWS, want_status=False))
             by = 32.0 * sd * B * T
             emit(path="c2g-" + name, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
-        del m
+        # the same variances, backward (constant-coefficient kernel): read grad_out, write 3 gradient rows per (frame, dim)
+        go = torch.randn(B, T, sd, dtype=torch.float64, device=dev, generator=gen)
+        for name, var in (("global", vg), ("unit", None)):
+            ms = gpu_time(lambda: _hip.backward(var, go, WINDOWS, 3 * sd, out_dtype=torch.float64, want_status=False))
+            by = 32.0 * sd * B * T
+            emit(path="c2g-" + name + "-backward", ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
+        del m, go
+        # config 5's mgc stream (T = 2000, 512 utterances = one GPU's share) with global variances
+        B5, T5 = 512, 2000
+        m5 = torch.randn(B5, T5, 3 * sd, dtype=torch.float64, device=dev, generator=gen)
+        ms = gpu_time(lambda: _hip.forward(m5, vg, WINDOWS, want_status=False))
+        by = 32.0 * sd * B5 * T5
+        emit(path="c5g-mgc-global-variances", ms=ms, frames_per_s=B5 * T5 / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
+        del m5
+        # long utterances, per-frame variances (T = 4000: 63 strips per utterance, dealt to the XCD work lists in two blocks)
+        B2, T2 = 64, 4000
+        m2 = torch.randn(B2, T2, 3 * sd, dtype=torch.float64, device=dev, generator=gen)
+        v2 = torch.rand(B2, T2, 3 * sd, dtype=torch.float64, device=dev, generator=gen) + 0.1
+        ms = gpu_time(lambda: _hip.forward(m2, v2, WINDOWS, want_status=False), steps=5)
+        by2 = 56.0 * sd * B2 * T2
+        emit(path="long-T4000-forward", ms=ms, frames_per_s=B2 * T2 / ms * 1e3, alg_bytes=by2, GBps=by2 / ms / 1e6)
+        del m2, v2
 
     # ---- c2h: config 2 end to end from host memory (numpy in -> numpy out through paramgen.mlpg_batch): PCIe-inclusive ----
     if want("c2h"):
