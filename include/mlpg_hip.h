@@ -63,11 +63,14 @@ extern "C" {
 #define MLPG_HIP_ALGO_CONST 5   /* global (D,) / unit variances: the matrix of a static dim is the same for every
                                    utterance (_mlpg.py:169-170 tiles the variances) -- factorised once per launch, the
                                    solves are constant-coefficient recurrences, lane-per-static-dim, any T */
+#define MLPG_HIP_ALGO_CHUNK 6   /* window extents up to 2 (5-tap windows: P has half-bandwidth 4), forward: chunks of 16 + 4 frames
+                                   eliminated twice around a block-tridiagonal solve over their separators; no workgroup waits
+                                   for another; lane-per-static-dim, any T */
 
 int mlpg_hip_abi_version(void);
 const char *mlpg_hip_last_error(void);
 /* Test aid, not part of the reference's interface: launches per MLPG kernel family since the library was loaded --
- * 0 natural-order, 1 wave-per-system, 2 strip, 3 strip with several streams merged, 4 constant-coefficient, 5 fused
+ * 0 natural-order, 1 wave-per-system, 2 strip, 3 strip with several streams merged, 4 constant-coefficient, 5 fused, 6 chunked
  * unit-variance step; -1 for any other `kind`.  (Tests use it to assert WHICH kernel a call took.) */
 long long mlpg_hip_launch_count(int kind);
 int mlpg_hip_device_count(void);

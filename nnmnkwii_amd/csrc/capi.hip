@@ -32,7 +32,7 @@ void note_launch(int kind) {
 // Launches on different streams of one device never share a buffer; a buffer is only ever
 // reused, grown or freed behind work of its own stream.
 namespace {
-constexpr int kMaxDevices = 16, kSlots = 6;
+constexpr int kMaxDevices = 16, kSlots = 7;
 struct Slot {
   void *ptr = nullptr;
   size_t bytes = 0;
@@ -179,7 +179,7 @@ int check_common(int B, int Tmax, int D, int nw) {
 // ones, generic kernel for window extents > 1 or utterances longer than either supports.
 int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool backward, const Problem &p,
                    const WinSet &ws, int device) {
-  if (algo < MLPG_HIP_ALGO_AUTO || algo > MLPG_HIP_ALGO_CONST) {
+  if (algo < MLPG_HIP_ALGO_AUTO || algo > MLPG_HIP_ALGO_CHUNK) {
     set_error("unknown algo %d", algo);
     return MLPG_HIP_EINVAL;
   }
@@ -193,6 +193,10 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
   }
   if (algo == MLPG_HIP_ALGO_CONST && !const_supported(p, ws)) {
     set_error("MLPG_HIP_ALGO_CONST needs global or unit variances and 2-3 windows of extent <= 1 (var_mode %d, %d windows, T=%d)", p.var_mode, ws.nw, p.Tmax);
+    return MLPG_HIP_EINVAL;
+  }
+  if (algo == MLPG_HIP_ALGO_CHUNK && (backward || in_dtype != out_dtype || !chunk_supported(p, ws))) {
+    set_error("MLPG_HIP_ALGO_CHUNK: forward pass, input dtype = output dtype, 1-3 windows of extent 1 or 2 (%d windows, extent %d)", ws.nw, ws.mw);
     return MLPG_HIP_EINVAL;
   }
   if (algo == MLPG_HIP_ALGO_PIPE) {
@@ -209,10 +213,12 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
   }
   if (algo == MLPG_HIP_ALGO_AUTO) {
     if (const_preferred(p, ws)) algo = MLPG_HIP_ALGO_CONST;
+    else if (in_dtype == out_dtype && chunk_preferred(p, ws, backward)) algo = MLPG_HIP_ALGO_CHUNK;
     else if (strip_preferred(p, ws, backward, in_dtype) || (strip_supported(p, ws) && !wave_supported(p, ws))) algo = MLPG_HIP_ALGO_STRIP;
     else algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
   }
   if (algo == MLPG_HIP_ALGO_CONST) return launch_const(st, in_dtype, out_dtype, backward, p, ws, device);
+  if (algo == MLPG_HIP_ALGO_CHUNK) return launch_chunk(st, in_dtype, out_dtype, backward, p, ws, device);
   if (algo == MLPG_HIP_ALGO_STRIP) return launch_strip(st, in_dtype, out_dtype, backward, p, ws, device);
   if (algo == MLPG_HIP_ALGO_WAVE) return launch_wave(st, in_dtype, out_dtype, backward, p, ws, device);
   return launch_generic(st, in_dtype, out_dtype, backward, p, ws, device);

@@ -58,10 +58,10 @@ struct StreamMap {
 
 void set_error(const char *fmt, ...);
 // launches per kernel family since the library was loaded (mlpg_hip_launch_count: a test aid)
-enum { kCountGeneric = 0, kCountWave, kCountStrip, kCountStripMulti, kCountConst, kCountFused, kCountKinds };
+enum { kCountGeneric = 0, kCountWave, kCountStrip, kCountStripMulti, kCountConst, kCountFused, kCountChunk, kCountKinds };
 void note_launch(int kind);
 // Grow-only scratch, cached per (device, stream, slot): slot 0 generic factor, 1 fastdtw pyramids,
-// 2 generic status, 3 strip records, 4 constant-coefficient kernel (factor table), 5 fastdtw from host costs (D rows, back-pointers).  Returns nullptr (and sets the error) on failure.
+// 2 generic status, 3 strip records, 4 constant-coefficient kernel (factor table), 5 fastdtw from host costs (D rows, back-pointers), 6 chunked kernel (records, block factors, separator solutions, marks).  Returns nullptr (and sets the error) on failure.
 void *scratch(int device, hipStream_t stream, int slot, size_t bytes, unsigned long long *gen = nullptr);
 
 // launchers (one per translation unit)
@@ -87,6 +87,9 @@ bool const_supported(const Problem &p, const WinSet &w);
 bool const_scratch_fresh(int device, hipStream_t stream, unsigned long long gen);
 bool const_preferred(const Problem &p, const WinSet &w);
 int launch_const(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
+bool chunk_supported(const Problem &p, const WinSet &w);
+bool chunk_preferred(const Problem &p, const WinSet &w, bool backward);
+int launch_chunk(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
 int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,
                      int ncols, void *dst, long ld_dst);
 int launch_stream_copy(hipStream_t s, const void *src, void *dst, size_t nbytes);
