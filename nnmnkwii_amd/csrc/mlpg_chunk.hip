@@ -53,13 +53,14 @@ int launch_q(hipStream_t st, const Problem &p, const WinSet &ws, int device) {
   a.nsg = p.B * a.ndg;
   const size_t nsg = (size_t)a.nsg;
   const size_t rec_b = nsg * a.K * G::kRec * 64 * sizeof(double), fac_b = nsg * a.K * G::kFac * 64 * sizeof(double),
-               xs_b = nsg * a.K * Q * 64 * sizeof(double), bad_b = nsg * 64 * sizeof(int);
-  char *sc = (char *)scratch(device, st, 6, rec_b + fac_b + xs_b + bad_b + 256);
+               xs_b = nsg * a.K * Q * 64 * sizeof(double), mid_b = nsg * G::kFac * 64 * sizeof(double), bad_b = nsg * 64 * sizeof(int);
+  char *sc = (char *)scratch(device, st, 6, rec_b + fac_b + xs_b + mid_b + bad_b + 256);
   if (!sc) return MLPG_HIP_ENOMEM;
   a.rec = (double *)sc;
   a.fac = (double *)(sc + rec_b);
   a.xs = (double *)(sc + rec_b + fac_b);
-  a.bad = (int *)(sc + rec_b + fac_b + xs_b);
+  a.mid = (double *)(sc + rec_b + fac_b + xs_b);
+  a.bad = (int *)(sc + rec_b + fac_b + xs_b + mid_b);
   MLPG_HIP_CHECK(hipMemsetAsync(a.bad, 0, bad_b, st));  // the marks of non-positive pivots
   constexpr size_t lds3 = (size_t)kW * (G::NLDS ? G::NLDS : 0) * (Q + 1) * 64 * sizeof(double);
   constexpr size_t lds1 = MLPG_CHUNK_US_LDS ? (size_t)kW * 8 * Q * 64 * sizeof(double) : 0;
@@ -71,7 +72,8 @@ int launch_q(hipStream_t st, const Problem &p, const WinSet &ws, int device) {
     case MLPG_HIP_VAR_GLOBAL: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_GLOBAL, Q, false>), grid, block, lds1, st, p, a); break;
     default: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_UNIT, Q, false>), grid, block, lds1, st, p, a);
   }
-  hipLaunchKernelGGL((reduce_kernel<Q>), dim3((unsigned)a.nsg), dim3(64), 0, st, p, a);
+  hipLaunchKernelGGL((reduce_elim_kernel<Q>), dim3((unsigned)(2 * a.nsg)), dim3(64), 0, st, p, a);
+  hipLaunchKernelGGL((reduce_subst_kernel<Q>), dim3((unsigned)(2 * a.nsg)), dim3(64), 0, st, p, a);
   switch (p.var_mode) {
     case MLPG_HIP_VAR_FRAME: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_FRAME, Q, true>), grid, block, lds3, st, p, a); break;
     case MLPG_HIP_VAR_GLOBAL: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_GLOBAL, Q, true>), grid, block, lds3, st, p, a); break;

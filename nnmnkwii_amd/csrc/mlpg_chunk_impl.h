@@ -8,8 +8,9 @@
 //           precisions spread over the 2 * EXT + 1 rows it touches) and eliminated in natural order with the INTERIOR rows as
 //           the only pivots; the Q columns that couple the first interior rows to the previous chunk's separator ride along
 //           as right-hand sides.  Only the chunk's record survives (Q = 4: 44 doubles per lane).
-//   pass 2  reduce_kernel: one wavefront per (utterance, dim group): the separators' block-tridiagonal system (Q x Q blocks),
-//           forward elimination over the chunks, back-substitution: the separators' solutions.
+//   pass 2  reduce_elim_kernel + reduce_subst_kernel: the separators' block-tridiagonal system (Q x Q blocks), two wavefronts per
+//           (utterance, dim group): elimination from both ends towards the middle, substitution from the middle outwards: the
+//           separators' solutions.
 //   pass 3  chunk_kernel<.., P3 = true>: the same elimination AGAIN with the neighbouring separators' solutions known; the
 //           factor rows of the chunk stay on chip this time (the first NLDS rows in LDS, the others in registers),
 //           back-substitution, the trajectory is stored.
@@ -45,6 +46,7 @@ struct Args {
   double *rec;  // [g][chunk][kRec][64]
   double *fac;  // [g][chunk][kFac][64]
   double *xs;   // [g][chunk][Q][64]
+  double *mid;  // [g][kFac][64]: the block where the two halves of pass 2 meet, before its factorisation
   int *bad;     // [g][64]
   int ndg, dgw, nsg, K;  // dim groups per utterance, dims per group, system groups, chunks per utterance (from Tmax)
   int nw, mw;
@@ -389,48 +391,17 @@ __global__ __launch_bounds__(kW * 64, 2) void chunk_kernel(const Problem p, cons
   }
 }
 
-// ---- pass 2: the separators' block-tridiagonal system, one wavefront per (utterance, dim group) ----
+// ---- pass 2: the separators' block-tridiagonal system ----
+// Two wavefronts per (utterance, dim group) that never talk to each other inside a kernel: reduce_elim_kernel eliminates the first
+// half of the blocks downwards (h = 0) and the second half upwards (h = 1), reduce_subst_kernel joins the two at the middle
+// (both wavefronts solve the same two-block system) and substitutes outwards.  One wavefront walking all the blocks is issue-bound
+// on its own instruction stream (~1 us per block, 120 us at T = 1000); the halves take half of that.
 template <int Q>
-__global__ __launch_bounds__(64) void reduce_kernel(const Problem p, const Args a) {
+struct Blk {
   using G = Geo<Q>;
-  constexpr int NS = G::NS, C = G::C;
-  const int lane = threadIdx.x;
-  const int g = blockIdx.x;
-  const int b = g / a.ndg;
-  int T = p.lengths ? p.lengths[b] : p.Tmax;
-  T = T < 0 ? 0 : (T > p.Tmax ? p.Tmax : T);
-  const int Kb = (T + C - 1) / C;  // chunks that hold frames of this utterance
-  if (Kb == 0) return;
-  const double *rec = a.rec + (size_t)g * a.K * G::kRec * 64 + lane;
-  double *fac = a.fac + (size_t)g * a.K * G::kFac * 64 + lane;
-  double *xs = a.xs + (size_t)g * a.K * Q * 64 + lane;
-  bool bad = false;
-  double Lp[NS], dpi[Q], rp[Q];  // the previous block's factor (strict lower part of Lp used) and right-hand side
-  // record fields of chunk k, loaded one chunk ahead
-  double nSRR[NS], nGR[Q], nSRL[Q * Q], nSLL[NS], nGL[Q];
-  auto load = [&](const int k) __attribute__((always_inline)) {
-    const double *rk = rec + (size_t)k * G::kRec * 64;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) nSRR[i] = rk[(G::oSRR + i) * 64];
-#pragma unroll
-    for (int i = 0; i < Q; ++i) nGR[i] = rk[(G::oGR + i) * 64];
-#pragma unroll
-    for (int i = 0; i < Q * Q; ++i) nSRL[i] = rk[(G::oSRL + i) * 64];
-    if (k + 1 < Kb) {
-      const double *rn = rk + (size_t)G::kRec * 64;
-#pragma unroll
-      for (int i = 0; i < NS; ++i) nSLL[i] = rn[(G::oSLL + i) * 64];
-#pragma unroll
-      for (int i = 0; i < Q; ++i) nGL[i] = rn[(G::oGL + i) * 64];
-    } else {
-#pragma unroll
-      for (int i = 0; i < NS; ++i) nSLL[i] = 0.0;
-#pragma unroll
-      for (int i = 0; i < Q; ++i) nGL[i] = 0.0;
-    }
-  };
+  static constexpr int NS = G::NS;
   // solve (L D L^T) v = e with the factor held as (Lf strict lower, di inverse pivots)
-  auto solve = [&](const double (&Lf)[NS], const double (&di)[Q], double (&v)[Q]) __attribute__((always_inline)) {
+  static __device__ __forceinline__ void solve(const double (&Lf)[NS], const double (&di)[Q], double (&v)[Q]) {
 #pragma unroll
     for (int i = 1; i < Q; ++i)
 #pragma unroll
@@ -441,40 +412,17 @@ __global__ __launch_bounds__(64) void reduce_kernel(const Problem p, const Args 
     for (int i = Q - 2; i >= 0; --i)
 #pragma unroll
       for (int j = i + 1; j < Q; ++j) v[i] = __builtin_fma(-Lf[tri(j, i)], v[j], v[i]);
-  };
-  load(0);
-  for (int k = 0; k < Kb; ++k) {
-    double D[NS], r[Q], E[Q * Q];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) D[i] = nSRR[i] + nSLL[i];
-#pragma unroll
-    for (int i = 0; i < Q; ++i) r[i] = nGR[i] + nGL[i];
-#pragma unroll
-    for (int i = 0; i < Q * Q; ++i) E[i] = nSRL[i];
-    if (k + 1 < Kb) load(k + 1);
-    if (k) {
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {  // row q of G = E Dprev^-1
-        double gq[Q];
-#pragma unroll
-        for (int s = 0; s < Q; ++s) gq[s] = E[q * Q + s];
-        solve(Lp, dpi, gq);
-#pragma unroll
-        for (int s = 0; s < Q; ++s) {
-          r[q] = __builtin_fma(-gq[s], rp[s], r[q]);
-#pragma unroll
-          for (int q2 = 0; q2 <= q; ++q2) D[tri(q, q2)] = __builtin_fma(-gq[s], E[q2 * Q + s], D[tri(q, q2)]);
-        }
-      }
-    }
-    // D = L Dg L^T
-    double di[Q], dv[Q];
+  }
+  // D (packed symmetric) -> unit-lower multipliers in its strict lower part, inverse pivots in di; false on a non-positive pivot
+  static __device__ __forceinline__ bool factor(double (&D)[NS], double (&di)[Q]) {
+    bool ok = true;
+    double dv[Q];
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
       double piv = D[tri(j, j)];
 #pragma unroll
       for (int m = 0; m < j; ++m) piv = __builtin_fma(-D[tri(j, m)] * D[tri(j, m)], dv[m], piv);
-      bad = bad || !(piv > 0.0);
+      ok = ok && (piv > 0.0);
       dv[j] = piv;
       di[j] = fast_rcp(piv);
 #pragma unroll
@@ -482,19 +430,32 @@ __global__ __launch_bounds__(64) void reduce_kernel(const Problem p, const Args 
         double v = D[tri(i, j)];
 #pragma unroll
         for (int m = 0; m < j; ++m) v = __builtin_fma(-D[tri(i, m)] * D[tri(j, m)], dv[m], v);
-        D[tri(i, j)] = v * di[j];  // multiplier
+        D[tri(i, j)] = v * di[j];
       }
     }
-    double *fk = fac + (size_t)k * G::kFac * 64;
+    return ok;
+  }
+  // (D, r) -= coupling through the neighbouring block (factor Lp, dpi; right-hand side rp).  DOWN: the neighbour is the block
+  // above, E[q][s] couples this block's row q to its column s;  !DOWN: the neighbour is the block below, E[q][s] couples ITS row
+  // q to this block's column s.
+  template <bool DOWN>
+  static __device__ __forceinline__ void couple(double (&D)[NS], double (&r)[Q], const double (&E)[Q * Q], const double (&Lp)[NS],
+                                                const double (&dpi)[Q], const double (&rp)[Q]) {
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      Lp[i] = D[i];
-    }
+    for (int i = 0; i < Q; ++i) {  // row i of E Dp^-1 (DOWN) / E^T Dp^-1
+      double gq[Q];
 #pragma unroll
-    for (int i = 0; i < Q; ++i) {
-      dpi[i] = di[i];
-      rp[i] = r[i];
+      for (int s = 0; s < Q; ++s) gq[s] = DOWN ? E[i * Q + s] : E[s * Q + i];
+      solve(Lp, dpi, gq);
+#pragma unroll
+      for (int s = 0; s < Q; ++s) {
+        r[i] = __builtin_fma(-gq[s], rp[s], r[i]);
+#pragma unroll
+        for (int i2 = 0; i2 <= i; ++i2) D[tri(i, i2)] = __builtin_fma(-gq[s], DOWN ? E[i2 * Q + s] : E[s * Q + i2], D[tri(i, i2)]);
+      }
     }
+  }
+  static __device__ __forceinline__ void store_fac(double *fk, const double (&D)[NS], const double (&di)[Q], const double (&r)[Q]) {
     int o = 0;
 #pragma unroll
     for (int i = 1; i < Q; ++i)
@@ -505,27 +466,7 @@ __global__ __launch_bounds__(64) void reduce_kernel(const Problem p, const Args 
 #pragma unroll
     for (int i = 0; i < Q; ++i) fk[(NS + i) * 64] = r[i];
   }
-  // back-substitution, the next block's factor and coupling requested one block ahead
-  double xn[Q];
-#pragma unroll
-  for (int i = 0; i < Q; ++i) xn[i] = 0.0;
-  double pF[G::kFac], pE[Q * Q];
-  auto load_back = [&](const int k) __attribute__((always_inline)) {
-    const double *fk = fac + (size_t)k * G::kFac * 64;
-#pragma unroll
-    for (int i = 0; i < G::kFac; ++i) pF[i] = fk[i * 64];
-    if (k + 1 < Kb) {
-      const double *rn = rec + (size_t)(k + 1) * G::kRec * 64;
-#pragma unroll
-      for (int i = 0; i < Q * Q; ++i) pE[i] = rn[(G::oSRL + i) * 64];
-    } else {
-#pragma unroll
-      for (int i = 0; i < Q * Q; ++i) pE[i] = 0.0;
-    }
-  };
-  load_back(Kb - 1);
-  for (int k = Kb - 1; k >= 0; --k) {
-    double Lf[NS], di[Q], v[Q], E[Q * Q];
+  static __device__ __forceinline__ void unpack_fac(const double (&pF)[G::kFac], double (&Lf)[NS], double (&di)[Q], double (&r)[Q]) {
     int o = 0;
 #pragma unroll
     for (int i = 0; i < NS; ++i) Lf[i] = 0.0;
@@ -536,19 +477,217 @@ __global__ __launch_bounds__(64) void reduce_kernel(const Problem p, const Args 
 #pragma unroll
     for (int i = 0; i < Q; ++i) di[i] = pF[NS - Q + i];
 #pragma unroll
-    for (int i = 0; i < Q; ++i) v[i] = pF[NS + i];
+    for (int i = 0; i < Q; ++i) r[i] = pF[NS + i];
+  }
+};
+
+// mid: [g][kFac][64] -- the middle block of the upward half BEFORE it is factorised (packed D, then r)
+template <int Q>
+__global__ __launch_bounds__(64) void reduce_elim_kernel(const Problem p, const Args a) {
+  using G = Geo<Q>;
+  using B = Blk<Q>;
+  constexpr int NS = G::NS, C = G::C;
+  const int lane = threadIdx.x;
+  const int g = blockIdx.x >> 1, h = blockIdx.x & 1;
+  const int b = g / a.ndg;
+  int T = p.lengths ? p.lengths[b] : p.Tmax;
+  T = T < 0 ? 0 : (T > p.Tmax ? p.Tmax : T);
+  const int Kb = (T + C - 1) / C;  // chunks that hold frames of this utterance
+  const int m = Kb / 2;            // blocks 0 .. m-1 are eliminated downwards, m .. Kb-1 upwards
+  const int k0 = h ? Kb - 1 : 0, k1 = h ? m - 1 : m, dk = h ? -1 : 1;  // k0, k0 + dk, ... while != k1
+  if (k0 == k1) return;
+  const double *rec = a.rec + (size_t)g * a.K * G::kRec * 64 + lane;
+  double *fac = a.fac + (size_t)g * a.K * G::kFac * 64 + lane;
+  bool bad = false;
+  double Lp[NS], dpi[Q], rp[Q];
+  // block k: diagonal (two parts), right-hand side (two parts), coupling to the block eliminated before it -- requested kPF2
+  // blocks ahead (a block is 22 KB per wavefront and a step is shorter than the memory's latency)
+  constexpr int kPF2 = 3, kBlk = 2 * NS + 2 * Q + Q * Q;
+  double pb[kPF2][kBlk];
+  auto load = [&](double (&dst)[kBlk], const int k) __attribute__((always_inline)) {
+    const bool in = h ? k > k1 : k < k1;
+    const double *rk = rec + (size_t)(in ? k : k0) * G::kRec * 64;
+    const bool nx = in && k + 1 < Kb;
+    const double *rn = rk + (nx ? (size_t)G::kRec * 64 : 0);
+    const int ke = h ? k + 1 : k;  // downwards: E_k (record k couples separator k to k-1); upwards: E_{k+1}
+    const bool he = in && ke >= 1 && ke < Kb;
+    const double *re = rec + (size_t)(he ? ke : k0) * G::kRec * 64;
 #pragma unroll
-    for (int i = 0; i < Q * Q; ++i) E[i] = pE[i];
-    if (k > 0) load_back(k - 1);
+    for (int i = 0; i < NS; ++i) dst[i] = rk[(G::oSRR + i) * 64];
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
+    for (int i = 0; i < Q; ++i) dst[NS + i] = rk[(G::oGR + i) * 64];
 #pragma unroll
-      for (int s = 0; s < Q; ++s) v[s] = __builtin_fma(-E[q * Q + s], xn[q], v[s]);
-    solve(Lf, di, v);
+    for (int i = 0; i < NS; ++i) dst[NS + Q + i] = nx ? rn[(G::oSLL + i) * 64] : 0.0;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) dst[2 * NS + Q + i] = nx ? rn[(G::oGL + i) * 64] : 0.0;
+#pragma unroll
+    for (int i = 0; i < Q * Q; ++i) dst[2 * NS + 2 * Q + i] = he ? re[(G::oSRL + i) * 64] : 0.0;
+  };
+#pragma unroll
+  for (int j = 0; j < kPF2; ++j) load(pb[j], k0 + j * dk);
+  for (int k = k0; k != k1; k += dk) {
+    double D[NS], r[Q], E[Q * Q];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) D[i] = pb[0][i] + pb[0][NS + Q + i];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) r[i] = pb[0][NS + i] + pb[0][2 * NS + Q + i];
+#pragma unroll
+    for (int i = 0; i < Q * Q; ++i) E[i] = pb[0][2 * NS + 2 * Q + i];
+#pragma unroll
+    for (int j = 0; j + 1 < kPF2; ++j)
+#pragma unroll
+      for (int i = 0; i < kBlk; ++i) pb[j][i] = pb[j + 1][i];
+    load(pb[kPF2 - 1], k + kPF2 * dk);
+    if (k != k0) {
+      if (h) B::template couple<false>(D, r, E, Lp, dpi, rp);
+      else B::template couple<true>(D, r, E, Lp, dpi, rp);
+    }
+    if (h && k == m) {  // the block where the halves meet: kept unfactorised for reduce_subst_kernel
+      double *mk = a.mid + (size_t)g * G::kFac * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) mk[i * 64] = D[i];
+#pragma unroll
+      for (int i = 0; i < Q; ++i) mk[(NS + i) * 64] = r[i];
+    }
+    double di[Q];
+    bad = !B::factor(D, di) || bad;
+    B::store_fac(fac + (size_t)k * G::kFac * 64, D, di, r);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) Lp[i] = D[i];
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
-      xn[i] = v[i];
-      xs[((size_t)k * Q + i) * 64] = v[i];
+      dpi[i] = di[i];
+      rp[i] = r[i];
+    }
+  }
+  if (bad) a.bad[(size_t)g * 64 + lane] = 1;
+}
+
+template <int Q>
+__global__ __launch_bounds__(64) void reduce_subst_kernel(const Problem p, const Args a) {
+  using G = Geo<Q>;
+  using B = Blk<Q>;
+  constexpr int NS = G::NS, C = G::C;
+  const int lane = threadIdx.x;
+  const int g = blockIdx.x >> 1, h = blockIdx.x & 1;
+  const int b = g / a.ndg;
+  int T = p.lengths ? p.lengths[b] : p.Tmax;
+  T = T < 0 ? 0 : (T > p.Tmax ? p.Tmax : T);
+  const int Kb = (T + C - 1) / C;
+  if (Kb == 0) return;
+  const int m = Kb / 2;
+  if (h == 0 && m == 0) return;
+  const double *rec = a.rec + (size_t)g * a.K * G::kRec * 64 + lane;
+  const double *fac = a.fac + (size_t)g * a.K * G::kFac * 64 + lane;
+  double *xs = a.xs + (size_t)g * a.K * Q * 64 + lane;
+  bool bad = false;
+  // ---- the middle: x_m (and, downwards, x_{m-1}) ----
+  double xm[Q];
+  {
+    double pF[G::kFac], D[NS], r[Q];
+    const double *mk = a.mid + (size_t)g * G::kFac * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < G::kFac; ++i) pF[i] = mk[i * 64];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) D[i] = pF[i];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) r[i] = pF[NS + i];
+    if (m >= 1) {
+      double pG[G::kFac], E[Q * Q], Lp[NS], dpi[Q], rp[Q];
+      const double *fk = fac + (size_t)(m - 1) * G::kFac * 64;
+#pragma unroll
+      for (int i = 0; i < G::kFac; ++i) pG[i] = fk[i * 64];
+      const double *re = rec + (size_t)m * G::kRec * 64;
+#pragma unroll
+      for (int i = 0; i < Q * Q; ++i) E[i] = re[(G::oSRL + i) * 64];
+      B::unpack_fac(pG, Lp, dpi, rp);
+      B::template couple<true>(D, r, E, Lp, dpi, rp);
+    }
+    double di[Q];
+    bad = !B::factor(D, di);
+#pragma unroll
+    for (int i = 0; i < Q; ++i) xm[i] = r[i];
+    B::solve(D, di, xm);
+  }
+  if (h) {
+    // upwards from the middle: x_k = D''_k^-1 (r''_k - E_k x_{k-1})
+#pragma unroll
+    for (int i = 0; i < Q; ++i) xs[((size_t)m * Q + i) * 64] = xm[i];
+    constexpr int kPF2 = 3;
+    double pF[kPF2][G::kFac], pE[kPF2][Q * Q];
+    auto load_up = [&](const int j, const int k) __attribute__((always_inline)) {
+      const int kk = k < Kb ? k : Kb - 1;
+      const double *fk = fac + (size_t)kk * G::kFac * 64;
+#pragma unroll
+      for (int i = 0; i < G::kFac; ++i) pF[j][i] = fk[i * 64];
+      const double *re = rec + (size_t)kk * G::kRec * 64;
+#pragma unroll
+      for (int i = 0; i < Q * Q; ++i) pE[j][i] = re[(G::oSRL + i) * 64];
+    };
+#pragma unroll
+    for (int j = 0; j < kPF2; ++j) load_up(j, m + 1 + j);
+    for (int k = m + 1; k < Kb; ++k) {
+      double Lf[NS], di[Q], v[Q], E[Q * Q];
+      B::unpack_fac(pF[0], Lf, di, v);
+#pragma unroll
+      for (int i = 0; i < Q * Q; ++i) E[i] = pE[0][i];
+#pragma unroll
+      for (int j = 0; j + 1 < kPF2; ++j) {
+#pragma unroll
+        for (int i = 0; i < G::kFac; ++i) pF[j][i] = pF[j + 1][i];
+#pragma unroll
+        for (int i = 0; i < Q * Q; ++i) pE[j][i] = pE[j + 1][i];
+      }
+      load_up(kPF2 - 1, k + kPF2);
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int s = 0; s < Q; ++s) v[q] = __builtin_fma(-E[q * Q + s], xm[s], v[q]);
+      B::solve(Lf, di, v);
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        xm[i] = v[i];
+        xs[((size_t)k * Q + i) * 64] = v[i];
+      }
+    }
+  } else {
+    // downwards from the middle: x_k = D'_k^-1 (r'_k - E_{k+1}^T x_{k+1}), k = m-1 .. 0
+    constexpr int kPF2 = 3;
+    double pF[kPF2][G::kFac], pE[kPF2][Q * Q];
+    auto load_dn = [&](const int j, const int k) __attribute__((always_inline)) {
+      const int kk = k >= 0 ? k : 0;
+      const double *fk = fac + (size_t)kk * G::kFac * 64;
+#pragma unroll
+      for (int i = 0; i < G::kFac; ++i) pF[j][i] = fk[i * 64];
+      const double *rn = rec + (size_t)(kk + 1) * G::kRec * 64;
+#pragma unroll
+      for (int i = 0; i < Q * Q; ++i) pE[j][i] = rn[(G::oSRL + i) * 64];
+    };
+#pragma unroll
+    for (int j = 0; j < kPF2; ++j) load_dn(j, m - 1 - j);
+    for (int k = m - 1; k >= 0; --k) {
+      double Lf[NS], di[Q], v[Q], E[Q * Q];
+      B::unpack_fac(pF[0], Lf, di, v);
+#pragma unroll
+      for (int i = 0; i < Q * Q; ++i) E[i] = pE[0][i];
+#pragma unroll
+      for (int j = 0; j + 1 < kPF2; ++j) {
+#pragma unroll
+        for (int i = 0; i < G::kFac; ++i) pF[j][i] = pF[j + 1][i];
+#pragma unroll
+        for (int i = 0; i < Q * Q; ++i) pE[j][i] = pE[j + 1][i];
+      }
+      load_dn(kPF2 - 1, k - kPF2);
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int s = 0; s < Q; ++s) v[s] = __builtin_fma(-E[q * Q + s], xm[q], v[s]);
+      B::solve(Lf, di, v);
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        xm[i] = v[i];
+        xs[((size_t)k * Q + i) * 64] = v[i];
+      }
     }
   }
   if (bad) a.bad[(size_t)g * 64 + lane] = 1;

@@ -196,6 +196,17 @@ def _run(only, quick, device_index):
         by = 32.0 * sd * B5 * T5
         emit(path="c5g-mgc-global-variances", ms=ms, frames_per_s=B5 * T5 / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6)
         del m5
+        # the reference's 5-tap test windows (tests/test_paramgen.py:21-26: P has half-bandwidth 4), config-2 shape, per-frame
+        # variances: the chunked kernel (AUTO) and the natural-order kernel
+        wide = [(0, 0, np.array([1.0])), (2, 2, np.array([1.0, -8.0, 0.0, 8.0, -1.0]) / 12.0),
+                (2, 2, np.array([-1.0, 16.0, -30.0, 16.0, -1.0]) / 12.0)]
+        mw_ = torch.randn(B, T, 3 * sd, dtype=torch.float64, device=dev, generator=gen)
+        vw_ = torch.rand(B, T, 3 * sd, dtype=torch.float64, device=dev, generator=gen) + 0.1
+        byw = 56.0 * sd * B * T
+        for name, algo in (("", 0), ("-natural-order-kernel", 1)):
+            ms = gpu_time(lambda: _hip.forward(mw_, vw_, wide, algo=algo, want_status=False), steps=5 if algo else 10)
+            emit(path="c2w-forward-5-tap-windows" + name, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=byw, GBps=byw / ms / 1e6)
+        del mw_, vw_
         # long utterances, per-frame variances (T = 4000: 63 strips per utterance, dealt to the XCD work lists in two blocks)
         B2, T2 = 64, 4000
         m2 = torch.randn(B2, T2, 3 * sd, dtype=torch.float64, device=dev, generator=gen)
