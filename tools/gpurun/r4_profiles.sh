@@ -27,6 +27,14 @@ for d in fwd bwd; do
     sum $tag --pmc
   done
 done
+# 4b. the chunked kernel (the reference's 5-tap windows at the config-2 shape): kernel trace and PMC per pass
+rocprofv3 --kernel-trace --stats -d gpurun_out/r04_chunk_trace -o run -- python tools/dbg/chunk_time.py > gpurun_out/r04_chunk_trace.log 2>&1
+sum r04_chunk_trace
+for c in FETCH_SIZE WRITE_SIZE; do
+  tag=r04_pmc_chunk_$c
+  rocprofv3 --kernel-trace --pmc $c -d gpurun_out/$tag -o run -- python tools/dbg/chunk_time.py > gpurun_out/$tag.log 2>&1
+  sum $tag --pmc
+done
 # 5. every secondary path
 rocprofv3 --kernel-trace --stats -d gpurun_out/r04_paths -o run -- python tools/bench_paths.py > gpurun_out/r04_paths.log 2>&1
 grep '"path"' gpurun_out/r04_paths.log > gpurun_out/r04_paths.jsonl; sum r04_paths
