@@ -122,3 +122,34 @@ def test_chunk_ill_conditioned_variances_as_the_other_kernels():
         assert rc == 0 and int(np.abs(st).max()) == 0
         ec, eg = rel_err(yc.reshape(-1, sd), yo.reshape(-1, sd)), rel_err(yg.reshape(-1, sd), yo.reshape(-1, sd))
         assert ec <= max(tol, 20 * eg), (sigma, ec, eg)
+
+
+def test_chunk_through_forward_streams_column_slices():
+    """Streams of one padded (B, T, ld) batch with the 5-tap windows (column slices read in place: row stride != stream width):
+    every stream takes the chunked kernel and equals the oracle on a dense copy of its slice."""
+    import torch
+    from nnmnkwii_amd import _hip
+    windows = WINDOW_SETS["wide3"]
+    rng = np.random.RandomState(23)
+    B, T = 5, 300
+    sds = [20, 3, 70]
+    ld = sum(3 * s for s in sds) + 4            # 4 unused columns between the streams and at the end
+    Y = rng.randn(B, T, ld)
+    V = rng.rand(B, T, ld) + 0.1
+    lengths = np.array([T, T - 1, 150, 21, 1], dtype=np.int32)
+    cols, c0 = [], 0
+    for s in sds:
+        cols.append(c0)
+        c0 += 3 * s + 1
+    n0 = _hip.lib().mlpg_hip_launch_count(6)
+    out, status = _hip.forward_streams(torch.from_numpy(Y).cuda(), torch.from_numpy(V).cuda(),
+                                       [(c, s, windows) for c, s in zip(cols, sds)], torch.from_numpy(lengths).cuda())
+    assert _hip.lib().mlpg_hip_launch_count(6) >= n0 + 2      # (a 3-dim stream may go to the natural-order kernel)
+    out = out.cpu().numpy()
+    assert int(status.abs().max()) == 0
+    o0 = 0
+    for c, s in zip(cols, sds):
+        yo, _, rc = O.mlpg_batch(np.ascontiguousarray(Y[:, :, c:c + 3 * s]), np.ascontiguousarray(V[:, :, c:c + 3 * s]), windows, lengths)
+        assert rc == 0
+        assert rel_err(out[:, :, o0:o0 + s].reshape(-1, s), yo.reshape(-1, s)) <= TOL64
+        o0 += s

@@ -1,7 +1,7 @@
-"""Random soak of every MLPG kernel (natural-order, wave-per-system, strip, constant-coefficient) against the C oracle (forward)
+"""Random soak of every MLPG kernel (natural-order, wave-per-system, strip, constant-coefficient, chunked) against the C oracle (forward)
 and against each other (backward: the natural-order kernel is the reference, itself pinned by tests/): random batch sizes,
 lengths (ragged), static dims 1..130, the three variance modes, float32 / float64, window sets of extent <= 1 (all kernels) and
-wider ones (natural-order kernel vs the oracle only).   usage: python tools/dbg/mlpg_algos_soak.py [seconds]"""
+the 5-tap set (natural-order and chunked kernels vs the oracle).   usage: python tools/dbg/mlpg_algos_soak.py [seconds]"""
 import os
 import sys
 import time
@@ -22,7 +22,7 @@ def soak(budget=40.0, seed=99):
     t0 = time.time()
     n = 0
     bad = None
-    names = {1: "generic", 2: "wave", 3: "strip", 5: "const"}
+    names = {1: "generic", 2: "wave", 3: "strip", 5: "const", 6: "chunk"}
     while time.time() - t0 < budget and bad is None:
         dt = [np.float64, np.float32][rng.randint(2)]
         tol = 2e-9 if dt == np.float64 else 3e-6
@@ -56,7 +56,7 @@ def soak(budget=40.0, seed=99):
         Ld = torch.from_numpy(lengths).cuda()
         scale = max(1.0, float(np.abs(ref).max()))
         slack = 1.0 if spread < 3.0 else 1e4              # ill-conditioned systems: the kernels agree with each other to ~1e-6
-        for algo in (1, 2, 3, 5):
+        for algo in (1, 2, 3, 5, 6):
             try:
                 out, status = _hip.forward(md, vd, win, Ld, algo=algo)
             except _hip.HipExtensionError:
