@@ -63,7 +63,7 @@ extern "C" {
 #define MLPG_HIP_ALGO_CONST 5   /* global (D,) / unit variances: the matrix of a static dim is the same for every
                                    utterance (_mlpg.py:169-170 tiles the variances) -- factorised once per launch, the
                                    solves are constant-coefficient recurrences, lane-per-static-dim, any T */
-#define MLPG_HIP_ALGO_CHUNK 6   /* window extents up to 2 (5-tap windows: P has half-bandwidth 4), forward: chunks of 16 + 4 frames
+#define MLPG_HIP_ALGO_CHUNK 6   /* window extents up to 2 (5-tap windows: P has half-bandwidth 4), forward and backward: chunks of 16 + 4 frames
                                    eliminated twice around a block-tridiagonal solve over their separators; no workgroup waits
                                    for another; lane-per-static-dim, any T */
 

@@ -195,8 +195,8 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     set_error("MLPG_HIP_ALGO_CONST needs global or unit variances and 2-3 windows of extent <= 1 (var_mode %d, %d windows, T=%d)", p.var_mode, ws.nw, p.Tmax);
     return MLPG_HIP_EINVAL;
   }
-  if (algo == MLPG_HIP_ALGO_CHUNK && (backward || in_dtype != out_dtype || !chunk_supported(p, ws))) {
-    set_error("MLPG_HIP_ALGO_CHUNK: forward pass, input dtype = output dtype, 1-3 windows of extent 1 or 2 (%d windows, extent %d)", ws.nw, ws.mw);
+  if (algo == MLPG_HIP_ALGO_CHUNK && (in_dtype != out_dtype || !chunk_supported(p, ws))) {
+    set_error("MLPG_HIP_ALGO_CHUNK: input dtype = output dtype, 1-3 windows of extent 1 or 2 (%d windows, extent %d)", ws.nw, ws.mw);
     return MLPG_HIP_EINVAL;
   }
   if (algo == MLPG_HIP_ALGO_PIPE) {

@@ -56,6 +56,13 @@ struct StreamMap {
   int begin[4], in_col[4], sd[4], out_col[4], stat_col[4];
 };
 
+// The strip, constant-coefficient and chunked kernels address an utterance's rows through a buffer descriptor with 32-bit byte
+// offsets from the utterance's first row (2 GB window): longer utterances (Tmax * row stride * 8 bytes) go to the natural-order kernel.
+inline bool rows_fit_buffer(const Problem &p) {
+  const long ld = p.ld_in > p.ld_out ? (p.ld_in > p.ld_gout ? p.ld_in : p.ld_gout) : (p.ld_out > p.ld_gout ? p.ld_out : p.ld_gout);
+  return (double)p.Tmax * (double)ld * 8.0 < 2147483647.0;
+}
+
 void set_error(const char *fmt, ...);
 // launches per kernel family since the library was loaded (mlpg_hip_launch_count: a test aid)
 enum { kCountGeneric = 0, kCountWave, kCountStrip, kCountStripMulti, kCountConst, kCountFused, kCountChunk, kCountKinds };

@@ -10,12 +10,13 @@ using namespace chunk;
 bool chunk_supported(const Problem &p, const WinSet &ws) {
   if (ws.nw < 1 || ws.nw > kMaxNw || ws.mw < 1 || ws.mw > 2) return false;
   if (p.pitch && p.pitch != p.sd) return false;
-  return true;
+  return rows_fit_buffer(p);
 }
 
 // the natural-order kernel is the only other one that takes extents of 2; a handful of systems are not worth three launches
 bool chunk_preferred(const Problem &p, const WinSet &ws, bool backward) {
-  return !backward && chunk_supported(p, ws) && ws.mw == 2 && (long)p.B * p.sd >= 64 && p.Tmax >= 64;
+  (void)backward;
+  return chunk_supported(p, ws) && ws.mw == 2 && (long)p.B * p.sd >= 64 && p.Tmax >= 64;
 }
 
 namespace {
@@ -42,7 +43,7 @@ void fill_args(const Problem &p, const WinSet &ws, Args *a) {
 // sequential latency is paid per slab); pass 2 of one part of the batch on a side stream under pass 1 / pass 3 of the others
 // (2 / 3 / 4 parts: 0.70 / 0.75 / 0.76 ms against 0.54: the chunk kernels book the whole register file, the side stream's
 // wavefronts wait for them to drain).
-template <typename TIN, typename TOUT, int Q>
+template <typename TIN, typename TOUT, int Q, bool BWD>
 int launch_q(hipStream_t st, const Problem &p, const WinSet &ws, int device) {
   using G = Geo<Q>;
   Args a;
@@ -68,35 +69,36 @@ int launch_q(hipStream_t st, const Problem &p, const WinSet &ws, int device) {
   const dim3 grid((unsigned)((items + kW - 1) / kW)), block(kW * 64);
   note_launch(kCountChunk);
   switch (p.var_mode) {
-    case MLPG_HIP_VAR_FRAME: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_FRAME, Q, false>), grid, block, lds1, st, p, a); break;
-    case MLPG_HIP_VAR_GLOBAL: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_GLOBAL, Q, false>), grid, block, lds1, st, p, a); break;
-    default: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_UNIT, Q, false>), grid, block, lds1, st, p, a);
+    case MLPG_HIP_VAR_FRAME: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_FRAME, Q, false, BWD>), grid, block, lds1, st, p, a); break;
+    case MLPG_HIP_VAR_GLOBAL: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_GLOBAL, Q, false, BWD>), grid, block, lds1, st, p, a); break;
+    default: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_UNIT, Q, false, BWD>), grid, block, lds1, st, p, a);
   }
   hipLaunchKernelGGL((reduce_elim_kernel<Q>), dim3((unsigned)(2 * a.nsg)), dim3(64), 0, st, p, a);
   hipLaunchKernelGGL((reduce_subst_kernel<Q>), dim3((unsigned)(2 * a.nsg)), dim3(64), 0, st, p, a);
   switch (p.var_mode) {
-    case MLPG_HIP_VAR_FRAME: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_FRAME, Q, true>), grid, block, lds3, st, p, a); break;
-    case MLPG_HIP_VAR_GLOBAL: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_GLOBAL, Q, true>), grid, block, lds3, st, p, a); break;
-    default: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_UNIT, Q, true>), grid, block, lds3, st, p, a);
+    case MLPG_HIP_VAR_FRAME: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_FRAME, Q, true, BWD>), grid, block, lds3, st, p, a); break;
+    case MLPG_HIP_VAR_GLOBAL: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_GLOBAL, Q, true, BWD>), grid, block, lds3, st, p, a); break;
+    default: hipLaunchKernelGGL((chunk_kernel<TIN, TOUT, MLPG_HIP_VAR_UNIT, Q, true, BWD>), grid, block, lds3, st, p, a);
   }
-  hipLaunchKernelGGL((verdict_kernel<TIN, TOUT, Q>), dim3((unsigned)(((long)p.B * p.sd + 255) / 256)), dim3(256), 0, st, p, ws, a);
+  hipLaunchKernelGGL((verdict_kernel<TIN, TOUT, Q, BWD>), dim3((unsigned)(((long)p.B * p.sd + 255) / 256)), dim3(256), 0, st, p, ws, a);
   MLPG_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 template <typename TIN, typename TOUT>
-int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, int device) {
-  return ws.mw == 2 ? launch_q<TIN, TOUT, 4>(st, p, ws, device) : launch_q<TIN, TOUT, 2>(st, p, ws, device);
+int launch_t(hipStream_t st, bool backward, const Problem &p, const WinSet &ws, int device) {
+  if (backward) return ws.mw == 2 ? launch_q<TIN, TOUT, 4, true>(st, p, ws, device) : launch_q<TIN, TOUT, 2, true>(st, p, ws, device);
+  return ws.mw == 2 ? launch_q<TIN, TOUT, 4, false>(st, p, ws, device) : launch_q<TIN, TOUT, 2, false>(st, p, ws, device);
 }
 
 }  // namespace
 
 int launch_chunk(hipStream_t st, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &ws, int device) {
-  if (backward || dtype != out_dtype || !chunk_supported(p, ws)) {
-    set_error("MLPG_HIP_ALGO_CHUNK: forward pass, input dtype = output dtype, 1-4 windows of extent 1 or 2");
+  if (dtype != out_dtype || !chunk_supported(p, ws)) {
+    set_error("MLPG_HIP_ALGO_CHUNK: input dtype = output dtype, 1-3 windows of extent 1 or 2");
     return MLPG_HIP_EINVAL;
   }
-  return dtype == MLPG_HIP_F32 ? launch_t<float, float>(st, p, ws, device) : launch_t<double, double>(st, p, ws, device);
+  return dtype == MLPG_HIP_F32 ? launch_t<float, float>(st, backward, p, ws, device) : launch_t<double, double>(st, backward, p, ws, device);
 }
 
 }  // namespace mlpg

@@ -98,7 +98,11 @@ __device__ __forceinline__ double tau_of<float>(float v) { return recip_in_dtype
 template <>
 __device__ __forceinline__ double tau_of<double>(double v) { return fast_rcp(v); }
 
-template <typename TIN, typename TOUT, int VM, int Q, bool P3>
+// BWD (paramgen/_mlpg.py:202-281, mlpg_grad): the same matrix, the right-hand side is grad_out, and pass 3 ends with
+// grad[t, w * sd + d] = tau_w[t] * sum_k c_w[l + k] z[t + k].  A row needs z up to EXT frames to its right, so a chunk writes the
+// gradient rows f0 - EXT .. f0 + C - EXT - 1 (the previous separator's solution is at hand); the utterance's last chunk also writes
+// its own last EXT rows.  The precisions are read again there (they were in the cache a few microseconds ago).
+template <typename TIN, typename TOUT, int VM, int Q, bool P3, bool BWD = false>
 __global__ __launch_bounds__(kW * 64, 2) void chunk_kernel(const Problem p, const Args a) {
   using G = Geo<Q>;
   constexpr int EXT = G::EXT, I = G::I, C = G::C, NLDS = P3 ? G::NLDS : 0, NF = C + 2 * EXT;
@@ -120,14 +124,19 @@ __global__ __launch_bounds__(kW * 64, 2) void chunk_kernel(const Problem p, cons
   const int f0 = c * C;
   const __amdgpu_buffer_rsrc_t ors = make_rsrc((TOUT *)p.out + (size_t)b * Tmax * p.ld_out + d0);
   const unsigned ooff = (unsigned)(d - d0) * (unsigned)sizeof(TOUT), ldo_bytes = (unsigned)p.ld_out * (unsigned)sizeof(TOUT);
+  const unsigned owin_bytes = (unsigned)sd * (unsigned)sizeof(TOUT);
   if (f0 >= T) {  // nothing of the utterance in this chunk
     if (P3 && lane_ok)
-      for (int r = 0; r < C && f0 + r < Tmax; ++r) st_buf(ors, (unsigned)(f0 + r) * ldo_bytes, ooff, (TOUT)0);
+      for (int r = 0; r < C && f0 + r < Tmax; ++r)
+        for (int w = 0; w < (BWD ? a.nw : 1); ++w) st_buf(ors, (unsigned)(f0 + r) * ldo_bytes + (unsigned)w * owin_bytes, ooff, (TOUT)0);
     return;
   }
-  const __amdgpu_buffer_rsrc_t mrs = make_rsrc((const TIN *)p.mean + (size_t)b * Tmax * p.ld_in + d0);
+  // forward: the means (window-major columns, stride ld_in); backward: grad_out (one column per dim, stride ld_gout)
+  const __amdgpu_buffer_rsrc_t mrs = make_rsrc(BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * p.ld_gout + d0
+                                                   : (const TIN *)p.mean + (size_t)b * Tmax * p.ld_in + d0);
+  const unsigned ldg_bytes = (unsigned)p.ld_gout * (unsigned)sizeof(TIN);
   const __amdgpu_buffer_rsrc_t vrs = make_rsrc(VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)b * Tmax * p.ld_in + d0
-                                                                      : (VM == MLPG_HIP_VAR_GLOBAL ? (const TIN *)p.var + d0 : (const TIN *)p.mean));
+                                                                      : (VM == MLPG_HIP_VAR_GLOBAL ? (const TIN *)p.var + d0 : (const TIN *)p.out));
   const unsigned loff = (unsigned)(d - d0) * (unsigned)sizeof(TIN);
   const unsigned ld_bytes = (unsigned)p.ld_in * (unsigned)sizeof(TIN), win_bytes = (unsigned)sd * (unsigned)sizeof(TIN);
   const __amdgpu_buffer_rsrc_t rrs = make_rsrc(a.rec + ((size_t)g * a.K + c) * G::kRec * 64);  // this chunk's record
@@ -200,7 +209,8 @@ __global__ __launch_bounds__(kW * 64, 2) void chunk_kernel(const Problem p, cons
       rm[s][w] = (TIN)0;
       if (fl && (FAST || w < nw)) {
         if (VM == MLPG_HIP_VAR_FRAME) rv[s][w] = ld_buf<TIN>(vrs, (unsigned)t * ld_bytes + (unsigned)w * win_bytes, loff);
-        rm[s][w] = ld_buf<TIN>(mrs, (unsigned)t * ld_bytes + (unsigned)w * win_bytes, loff);
+        if (!BWD) rm[s][w] = ld_buf<TIN>(mrs, (unsigned)t * ld_bytes + (unsigned)w * win_bytes, loff);
+        else if (w == 0) rm[s][0] = ld_buf<TIN>(mrs, (unsigned)t * ldg_bytes, loff);
       }
     }
   };
@@ -212,8 +222,9 @@ __global__ __launch_bounds__(kW * 64, 2) void chunk_kernel(const Problem p, cons
     // ---- frame t = f0 + s - EXT spreads its precisions over rows t - EXT .. t + EXT ----
     const int t = f0 + s - EXT;
     const bool fl = FAST || (t >= 0 && t < T);
+    if (BWD && s - EXT >= 0 && s - EXT < C) accb[s - EXT] = fl ? (double)rm[s][0] : 0.0;  // backward: row r's right-hand side is grad_out[f0 + r]
     if (s < C) {  // the row this frame is the first to touch
-      accb[s] = 0.0;
+      if (!BWD) accb[s] = 0.0;
 #pragma unroll
       for (int k = 0; k <= Q; ++k) acc[s][k] = 0.0;
     }
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(kW * 64, 2) void chunk_kernel(const Problem p, cons
           if (r >= 0 && r < C) {
             const double t0 = tau * a.cpad[w][EXT];
             acc[r][0] = __builtin_fma(t0, a.cpad[w][EXT], acc[r][0]);
-            accb[r] = __builtin_fma(t0, mu, accb[r]);
+            if (!BWD) accb[r] = __builtin_fma(t0, mu, accb[r]);
           }
         } else {
           double ta[2 * EXT + 1];
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(kW * 64, 2) void chunk_kernel(const Problem p, cons
           for (int j1 = -EXT; j1 <= EXT; ++j1) {
             const int r = s - EXT + j1;  // local row
             if (r < 0 || r >= C) continue;
-            accb[r] = __builtin_fma(ta[j1 + EXT], mu, accb[r]);
+            if (!BWD) accb[r] = __builtin_fma(ta[j1 + EXT], mu, accb[r]);
 #pragma unroll
             for (int j2 = -EXT; j2 <= j1; ++j2) {
               const int r2 = s - EXT + j2;  // local column
@@ -382,11 +393,45 @@ __global__ __launch_bounds__(kW * 64, 2) void chunk_kernel(const Problem p, cons
     }
     x[r] = v;
   }
-  if (lane_ok) {
+  if (!BWD) {
+    if (lane_ok) {
 #pragma unroll
-    for (int r = 0; r < C; ++r) {
-      const int t = f0 + r;
-      if (t < Tmax) st_buf(ors, (unsigned)t * ldo_bytes, ooff, t < T ? (TOUT)x[r] : (TOUT)0);
+      for (int r = 0; r < C; ++r) {
+        const int t = f0 + r;
+        if (t < Tmax) st_buf(ors, (unsigned)t * ldo_bytes, ooff, t < T ? (TOUT)x[r] : (TOUT)0);
+      }
+    }
+    return;
+  }
+  // ---- backward epilogue: grad[t, w] = tau_w[t] * sum_k c_w[l + k] z[t + k] for the rows this chunk is responsible for ----
+  // z at local index i (frame f0 + i), i in [-Q, C + EXT): the previous separator, this chunk, nothing beyond the utterance
+  const bool lastc = f0 + C >= T;  // the utterance ends in this chunk: it writes its last EXT rows itself
+  auto z_at = [&](const int i) __attribute__((always_inline)) -> double {
+    if (i < 0) return i >= -Q ? xl[Q + i] : 0.0;
+    if (i < C) return (f0 + i < T) ? x[i] : 0.0;
+    return 0.0;  // (only read by the last chunk's own rows: frames behind the end)
+  };
+#pragma unroll
+  for (int i = -EXT; i < C; ++i) {
+    const int t = f0 + i;
+    const bool mine = i < C - EXT || lastc;
+    if (t < 0 || t >= Tmax || !mine) continue;
+    const bool fl = t < T;
+#pragma unroll
+    for (int w = 0; w < kMaxNw; ++w) {
+      if (w >= nw) continue;
+      double gval = 0.0;
+      const bool lv = fl && (w == 0 || (mw != 0 && t >= mw && t < T - mw));
+      if (lv) {
+        double tau = 1.0;
+        if (VM == MLPG_HIP_VAR_FRAME) tau = tau_of<TIN>(ld_buf<TIN>(vrs, (unsigned)t * ld_bytes + (unsigned)w * win_bytes, loff));
+        else if (VM == MLPG_HIP_VAR_GLOBAL) tau = tau_g[w];
+        double acc_w = 0.0;
+#pragma unroll
+        for (int j = -EXT; j <= EXT; ++j) acc_w = __builtin_fma(a.cpad[w][j + EXT], z_at(i + j), acc_w);
+        gval = tau * acc_w;
+      }
+      if (lane_ok) st_buf(ors, (unsigned)t * ldo_bytes + (unsigned)w * owin_bytes, ooff, (TOUT)gval);
     }
   }
 }
@@ -695,7 +740,7 @@ __global__ __launch_bounds__(64) void reduce_subst_kernel(const Problem p, const
 
 // One thread per system, after pass 3: marked systems get the reference's verdict (natural-order first failing pivot;
 // -2 if that scan finds none: the blocked elimination broke down on a numerically singular system) and a zero column.
-template <typename TIN, typename TOUT, int Q>
+template <typename TIN, typename TOUT, int Q, bool BWD = false>
 __global__ __launch_bounds__(256) void verdict_kernel(const Problem p, const WinSet ws, const Args a) {
   const long s = (long)blockIdx.x * 256 + threadIdx.x;
   if (s >= (long)p.B * p.sd) return;
@@ -707,11 +752,12 @@ __global__ __launch_bounds__(256) void verdict_kernel(const Problem p, const Win
     *flag = 0;  // (the next launch on this stream finds the marks cleared)
     int T = p.lengths ? p.lengths[b] : p.Tmax;
     T = T < 0 ? 0 : (T > p.Tmax ? p.Tmax : T);
-    const SysView<TIN, false> view = make_view<TIN, false>(p, ws, b, d, T);
-    status = first_bad_pivot<Q, TIN, false>(view, ws);
+    const SysView<TIN, BWD> view = make_view<TIN, BWD>(p, ws, b, d, T);
+    status = first_bad_pivot<Q, TIN, BWD>(view, ws);
     if (status == 0) status = -2;
     TOUT *out_b = (TOUT *)p.out + (size_t)b * p.Tmax * p.ld_out + d;
-    for (int t = 0; t < p.Tmax; ++t) out_b[(size_t)t * p.ld_out] = (TOUT)0;
+    for (int t = 0; t < p.Tmax; ++t)
+      for (int w = 0; w < (BWD ? ws.nw : 1); ++w) out_b[(size_t)t * p.ld_out + (size_t)w * p.sd] = (TOUT)0;
   }
   if (p.status) p.status[(size_t)b * p.ld_status + d] = status;
 }

@@ -35,7 +35,7 @@ bool const_supported(const Problem &p, const WinSet &ws) {
     if (ws.l[w] > 1 || ws.u[w] > 1) return false;
   if (p.pitch && p.pitch != p.sd) return false;
   if (p.Tmax < 1 || p.sd < 1 || p.B < 1) return false;
-  return true;
+  return rows_fit_buffer(p);
 }
 
 // AUTO (measured on MI355X, tools/dbg/const_time.py): one workgroup walks one (utterance, dim group) sequence, so the

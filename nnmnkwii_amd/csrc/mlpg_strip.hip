@@ -28,7 +28,7 @@ bool strip_supported(const Problem &p, const WinSet &ws) {
   if (p.Tmax < 1 || (p.Tmax + kStripFrames - 1) / kStripFrames > kMaxStrips) return false;
   for (int w = 0; w < ws.nw; ++w)
     if (ws.l[w] > 1 || ws.u[w] > 1) return false;
-  return true;
+  return rows_fit_buffer(p);
 }
 
 // AUTO policy (measured on MI355X with tools/algo_sweep.py, profiles/r02_algo_sweep.txt): the strip kernel puts

@@ -153,3 +153,61 @@ def test_chunk_through_forward_streams_column_slices():
         assert rc == 0
         assert rel_err(out[:, :, o0:o0 + s].reshape(-1, s), yo.reshape(-1, s)) <= TOL64
         o0 += s
+
+
+@pytest.mark.parametrize("wname", ["wide3", "std3", "asym2"])
+@pytest.mark.parametrize("T", [1, 2, 3, 5, 17, 19, 20, 21, 22, 23, 40, 41, 42, 61, 100, 257, 1000])
+def test_chunk_backward_all_lengths(wname, T):
+    """mlpg_hip_backward on the chunked kernel (the gradient rows of a chunk are written by the chunk to their right, the utterance's
+    last chunk writes its own): against the natural-order kernel (== the reference's mlpg_grad: tests/test_parity_r2_gpu.py) for
+    every chunk count around the boundaries, ragged lengths, two dim groups, the three variance modes, float64 and float32; small T
+    also against the oracle's dense mlpg_grad."""
+    import torch
+    from nnmnkwii_amd import _hip
+    windows = WINDOW_SETS[wname]
+    nw = len(windows)
+    B, sd = 4, 70 if T <= 300 else 9
+    rng = np.random.RandomState(T + 3 * nw)
+    V_ = rng.rand(B, T, nw * sd) + 0.1
+    go = rng.randn(B, T, sd)
+    lengths = np.array([T, max(1, T - 1), max(1, T // 2), max(1, T - 3)], dtype=np.int32)
+    L = torch.from_numpy(lengths).cuda()
+    for dt, tol in ((np.float64, 1e-10), (np.float32, 3e-6)):
+        g = torch.from_numpy(go.astype(dt)).cuda()
+        for var in (V_, V_[0, 0].copy(), None):
+            v = None if var is None else torch.from_numpy(var.astype(dt)).cuda()
+            gc, st = _hip.backward(v, g, windows, nw * sd, L, out_dtype=g.dtype, algo=_hip.ALGO_CHUNK)
+            gg, _ = _hip.backward(v, g, windows, nw * sd, L, out_dtype=g.dtype, algo=_hip.ALGO_GENERIC)
+            assert int(st.abs().max()) == 0
+            scale = float(gg.abs().max()) + 1e-300
+            assert float((gc - gg).abs().max()) <= tol * scale, (wname, T, dt.__name__, None if var is None else var.ndim)
+            for b in range(B):
+                assert not bool(gc[b, int(lengths[b]):].any())
+    if T <= 41:
+        gc, _ = _hip.backward(torch.from_numpy(V_).cuda(), torch.from_numpy(go).cuda(), windows, nw * sd, L, out_dtype=torch.float64,
+                              algo=_hip.ALGO_CHUNK)
+        gc = gc.cpu().numpy()
+        for b in range(B):
+            Tb = int(lengths[b])
+            gr = O.mlpg_grad(np.zeros((Tb, nw * sd)), V_[b, :Tb], windows, go[b, :Tb])      # float32, as the reference
+            assert np.abs(gc[b, :Tb] - gr).max() <= 5e-7 * max(1.0, np.abs(gr).max()), (wname, T, b)
+
+
+def test_chunk_backward_config2_shape_is_the_auto_choice_for_5_tap_windows():
+    import torch
+    from nnmnkwii_amd import _hip
+    windows = WINDOW_SETS["wide3"]
+    B, T, sd = 64, 1000, 60
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    v = torch.rand(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=gen) + 0.1
+    g = torch.randn(B, T, sd, dtype=torch.float64, device="cuda", generator=gen)
+    n0 = _hip.lib().mlpg_hip_launch_count(6)
+    ga, st = _hip.backward(v, g, windows, 3 * sd, out_dtype=torch.float64)
+    assert _hip.lib().mlpg_hip_launch_count(6) == n0 + 1 and int(st.abs().max()) == 0
+    gg, _ = _hip.backward(v, g, windows, 3 * sd, out_dtype=torch.float64, algo=_hip.ALGO_GENERIC)
+    assert float((ga - gg).abs().max()) <= 1e-10 * float(gg.abs().max())
+    # adjointness with the forward pass of the same kernel: <forward(m), g> == <m, backward(g)>
+    m = torch.randn(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=gen)
+    y, _ = _hip.forward(m, v, windows, algo=_hip.ALGO_CHUNK)
+    lhs, rhs = float((y * g).sum()), float((m * ga).sum())
+    assert abs(lhs - rhs) <= 1e-9 * abs(lhs)

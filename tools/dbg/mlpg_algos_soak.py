@@ -69,7 +69,7 @@ def soak(budget=40.0, seed=99):
             g = torch.from_numpy(rng.randn(B, T, sd).astype(dt)).cuda()
             gref, _ = _hip.backward(vd, g, win, nw * sd, lengths=Ld, out_dtype=md.dtype, algo=1)
             gs = max(1e-30, float(gref.abs().max()))
-            for algo in (2, 3, 5):
+            for algo in (2, 3, 5, 6):
                 try:
                     go, status = _hip.backward(vd, g, win, nw * sd, lengths=Ld, out_dtype=md.dtype, algo=algo)
                 except _hip.HipExtensionError:
