@@ -168,6 +168,9 @@ int mlpg_hip_fastdtw_host(int device, int dtype, const void *X_h, const void *Y_
  * behaviour is the single-device call's, results and verdicts land at the chunk's own offset of the caller's arrays.
  * A device may be listed up to 4 times (each occurrence has its own staging buffers and streams).  On an error every
  * stream that was used is drained before the call returns.  mlpg_hip_forward_host(d, ...) == _multi(&d, 1, ...).
+ * Environment (read once): MLPG_HIP_HOST_CHUNK_MB (input bytes per chunk, default 64), MLPG_HIP_HOST_COPY_THREADS (threads of the
+ * staging copy, default 16, at most 64), MLPG_HIP_HOST_TRACE=1 (one line per call on stderr: where the calling thread and the
+ * collector thread spent their time).
  */
 int mlpg_hip_forward_host_multi(const int32_t *devices, int num_devices, int dtype, int algo, const void *mean_h,
                                 const void *var_h, int var_mode, const int32_t *lengths_h, int B, int Tmax, int D,
