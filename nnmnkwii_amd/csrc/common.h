@@ -92,6 +92,8 @@ int launch_unit_mse(hipStream_t s, int dtype, const Problem &p, const WinSet &w,
 bool const_supported(const Problem &p, const WinSet &w);
 // true once per scratch allocation (device, stream): the constant-coefficient kernel's table holds nothing yet
 bool const_scratch_fresh(int device, hipStream_t stream, unsigned long long gen);
+// unit variances: true if this (device, stream) last built its table from the same key on the same scratch allocation
+bool const_unit_table_cached(int device, hipStream_t stream, unsigned long long gen, bool fresh, const double *key, int n);
 bool const_preferred(const Problem &p, const WinSet &w);
 int launch_const(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
 bool chunk_supported(const Problem &p, const WinSet &w);

@@ -1,6 +1,8 @@
 // Constant-coefficient MLPG kernels (global / unit variances): dispatch.  The kernels live in mlpg_const_impl.h and
 // are instantiated per dtype in mlpg_const_{fwd,bwd}_{f32,f64}.hip so that they compile in parallel.
+#include <algorithm>
 #include <map>
+#include <vector>
 #include <mutex>
 #include <utility>
 #include "common.h"
@@ -23,6 +25,26 @@ bool const_scratch_fresh(int device, hipStream_t stream, unsigned long long gen)
   const bool fresh = capturing || g != gen;
   g = capturing ? 0ull : gen;
   return fresh;
+}
+
+bool const_unit_table_cached(int device, hipStream_t stream, unsigned long long gen, bool fresh, const double *key, int n) {
+  struct Entry {
+    unsigned long long gen = 0;
+    std::vector<double> key;
+  };
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Entry> seen;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+  std::lock_guard<std::mutex> lk(mu);
+  Entry &e = seen[{device, stream}];
+  // (the table is shared with the global-variance launches of this stream: any of those in between rewrites it, and the
+  // device-side key would notice -- the host-side one cannot, so a global-variance launch forgets the entry, see below)
+  const bool same = !fresh && !capturing && e.gen == gen && (int)e.key.size() == n && std::equal(e.key.begin(), e.key.end(), key);
+  e.gen = capturing ? 0ull : gen;
+  e.key.assign(key, key + n);
+  if (capturing) e.key.clear();
+  return same;
 }
 
 // Global (D,) or unit variances, windows of extent <= 1 with at least one dynamic window (mw == 1), two or three

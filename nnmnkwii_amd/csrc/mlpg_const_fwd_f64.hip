@@ -9,6 +9,6 @@ int launch_const_fwd_f64(hipStream_t st, int out_dtype, const Problem &p, const 
   if (!sc) return MLPG_HIP_ENOMEM;
   const bool fresh = const_scratch_fresh(device, st, gen);
   (void)out_dtype;
-  return cst::launch_t<double, double, false>(st, p, ws, sc, q, fresh);
+  return cst::launch_t<double, double, false>(st, p, ws, sc, q, fresh, device, gen);
 }
 }  // namespace mlpg

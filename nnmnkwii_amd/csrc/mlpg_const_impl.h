@@ -1114,7 +1114,8 @@ inline Plan make_plan(const Problem &p, int M, int W) {
 }
 
 template <typename TIN, typename TOUT, bool BWD, int VM, int NW, int M, int W, int WPS, int SLOTS>
-int launch_cfg(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, const Plan &q, bool fresh) {
+int launch_cfg(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, const Plan &q, bool fresh, int device,
+               unsigned long long gen) {
   Args a;
   a.key = (double *)((char *)scratch_base + q.key_off);
   a.tab = (double *)((char *)scratch_base + q.tab_off);
@@ -1134,7 +1135,20 @@ int launch_cfg(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch
   auto kern = stream_kernel<TIN, TOUT, BWD, VM, NW, M, W, WPS, SLOTS>;
   int resident = 0;
   if (int rc = resident_grid((const void *)kern, W * 64, &resident)) return rc;
-  hipLaunchKernelGGL((setup_kernel<TIN, VM, NW>), dim3((unsigned)q.ndg), dim3(64), 0, st, p, a, M, W, fresh ? 1 : 0);
+  // Unit variances: the table depends on the windows and the shape only, which the HOST can compare -- the launch of
+  // setup_kernel (2.7 us when it only compares its key) is skipped when this (device, stream) ran the same thing last.
+  bool skip = false;
+  if (VM == MLPG_HIP_VAR_UNIT) {
+    double key[2 + 3 * kMaxWindows] = {};
+    key[0] = (double)((((((long long)a.tab_rows * 1024 + a.ndg) * 128 + a.dgw) * 64 + M) * 32 + W) * 8 + NW);
+    key[1] = (double)sizeof(TIN);
+    for (int w = 0; w < ws.nw && w < kMaxWindows; ++w)
+      for (int k = 0; k < 3; ++k) key[2 + 3 * w + k] = a.wc[w][k];
+    skip = const_unit_table_cached(device, st, gen, fresh, key, 2 + 3 * kMaxWindows);
+  } else {
+    (void)const_unit_table_cached(device, st, gen, true, nullptr, 0);  // this launch rewrites the stream's table: forget the unit entry
+  }
+  if (!skip) hipLaunchKernelGGL((setup_kernel<TIN, VM, NW>), dim3((unsigned)q.ndg), dim3(64), 0, st, p, a, M, W, fresh ? 1 : 0);
   MLPG_HIP_CHECK(hipGetLastError());
   const int grid = q.nsg < resident ? q.nsg : resident;
   note_launch(kCountConst);
@@ -1147,12 +1161,13 @@ int launch_cfg(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch
 // every chunk of a super-step can be parked (the one-step lag reaches 128 frames), the whole next chunk's frames are in
 // flight while this one is worked on
 template <typename TIN, typename TOUT, bool BWD>
-int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, const Plan &q, bool fresh) {
+int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, const Plan &q, bool fresh, int device,
+             unsigned long long gen) {
   auto go = [&](auto vm, auto nw) -> int {
     constexpr int VM = decltype(vm)::value, NW = decltype(nw)::value;
     // (measured on MI355X, tools/gpurun/r4_stream6.sh: 24- and 32-frame chunks are 1.4x and 2x slower -- their register
     // arrays no longer fit beside the ring)
-    return launch_cfg<TIN, TOUT, BWD, VM, NW, 16, 8, 2, 8>(st, p, ws, scratch_base, q, fresh);
+    return launch_cfg<TIN, TOUT, BWD, VM, NW, 16, 8, 2, 8>(st, p, ws, scratch_base, q, fresh, device, gen);
   };
   using G = std::integral_constant<int, MLPG_HIP_VAR_GLOBAL>;
   using U = std::integral_constant<int, MLPG_HIP_VAR_UNIT>;

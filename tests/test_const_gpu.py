@@ -163,3 +163,23 @@ def test_const_is_the_auto_choice_for_global_and_unit_variances():
     ya, _ = _fwd(M_[:8], vg, windows, None, algo=0)
     yw, _ = _fwd(M_[:8], vg, windows, None, algo=2)
     assert np.array_equal(ya, yw)
+
+
+def test_const_unit_table_is_reused_and_invalidated_correctly():
+    """Unit variances: the host skips the table launch when the stream ran the same windows and shape last.  Interleaved with
+    global-variance launches (which rewrite the stream's table), other windows and another length, every result still equals
+    the oracle."""
+    rng = np.random.RandomState(12)
+    B, sd = 200, 40
+    seq = [("std3", 150, None), ("std3", 150, None), ("std3", 150, "g"), ("std3", 150, None), ("asym2", 150, None),
+           ("std3", 150, None), ("std3", 97, None), ("std3", 150, None), ("std3", 150, "g"), ("std3", 150, "g"), ("std3", 150, None)]
+    for wname, T, mode in seq:
+        windows = WINDOW_SETS[wname]
+        nw = len(windows)
+        M_ = rng.randn(B, T, nw * sd)
+        var = (rng.rand(nw * sd) + 0.1) if mode == "g" else None
+        ys, sts = _fwd(M_, var, windows, None)
+        assert int(np.abs(sts).max()) == 0
+        sel = [0, 1, 77, 199]
+        yo, _, rc = O.mlpg_batch(M_[sel], np.ones(nw * sd) if var is None else var, windows)
+        assert rc == 0 and rel_err(ys[sel].reshape(-1, sd), yo.reshape(-1, sd)) <= TOL64, (wname, T, mode)

@@ -1,6 +1,7 @@
 """Random soak of the fastdtw kernel against the C oracle (oracle/dtw_oracle.c): batches of random size (both the
 512-thread single launch and the 256-thread two-launch form), random lengths 1..420, feature dims 1..30, radius 1..30,
-smooth tracks, white noise, integer-valued (tie-heavy) and step/ramp pairs.  Prints the number of pairs checked and the
+smooth tracks, white noise, integer-valued (tie-heavy) and step/ramp pairs, either tie rule; small batches also through the
+host-evaluated-cost route (a Python callable per window cell, DP on the GPU).  Prints the number of pairs checked and the
 first mismatch, if any.   usage: python tools/dbg/dtw_soak.py [seconds]"""
 import os
 import sys
@@ -44,12 +45,13 @@ def soak(budget=40.0, seed=20260926):
             Y[n, :len(y)] = y
         lx = torch.tensor([len(x) for x, _ in pairs], dtype=torch.int32, device="cuda")
         ly = torch.tensor([len(y) for _, y in pairs], dtype=torch.int32, device="cuda")
-        pi, pj, pl, cost = _hip.fastdtw_l2(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), lx, ly, radius)
+        tie = int(rng.randint(2))
+        pi, pj, pl, cost = _hip.fastdtw_l2(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), lx, ly, radius, tie_rule=tie)
         pi, pj, pl, cost = pi.cpu().numpy(), pj.cpu().numpy(), pl.cpu().numpy(), cost.cpu().numpy()
         step = max(1, N // 60)
         for n in range(0, N, step):
             x, y = pairs[n]
-            d, path = OD.fastdtw(x, y, radius)
+            d, path = OD.fastdtw(x, y, radius, tie=tie)
             ok = pl[n] == len(path) and np.array_equal(pi[n, :pl[n]], path[:, 0]) and np.array_equal(pj[n, :pl[n]], path[:, 1])
             # tie-heavy data: equal cost is what the reference itself guarantees; everything else bit for bit
             if not ok and kind == 2 and pl[n] > 0 and abs(cost[n] - d) <= 1e-12 * max(d, 1e-300):
@@ -58,6 +60,16 @@ def soak(budget=40.0, seed=20260926):
                 bad = (batches, n, N, D, radius, kind, len(x), len(y), int(pl[n]), len(path), float(cost[n]), float(d))
                 break
             checked += 1
+        if bad is None and N <= 40 and tmax <= 60:
+            # the same pairs with the local costs evaluated on the host by a callable
+            qi, qj, ql, qc = _hip.fastdtw_callable([p_[0] for p_ in pairs], [p_[1] for p_ in pairs], radius,
+                                                   lambda u, v: float(np.sqrt(((u - v) ** 2).sum())), tie)
+            for n in range(N):
+                k = int(pl[n])
+                same = ql[n] == k and np.array_equal(qi[n, :k], pi[n, :k]) and np.array_equal(qj[n, :k], pj[n, :k])
+                if not same and not (kind == 2 and abs(qc[n] - cost[n]) <= 1e-9 * max(cost[n], 1e-300)):
+                    bad = ("callable route", batches, n, N, D, radius, kind, tie, int(ql[n]), k, float(qc[n]), float(cost[n]))
+                    break
         batches += 1
     return batches, checked, bad
 
