@@ -64,6 +64,29 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel ships its own libamdhip64 / libhsa-runtime64 and loads them by path;
+    libmlpg_hip.so asks for "libamdhip64.so.7".  Loaded after torch, the library is given torch's copy (same SONAME) and all is
+    well; loaded BEFORE torch -- a program that starts with the numpy-only entry points -- it would bring in the system's runtime,
+    torch would then add its own, and with two runtimes in the process ``torch.cuda.is_available()`` turns False.  So, when torch is
+    installed but not imported yet, its runtime libraries are loaded first (no ``import torch``: that costs seconds and the
+    host-pointer entry points do not need it)."""
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 -- best effort: without it the system's runtime is used, as before
+        pass
+
+
 def lib():
     """Load libmlpg_hip.so (once). Raises HipExtensionError if it is not built."""
     global _lib
@@ -76,6 +99,7 @@ def lib():
             raise HipExtensionError(
                 "nnmnkwii_amd: %s is missing -- build it with `python nnmnkwii_amd/csrc/build.py` "
                 "(or __graft_entry__.build()); there is no CPU fallback" % SO_PATH)
+        _preload_torch_hip_runtime()
         try:
             L = ctypes.CDLL(SO_PATH)
         except OSError as e:  # pragma: no cover

@@ -4,6 +4,8 @@ and the host-side mirrors of the reference helpers behave like the reference."""
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -214,3 +216,20 @@ def test_host_chunk_plan_deals_round_robin_and_covers_the_batch():
         _hip.host_chunk_plan(10, 0, 1)
     assert _hip.device_list("all").size == 0 and _hip.device_list([1, 1, 0]).tolist() == [1, 1, 0]
     assert _hip.device_list(3).tolist() == [3] and _hip.device_list("cuda:2").tolist() == [2]
+
+
+def test_one_hip_runtime_whichever_is_loaded_first():
+    """Loading libmlpg_hip.so BEFORE torch must not bring a second HIP runtime into the process (the PyTorch-ROCm wheel ships its
+    own copy; with two of them torch.cuda.is_available() turns False): checked in a fresh interpreter, library first."""
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+from nnmnkwii_amd import _hip
+_hip.lib()
+import torch
+libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))
+print(len(libs), libs)
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert out.stdout.split()[0] == "1", out.stdout

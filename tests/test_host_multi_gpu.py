@@ -86,3 +86,34 @@ def test_device_list_errors():
         _hip.forward_host(M_, None, windows, device=[0] * 5)        # at most 4 occurrences of one device
     y, st = _hip.forward_host(M_, None, windows, device=[0])         # and the library is usable afterwards
     assert not y.any() and not st.any()
+
+
+def test_numpy_entry_points_first_then_torch_in_a_fresh_interpreter():
+    """A program that starts with the numpy-only entry points (libmlpg_hip.so loaded before torch) and later uses the tensor API:
+    one HIP runtime in the process, torch still sees the GPU, both calls give the oracle's result."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from nnmnkwii_amd import paramgen as G
+assert "torch" not in sys.modules
+W3 = [(0, 0, np.array([1.0])), (1, 1, np.array([-0.5, 0.0, 0.5])), (1, 1, np.array([1.0, -2.0, 1.0]))]
+rng = np.random.RandomState(0)
+M, V = rng.randn(3, 50, 6), rng.rand(3, 50, 6) + 0.1
+y = G.mlpg_batch(M, V, W3)                       # numpy in, numpy out: the host-pointer entry point
+assert "torch" not in sys.modules
+import torch
+assert torch.cuda.is_available()
+yt = G.mlpg_batch(torch.from_numpy(M).cuda(), torch.from_numpy(V).cuda(), W3).cpu().numpy()
+from oracle import mlpg as O
+yo, _, rc = O.mlpg_batch(M, V, W3)
+assert rc == 0 and np.abs(y - yo).max() < 1e-10 and np.abs(yt - yo).max() < 1e-10
+print("ok")
+""" % (root, os.path.join(root, "tests", "golden"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-300:], out.stderr[-800:])
