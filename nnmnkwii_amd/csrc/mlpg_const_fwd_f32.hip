@@ -2,7 +2,7 @@
 #include "mlpg_const_impl.h"
 namespace mlpg {
 int launch_const_fwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, int device, int shape) {
-  const cst::Plan q = cst::make_plan(p, 16, 8);
+  const cst::Plan q = cst::make_plan(p, 16, cst::kConstW);
   (void)shape;
   unsigned long long gen = 0;
   void *sc = scratch(device, st, 4, q.total, &gen);

@@ -1094,6 +1094,10 @@ inline int resident_grid(const void *kern, int threads, int *out) {
   return 0;
 }
 
+#ifndef MLPG_CONST_W
+#define MLPG_CONST_W 8  // wavefronts (chunks) per workgroup; 4: two workgroups per CU (experiment)
+#endif
+constexpr int kConstW = MLPG_CONST_W;
 struct Plan {
   int M, W, ndg, dgw, nsg, tab_rows;
   size_t key_off, tab_off, tabi_off, total;
@@ -1167,7 +1171,7 @@ int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_b
     constexpr int VM = decltype(vm)::value, NW = decltype(nw)::value;
     // (measured on MI355X, tools/gpurun/r4_stream6.sh: 24- and 32-frame chunks are 1.4x and 2x slower -- their register
     // arrays no longer fit beside the ring)
-    return launch_cfg<TIN, TOUT, BWD, VM, NW, 16, 8, 2, 8>(st, p, ws, scratch_base, q, fresh, device, gen);
+    return launch_cfg<TIN, TOUT, BWD, VM, NW, 16, kConstW, 2, kConstW>(st, p, ws, scratch_base, q, fresh, device, gen);
   };
   using G = std::integral_constant<int, MLPG_HIP_VAR_GLOBAL>;
   using U = std::integral_constant<int, MLPG_HIP_VAR_UNIT>;
