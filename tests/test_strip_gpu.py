@@ -443,3 +443,19 @@ def test_strip_whole_utterance_route_while_another_stream_holds_cus():
     for o, st in outs:
         assert int(st.abs().max().item()) == 0
         assert float(((o - ref).abs() / scale).max()) <= 1e-7
+
+
+def test_retired_pipe_algo_selects_the_strip_kernel():
+    """MLPG_HIP_ALGO_PIPE (= 4; the software-pipelined kernel of round 3, now under tools/experimental/pipe) is still accepted and
+    runs the strip kernel: same bits, one strip launch."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    g = torch.Generator(device="cuda").manual_seed(21)
+    m = torch.randn(16, 700, 180, dtype=torch.float64, device="cuda", generator=g)
+    v = torch.rand(16, 700, 180, dtype=torch.float64, device="cuda", generator=g) + 0.1
+    n0 = _hip.lib().mlpg_hip_launch_count(2)
+    a, _ = _hip.forward(m, v, STD3, algo=_hip.ALGO_PIPE)
+    assert _hip.lib().mlpg_hip_launch_count(2) == n0 + 1
+    b, _ = _hip.forward(m, v, STD3, algo=_hip.ALGO_STRIP)
+    assert torch.equal(a, b)
