@@ -2,7 +2,7 @@
 512-thread single launch and the 256-thread two-launch form), random lengths 1..420, feature dims 1..30, radius 1..30,
 smooth tracks, white noise, integer-valued (tie-heavy) and step/ramp pairs, either tie rule; small batches also through the
 host-evaluated-cost route (a Python callable per window cell, DP on the GPU).  Prints the number of pairs checked and the
-first mismatch, if any.   usage: python tools/dbg/dtw_soak.py [seconds]"""
+first mismatch, if any.   usage: python tools/dbg/dtw_soak.py [seconds [seed]]"""
 import os
 import sys
 import time
@@ -75,5 +75,5 @@ def soak(budget=40.0, seed=20260926):
 
 
 if __name__ == "__main__":
-    r = soak(float(sys.argv[1]) if len(sys.argv) > 1 else 40.0)
+    r = soak(float(sys.argv[1]) if len(sys.argv) > 1 else 40.0, int(sys.argv[2]) if len(sys.argv) > 2 else 20260926)
     print("batches", r[0], "pairs checked", r[1], "mismatch", r[2])

@@ -1,7 +1,7 @@
 """Random soak of every MLPG kernel (natural-order, wave-per-system, strip, constant-coefficient, chunked) against the C oracle (forward)
 and against each other (backward: the natural-order kernel is the reference, itself pinned by tests/): random batch sizes,
 lengths (ragged), static dims 1..130, the three variance modes, float32 / float64, window sets of extent <= 1 (all kernels) and
-the 5-tap set (natural-order and chunked kernels vs the oracle).   usage: python tools/dbg/mlpg_algos_soak.py [seconds]"""
+the 5-tap set (natural-order and chunked kernels vs the oracle).   usage: python tools/dbg/mlpg_algos_soak.py [seconds [seed]]"""
 import os
 import sys
 import time
@@ -83,5 +83,5 @@ def soak(budget=40.0, seed=99):
 
 
 if __name__ == "__main__":
-    r = soak(float(sys.argv[1]) if len(sys.argv) > 1 else 40.0)
+    r = soak(float(sys.argv[1]) if len(sys.argv) > 1 else 40.0, int(sys.argv[2]) if len(sys.argv) > 2 else 99)
     print("cases", r[0], "mismatch", r[1])
