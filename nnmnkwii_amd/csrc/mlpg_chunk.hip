@@ -64,7 +64,7 @@ int launch_q(hipStream_t st, const Problem &p, const WinSet &ws, int device) {
   a.bad = (int *)(sc + rec_b + fac_b + xs_b + mid_b);
   MLPG_HIP_CHECK(hipMemsetAsync(a.bad, 0, bad_b, st));  // the marks of non-positive pivots
   constexpr size_t lds3 = (size_t)kW * (G::NLDS ? G::NLDS : 0) * (Q + 1) * 64 * sizeof(double);
-  constexpr size_t lds1 = MLPG_CHUNK_US_LDS ? (size_t)kW * 8 * Q * 64 * sizeof(double) : 0;
+  constexpr size_t lds1 = 0;
   const long items = (long)a.nsg * a.K;
   const dim3 grid((unsigned)((items + kW - 1) / kW)), block(kW * 64);
   note_launch(kCountChunk);

@@ -106,7 +106,7 @@ template <typename TIN, typename TOUT, int VM, int Q, bool P3, bool BWD = false>
 __global__ __launch_bounds__(kW * 64, 2) void chunk_kernel(const Problem p, const Args a) {
   using G = Geo<Q>;
   constexpr int EXT = G::EXT, I = G::I, C = G::C, NLDS = P3 ? G::NLDS : 0, NF = C + 2 * EXT;
-  extern __shared__ double lds_rows[];  // pass 3: [kW][NLDS][Q + 1][64]; pass 1: [kW][8][Q][64] (the left-coupling columns)
+  extern __shared__ double lds_rows[];  // pass 3: [kW][NLDS][Q + 1][64]
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long item = (long)blockIdx.x * kW + wv;
@@ -160,29 +160,14 @@ __global__ __launch_bounds__(kW * 64, 2) void chunk_kernel(const Problem p, cons
   }
 
   // ---- the frames, requested PF ahead of their use ----
-#ifndef MLPG_CHUNK_PF1
-#define MLPG_CHUNK_PF1 4
-#endif
-#ifndef MLPG_CHUNK_PF3
-#define MLPG_CHUNK_PF3 4
-#endif
-  constexpr int PF = P3 ? MLPG_CHUNK_PF3 : MLPG_CHUNK_PF1;  // frames requested ahead of their use (12 registers each in float64)
+  constexpr int PF = 4;  // frames requested ahead of their use (12 registers each in float64; 2 ... 7: no difference, profiles/r04_notes.md section 9)
   TIN rv[NF][kMaxNw], rm[NF][kMaxNw];
   double acc[C][Q + 1], accb[C];  // rows of P and b under assembly: row r is open from frame slot s = r to s = r + 2 EXT
   double Lm[C][Q + 1];  // Lm[r][m]: multiplier of row r for column r - m (an interior pivot), else 0
   double dinv[C], ub[C];
   // pass 1: the left-coupling columns, forward-substituted
-#ifndef MLPG_CHUNK_US_LDS
-#define MLPG_CHUNK_US_LDS 0  // 1: the left-coupling columns in LDS (a ring of 8 rows) instead of registers
-#endif
-#if MLPG_CHUNK_US_LDS
-  // (indexed from the __shared__ array itself: through a plain pointer these become flat accesses with a 64-bit address each)
-  const int us_base = wv * 8 * Q * 64 + lane;
-  auto us_at = [&](const int r, const int q) __attribute__((always_inline)) -> double & { return lds_rows[us_base + ((r & 7) * Q + q) * 64]; };
-#else
-  double us_reg[C][Q];
+  double us_reg[C][Q];  // (in LDS instead -- a ring of 8 rows -- measured no faster once the sink problem below was understood)
   auto us_at = [&](const int r, const int q) __attribute__((always_inline)) -> double & { return us_reg[r][q]; };
-#endif
   double sll[G::NS], gl[Q];
 #pragma unroll
   for (int k = 0; k < G::NS; ++k) sll[k] = 0.0;

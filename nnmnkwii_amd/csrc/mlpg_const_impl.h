@@ -92,9 +92,6 @@ template <typename T>
 __device__ __forceinline__ double tau_of(T v) { return recip_in_dtype<T>(v); }  // 1/var in the input dtype (_mlpg.py:188)
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-#ifndef MLPG_CONST_ST_AUX
-#define MLPG_CONST_ST_AUX 0  // cache policy of the output stores (2: nt)
-#endif
 // ---- buffer loads / stores: wave-uniform descriptor, row offset in an SGPR, this lane's byte offset in one VGPR ----
 template <typename T>
 __device__ __forceinline__ T ld_row(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff);
@@ -122,10 +119,10 @@ __device__ __forceinline__ float ld_row<float>(__amdgpu_buffer_rsrc_t rs, unsign
 __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff, double v) {
   const unsigned long long u = (unsigned long long)__double_as_longlong(v);
   const u32x2 w = {(unsigned)u, (unsigned)(u >> 32)};
-  __builtin_amdgcn_raw_buffer_store_b64(w, rs, loff, soff, MLPG_CONST_ST_AUX);
+  __builtin_amdgcn_raw_buffer_store_b64(w, rs, loff, soff, 0);
 }
 __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, loff, soff, MLPG_CONST_ST_AUX);
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, loff, soff, 0);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
   // the base must be wave-uniform PROVABLY (a lane-tainted descriptor is wrapped in a waterfall loop per access)
@@ -502,25 +499,11 @@ struct Lds {
   double carry[2][3][64];  // by super-step parity: the forward state entering it (2), the row-below sum of the one before (1)
   double park[SLOTS][M][64];  // chunks that wait for the next super-step (the SLOTS lowest of a super-step)
   int bad[2];                 // lanes (systems) of the sequence that met a failing pivot
-  int sink[W][64];            // where the touch loads land (touch_lines); never read
 };
 #ifndef MLPG_CONST_RING
 #define MLPG_CONST_RING 6
 #endif
 constexpr int kRing = MLPG_CONST_RING;  // frames of loads in flight per wavefront
-
-#ifndef MLPG_CONST_TOUCH
-#define MLPG_CONST_TOUCH 0  // (measured: 0.146 -> 0.157 ms on config 2 with global variances -- the loads are not what the kernel waits for) request the rest of the next chunk's cache lines while the current super-step is worked on
-#endif
-// One dword per lane, fetched straight into LDS (no destination register, nothing ever waits for it): the lines it
-// names travel from HBM to the L2 while the wavefront computes, so that the ring's real loads -- 6 frames deep, all
-// the registers allow -- find them there.  Written as assembly on purpose: the compiler orders every LDS access
-// behind an LDS-DMA load it knows about (a full memory round trip in front of the next ds_read); one it does not
-// know about only makes the s_waitcnt vmcnt(n) it places for its own loads wait for a few more (older or as old)
-// operations, never for fewer.
-__device__ __forceinline__ void touch_lines(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dword %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(lds_addr) : "memory");
-}
 
 template <typename TIN, typename TOUT, bool BWD, int VM, int NW, int M, int W, int WPS, int SLOTS>
 __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet ws, Args a) {
@@ -580,22 +563,6 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
         make_rsrc(BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * p.ld_gout + d0 : (const TIN *)p.mean + (size_t)b * Tmax * p.ld_in + d0);
     const unsigned ld_bytes = (unsigned)(BWD ? p.ld_gout : p.ld_in) * (unsigned)sizeof(TIN);
     const unsigned win_bytes = (unsigned)p.sd * (unsigned)sizeof(TIN);
-    // touch_lines geometry: a frame's rows of this dim group span `span` bytes (window-major columns), lpf lines of
-    // 128 bytes cover them wherever they start; lane L names line L % lpf of frame L / lpf of a batch of fpi frames
-    const unsigned span = (unsigned)(NL - 1) * win_bytes + (unsigned)nd * (unsigned)sizeof(TIN);
-    const int lpf = (int)((span + 127u) / 128u) + 1, fpi = 64 / lpf;
-    const int t_fi = lane / lpf < fpi ? lane / lpf : 0;
-    const unsigned t_off = (unsigned)(lane % lpf) * 128u < span - 4u ? (unsigned)(lane % lpf) * 128u : span - 4u;
-    const unsigned sink_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) int *)lds.sink[wv]);
-    auto touch_frames = [&](const int t0, const int n) __attribute__((always_inline)) {  // frames t0 .. t0+n-1 (clamped into the utterance)
-      if (!MLPG_CONST_TOUCH) return;
-      for (int i = 0; i < n; i += fpi) {
-        int t = t0 + i + t_fi;
-        t = t > t0 + n - 1 ? t0 + n - 1 : t;
-        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
-        touch_lines(irs, (unsigned)t * ld_bytes + t_off, sink_addr);
-      }
-    };
 
     // this wavefront's first chunk: its frames are requested before anything else
     TIN ring[kRing][NL];
@@ -603,7 +570,6 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
       const int a0 = T - (NC - wv) * M;
 #pragma unroll
       for (int f = 0; f < kRing; ++f) ring_issue<TIN, BWD, NW, kRing>(ring, f, f, irs, loff, ld_bytes, win_bytes, a0);
-      touch_frames(a0 + kRing, M - kRing);
     }
     // the table's head
     const int i_s_v = a.tabi[dg * 128], ok_v = a.tabi[dg * 128 + 1];
@@ -736,7 +702,6 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
         if (j + W < NC) {
 #pragma unroll
           for (int f = 0; f < kRing; ++f) ring_issue<TIN, BWD, NW, kRing>(ring, f, f, irs, loff, ld_bytes, win_bytes, a0 + S);
-          touch_frames(a0 + S + kRing, M - kRing);
         }
         if (!BWD) {
           lds.halo[wv][0][lane] = up;
@@ -849,7 +814,6 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
       // (nobody is parked after the last super-step)
       redo = __syncthreads_or(redo);
     }
-#ifndef MLPG_CONST_NO_SLOW
     if (redo) {
       // ---- exact two-sweep path (slow decay): forward sweep, the scaled z parked in the output rows ...
       if (wv < NC) {
@@ -1027,7 +991,6 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
         __syncthreads();
       }
     }
-#endif
     CST_TICK(9);
     // ---- verdict: a failing pivot (the table's, above this utterance's tail, or the tail's own) gets the reference's
     // status -- the natural-order first failing pivot (linalg.pyx:79-82) -- and an all-zero column, like every other kernel
@@ -1094,10 +1057,7 @@ inline int resident_grid(const void *kern, int threads, int *out) {
   return 0;
 }
 
-#ifndef MLPG_CONST_W
-#define MLPG_CONST_W 8  // wavefronts (chunks) per workgroup; 4: two workgroups per CU (experiment)
-#endif
-constexpr int kConstW = MLPG_CONST_W;
+constexpr int kConstW = 8;  // wavefronts (chunks) per workgroup (4, two workgroups per CU: measured, no gain -- profiles/r04_notes.md section 1)
 struct Plan {
   int M, W, ndg, dgw, nsg, tab_rows;
   size_t key_off, tab_off, tabi_off, total;
