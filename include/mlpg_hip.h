@@ -66,11 +66,15 @@ extern "C" {
 #define MLPG_HIP_ALGO_CHUNK 6   /* window extents up to 2 (5-tap windows: P has half-bandwidth 4), forward and backward: chunks of 16 + 4 frames
                                    eliminated twice around a block-tridiagonal solve over their separators; no workgroup waits
                                    for another; lane-per-static-dim, any T */
+#define MLPG_HIP_ALGO_FIR 7     /* unit variances on float32 tensors (autograd.unit_variance_mlpg, autograd/_impl/mlpg.py:108-172: the
+                                   reference multiplies by a dense float32 R): P^-1 is Toeplitz away from the ends and decays by
+                                   about a bit per frame -- a 49-tap FIR filter plus 24 table rows per end, every 32-frame tile
+                                   independent; the decay is checked per window set, else MLPG_HIP_EINVAL (AUTO: another kernel) */
 
 int mlpg_hip_abi_version(void);
 const char *mlpg_hip_last_error(void);
 /* Test aid, not part of the reference's interface: launches per MLPG kernel family since the library was loaded --
- * 0 natural-order, 1 wave-per-system, 2 strip, 3 strip with several streams merged, 4 constant-coefficient, 5 fused, 6 chunked
+ * 0 natural-order, 1 wave-per-system, 2 strip, 3 strip with several streams merged, 4 constant-coefficient, 5 fused, 6 chunked, 7 FIR
  * unit-variance step; -1 for any other `kind`.  (Tests use it to assert WHICH kernel a call took.) */
 long long mlpg_hip_launch_count(int kind);
 int mlpg_hip_device_count(void);

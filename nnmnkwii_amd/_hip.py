@@ -15,7 +15,7 @@ import numpy as np
 F32, F64 = 0, 1
 ABI_VERSION = 11               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
-ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE, ALGO_STRIP, ALGO_PIPE, ALGO_CONST, ALGO_CHUNK = 0, 1, 2, 3, 4, 5, 6
+ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE, ALGO_STRIP, ALGO_PIPE, ALGO_CONST, ALGO_CHUNK, ALGO_FIR = 0, 1, 2, 3, 4, 5, 6, 7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NNMNKWII_AMD_SO selects another build of the same library (kernel experiments); default: the in-tree build

@@ -179,7 +179,7 @@ int check_common(int B, int Tmax, int D, int nw) {
 // ones, generic kernel for window extents > 1 or utterances longer than either supports.
 int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool backward, const Problem &p,
                    const WinSet &ws, int device) {
-  if (algo < MLPG_HIP_ALGO_AUTO || algo > MLPG_HIP_ALGO_CHUNK) {
+  if (algo < MLPG_HIP_ALGO_AUTO || algo > MLPG_HIP_ALGO_FIR) {
     set_error("unknown algo %d", algo);
     return MLPG_HIP_EINVAL;
   }
@@ -199,6 +199,18 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     set_error("MLPG_HIP_ALGO_CHUNK: input dtype = output dtype, 1-3 windows of extent 1 or 2 (%d windows, extent %d)", ws.nw, ws.mw);
     return MLPG_HIP_EINVAL;
   }
+  if (algo == MLPG_HIP_ALGO_FIR) {
+    if (!fir_shape_supported(p, ws, in_dtype, out_dtype)) {
+      set_error("MLPG_HIP_ALGO_FIR: unit variances, float32 in and out, no lengths, T >= 96, 1-3 windows of extent <= 2 (the first a single tap)");
+      return MLPG_HIP_EINVAL;
+    }
+    const int rc = launch_fir(st, backward, p, ws, device);
+    if (rc == kFirNotApplicable) {
+      set_error("MLPG_HIP_ALGO_FIR: the inverse of this window set does not decay to 2^-26 within 24 frames (or the stream is being captured before the tap table exists)");
+      return MLPG_HIP_EINVAL;
+    }
+    return rc;
+  }
   if (algo == MLPG_HIP_ALGO_PIPE) {
     // retired (tools/experimental/pipe): the strip scheme it pipelined, or the kernel AUTO would take
     algo = strip_supported(p, ws) ? MLPG_HIP_ALGO_STRIP : MLPG_HIP_ALGO_AUTO;
@@ -210,6 +222,10 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
       return MLPG_HIP_EINVAL;
     }
     algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
+  }
+  if (algo == MLPG_HIP_ALGO_AUTO && fir_shape_supported(p, ws, in_dtype, out_dtype)) {
+    const int rc = launch_fir(st, backward, p, ws, device);
+    if (rc != kFirNotApplicable) return rc;
   }
   if (algo == MLPG_HIP_ALGO_AUTO) {
     if (const_preferred(p, ws)) algo = MLPG_HIP_ALGO_CONST;

@@ -65,7 +65,7 @@ inline bool rows_fit_buffer(const Problem &p) {
 
 void set_error(const char *fmt, ...);
 // launches per kernel family since the library was loaded (mlpg_hip_launch_count: a test aid)
-enum { kCountGeneric = 0, kCountWave, kCountStrip, kCountStripMulti, kCountConst, kCountFused, kCountChunk, kCountKinds };
+enum { kCountGeneric = 0, kCountWave, kCountStrip, kCountStripMulti, kCountConst, kCountFused, kCountChunk, kCountFir, kCountKinds };
 void note_launch(int kind);
 // Grow-only scratch, cached per (device, stream, slot): slot 0 generic factor, 1 fastdtw pyramids,
 // 2 generic status, 3 strip records, 4 constant-coefficient kernel (factor table), 5 fastdtw from host costs (D rows, back-pointers), 6 chunked kernel (records, block factors, separator solutions, marks).  Returns nullptr (and sets the error) on failure.
@@ -99,6 +99,11 @@ int launch_const(hipStream_t s, int dtype, int out_dtype, bool backward, const P
 bool chunk_supported(const Problem &p, const WinSet &w);
 bool chunk_preferred(const Problem &p, const WinSet &w, bool backward);
 int launch_chunk(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
+// unit variances on float32 tensors as a FIR filter; launch_fir returns kFirNotApplicable when the window set's inverse does not decay
+// fast enough (or its tap table cannot be built now: stream capture)
+constexpr int kFirNotApplicable = -2000;
+bool fir_shape_supported(const Problem &p, const WinSet &w, int in_dtype, int out_dtype);
+int launch_fir(hipStream_t s, bool backward, const Problem &p, const WinSet &w, int device);
 int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,
                      int ncols, void *dst, long ld_dst);
 int launch_stream_copy(hipStream_t s, const void *src, void *dst, size_t nbytes);

@@ -1,0 +1,477 @@
+// Unit-variance MLPG on float32 tensors as a FIR filter (MLPG_HIP_ALGO_FIR): autograd.unit_variance_mlpg forward / backward,
+// BASELINE config 3.  Executable specification: tools/fir_model.py.
+//
+// With unit variances P = sum_w W~_w^T W_w is one matrix for every system of the launch (paramgen/_mlpg.py:297-373); the reference
+// multiplies by the dense float32 R = P^-1 [W~_w^T] (autograd/_impl/mlpg.py:108-172).  Away from an utterance's ends P is Toeplitz and
+// its inverse decays by about a bit per frame, so to 2^-26 of the largest tap
+//     y = P^-1 b,   b[i] = sum_w sum_t W_w[t, i] m_w[t] mu_w[t]
+// is a FIR filter of 2 H + 1 = 49 taps on b in the interior plus a table of E = 24 rows at either end (the matrix near the end does not
+// depend on T).  No recurrence, no chain: lane = static dim, wavefront = a tile of 32 frames, every tile independent -- what a launch of
+// 64 utterances needs to fill 256 CUs.  The table (1 + 2 E rows of 49 taps) comes from ONE exact solve of 49 one-hot right-hand sides on
+// a 160-frame system with the library's own kernels, once per (device, window set); the decay is CHECKED there, a window set that does
+// not decay to 2^-26 within 24 taps is refused and the other kernels take the call.
+// Backward (autograd/_impl/mlpg.py:145-172: R^T grad): z = P^-1 grad_out by the same table (P^-1 is symmetric), then
+// grad[t, w] = m_w[t] sum_k c_w[l + k] z[t + k].
+// Float32 in, float32 out, float32 arithmetic (the reference's is a float32 GEMM over 3 T terms; here 49 terms in four partial sums).
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace mlpg {
+
+int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool backward, const Problem &p, const WinSet &ws, int device);
+
+namespace fir {
+
+constexpr int kH = 24, kE = 24, kTaps = 2 * kH + 1, kRows = 1 + 2 * kE, kTT = 32, kEXT = 2, kTref = 160, kW = 4, kMaxNw = 3;
+
+struct Args {
+  const float *tap;  // [kRows][kTaps]: row 0 interior, 1..E rows t = 0..E-1, E+1..2E rows T-1 .. T-E with their taps in reverse order
+  int ndg, dgw, nsg, nt;  // dim groups per utterance, dims per group, (utterance, dim group) pairs, tiles per utterance
+  int nw, mw;
+  int narrow[kMaxNw];
+  float cpad[kMaxNw][2 * kEXT + 1];  // window coefficients, zero padded to [-2, 2]
+};
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
+  const unsigned long long u = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float ld_f32(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, loff, soff, 0));
+}
+__device__ __forceinline__ void st_f32(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, loff, soff, 0);
+}
+
+// fir_kernel: one wavefront = one tile of kTT frames of one (utterance, dim group), every row with the INTERIOR taps.
+// Written for a wavefront that is alone on its SIMD (64 utterances x 16 tiles = one wavefront per SIMD of the chip):
+//   - branch-free: a frame outside the utterance is read from the nearest frame inside and enters with coefficient 0 (the
+//     coefficients are scalars selected per frame); a row that is not this kernel's is stored to an offset the buffer drops;
+//   - the 252 loads of a forward tile are issued in batches, each a batch ahead of its use (left to itself the compiler keeps 4-6 in
+//     flight and the tile costs 84 round trips);
+//   - the taps sit in the lanes of one register and are read out one at a time (v_readlane): 49 scalars held live cost more scalar
+//     registers than there are, and the reloads from the kernel arguments that followed cost more than the arithmetic.
+template <bool BWD>
+__global__ __launch_bounds__(kW * 64, 2) void fir_kernel(const Problem p, const Args a) {
+  constexpr int H = kH, E = kE, TT = kTT, EXT = kEXT;
+  // FIR outputs of a tile: its own frames (forward); EXT more on either side (backward: W_w z needs the neighbours)
+  constexpr int NO = BWD ? TT + 2 * EXT : TT;
+  constexpr int NB = NO + 2 * H;                   // right-hand-side rows under the taps
+  constexpr int NF = BWD ? NB : NB + 2 * EXT;      // frames read (forward: b[i] needs mu of i - EXT .. i + EXT)
+  constexpr int EW = BWD ? E + EXT : E;            // rows at either end that fir_edge_kernel writes
+  constexpr int FB = 14;                           // frames per batch of loads
+  static_assert(NF % FB == 0, "batches");
+  constexpr unsigned kDrop = 0x80000000u;          // an offset behind the buffer's end: the store is dropped
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long item = (long)blockIdx.x * kW + wv;
+  if (item >= (long)a.nsg * a.nt) return;
+  const int g = (int)(item / a.nt), tile = (int)(item - (long)g * a.nt);
+  const int b = g / a.ndg, dg = g - b * a.ndg;
+  const int T = p.Tmax, sd = p.sd;
+  const int d0 = dg * a.dgw;
+  const int nd = sd - d0 < a.dgw ? sd - d0 : a.dgw;
+  const bool lane_ok = lane < nd;
+  const int d = d0 + (lane_ok ? lane : nd - 1);
+  const int t0 = tile * TT;
+  if (t0 + TT <= EW || t0 >= T - EW) return;  // every row of the tile belongs to fir_edge_kernel
+  const int nw = a.nw, mw = a.mw;
+  const __amdgpu_buffer_rsrc_t irs = make_rsrc(BWD ? (const float *)p.grad_out + (size_t)b * T * p.ld_gout + d0
+                                                   : (const float *)p.mean + (size_t)b * T * p.ld_in + d0);
+  const __amdgpu_buffer_rsrc_t ors = make_rsrc((float *)p.out + (size_t)b * T * p.ld_out + d0);
+  const unsigned loff = (unsigned)(d - d0) * 4u;
+  const unsigned soff_ok = lane_ok ? loff : kDrop;
+  const unsigned ldi_bytes = (unsigned)(BWD ? p.ld_gout : p.ld_in) * 4u, ldo_bytes = (unsigned)p.ld_out * 4u, win_bytes = (unsigned)sd * 4u;
+  const int f_b = t0 - (BWD ? EXT : 0) - H;        // frame of right-hand-side row 0
+  const int f_first = f_b - (BWD ? 0 : EXT);       // first frame read
+  const float tapv = a.tap[lane < kTaps ? lane : 0];  // the interior row, tap k in lane k
+  // window w applies to the frames lo[w] <= t < lo[w] + span[w] (one unsigned comparison per load / store)
+  int lo[kMaxNw];
+  unsigned span[kMaxNw];
+#pragma unroll
+  for (int w = 0; w < kMaxNw; ++w) {
+    lo[w] = w == 0 ? 0 : mw;
+    span[w] = w >= nw ? 0u : (w == 0 ? (unsigned)T : (mw != 0 && T > 2 * mw ? (unsigned)(T - 2 * mw) : 0u));
+  }
+  float cw[kMaxNw][2 * EXT + 1];
+#pragma unroll
+  for (int w = 0; w < kMaxNw; ++w)
+#pragma unroll
+    for (int k = 0; k <= 2 * EXT; ++k) cw[w][k] = a.cpad[w][k];
+  float bb[NB];  // the right-hand side under the taps: row ib <-> frame f_b + ib
+  float out[NO];
+
+  if (BWD) {
+#pragma unroll
+    for (int s = 0; s < NF; ++s) {
+      const int t = f_first + s;
+      const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+      bb[s] = ld_f32(irs, (unsigned)tc * ldi_bytes, (unsigned)t < (unsigned)T ? loff : kDrop);  // (a read behind the buffer's end returns 0)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+    float mu[2][FB][kMaxNw];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bb[i] = 0.0f;
+#pragma unroll
+    for (int q = -1; q < NF / FB; ++q) {
+      if (q + 1 < NF / FB) {  // the loads of batch q + 1
+        // (opaque: else the scalar offsets and masks of all 252 loads are computed at the top of the kernel and spill)
+        int fq = f_first + (q + 1) * FB;
+        asm volatile("" : "+s"(fq));
+#pragma unroll
+        for (int s = 0; s < FB; ++s) {
+          const int t = fq + s;
+          const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+#pragma unroll
+          for (int w = 0; w < kMaxNw; ++w) {
+            // the window's mask and the utterance's ends through the offset: a read behind the buffer's end returns 0
+            const bool lv = (unsigned)(t - lo[w]) < span[w];
+            mu[(q + 1) & 1][s][w] = ld_f32(irs, (unsigned)tc * ldi_bytes + (unsigned)(w < nw ? w : 0) * win_bytes, lv ? loff : kDrop);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (q >= 0) {  // frame t = f_first + s spreads c_w[l + k] mu_w[t] over b[t + k]
+#pragma unroll
+        for (int sl = 0; sl < FB; ++sl) {
+          const int s = q * FB + sl;
+#pragma unroll
+          for (int w = 0; w < kMaxNw; ++w) {
+            const float m = mu[q & 1][sl][w];
+#pragma unroll
+            for (int k = -EXT; k <= EXT; ++k) {
+              const int ib = s - EXT + k;
+              if (ib < 0 || ib >= NB) continue;
+              if (w == 0 && k != 0) continue;  // (window 0 is a single tap: fir_shape_supported)
+              bb[ib] = __builtin_fmaf(cw[w][k + EXT], m, bb[ib]);
+            }
+          }
+          // b is only read by the taps below, and the compiler knows it: left alone it sinks every one of these sums down there
+          // and keeps all the loaded values alive until then.  An opaque use pins the row this frame completes.
+          if (s - 2 * EXT >= 0 && s - 2 * EXT < NB) asm volatile("" : "+v"(bb[s - 2 * EXT]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < NO; ++r) out[r] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kTaps; ++k) {
+    const float tk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tapv), k));
+#pragma unroll
+    for (int r = 0; r < NO; ++r) out[r] = __builtin_fmaf(tk, bb[r + k], out[r]);
+  }
+
+  // (opaque, and behind the first output: else the offsets and masks of every store are computed at the top of the kernel and spill)
+  int t0e = t0;
+  asm volatile("" : "+s"(t0e), "+v"(out[0]));
+  if (!BWD) {
+#pragma unroll
+    for (int r = 0; r < TT; ++r) {
+      const int t = t0e + r;
+      st_f32(ors, (unsigned)(t < T ? t : 0) * ldo_bytes, (unsigned)(t - EW) < (unsigned)(T - 2 * EW) ? soff_ok : kDrop, out[r]);
+      if (r % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // (else every offset is computed up front and the scalars spill)
+    }
+  } else {
+    // grad[t, w] = m_w[t] sum_k c_w[l + k] z[t + k];  z of frame t0 + r + k is out[r + EXT + k]
+#pragma unroll
+    for (int r = 0; r < TT; ++r) {
+      const int t = t0e + r;
+      const bool mine = (unsigned)(t - EW) < (unsigned)(T - 2 * EW);
+#pragma unroll
+      for (int w = 0; w < kMaxNw; ++w) {
+        const bool lv = (unsigned)(t - lo[w]) < span[w];
+        float gsum = 0.0f;
+#pragma unroll
+        for (int k = -EXT; k <= EXT; ++k) {
+          if (w == 0 && k != 0) continue;
+          gsum = __builtin_fmaf(cw[w][k + EXT], out[r + EXT + k], gsum);
+        }
+        st_f32(ors, (unsigned)(t < T ? t : 0) * ldo_bytes + (unsigned)(w < nw ? w : 0) * win_bytes, (mine && w < nw) ? soff_ok : kDrop, lv ? gsum : 0.0f);
+      }
+      if (r % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // (else every offset is computed up front and the scalars spill)
+    }
+  }
+}
+
+// fir_edge_kernel: one workgroup per (utterance, dim group, end): the EW rows at that end, whose taps come from the table.
+// Rows are counted from the end (j = 0 is the first / last frame; the table's rows for the last frames are stored mirrored, so both
+// ends run the same code).  Eight wavefronts share the rows: right-hand side and filter outputs through LDS, H rows of zeros in front
+// of the right-hand side standing for the frames beyond the end.  No condition inside the loops.
+template <bool BWD>
+__global__ __launch_bounds__(512) void fir_edge_kernel(const Problem p, const Args a) {
+  constexpr int H = kH, E = kE, EXT = kEXT, NWV = 8;
+  constexpr int EW = BWD ? E + EXT : E;            // rows written
+  constexpr int NZ = BWD ? EW + EXT : EW;          // FIR outputs needed (backward: z up to EXT beyond the last gradient row)
+  constexpr int NBE = NZ + H;                      // right-hand-side rows needed (towards the interior; nothing beyond the end)
+  __shared__ float lb[H + NBE][64];                // right-hand side: row H + j <-> the frame j from the end
+  __shared__ float lz[NZ][64];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = blockIdx.x >> 1;
+  const bool bottom = blockIdx.x & 1;
+  const int b = g / a.ndg, dg = g - b * a.ndg;
+  const int T = p.Tmax, sd = p.sd;
+  const int d0 = dg * a.dgw;
+  const int nd = sd - d0 < a.dgw ? sd - d0 : a.dgw;
+  const bool lane_ok = lane < nd;
+  const int d = d0 + (lane_ok ? lane : nd - 1);
+  const int nw = a.nw, mw = a.mw;
+  constexpr unsigned kDrop = 0x80000000u;          // an offset behind the buffer's end: the read returns 0
+  const __amdgpu_buffer_rsrc_t irs = make_rsrc(BWD ? (const float *)p.grad_out + (size_t)b * T * p.ld_gout + d0
+                                                   : (const float *)p.mean + (size_t)b * T * p.ld_in + d0);
+  const unsigned loff = (unsigned)(d - d0) * 4u;
+  const unsigned ldi_bytes = (unsigned)(BWD ? p.ld_gout : p.ld_in) * 4u, win_bytes = (unsigned)sd * 4u;
+  float *obase = (float *)p.out + (size_t)b * T * p.ld_out + d;
+  auto frame = [&](int j) { return bottom ? T - 1 - j : j; };
+  float cb[kMaxNw][2 * EXT + 1];  // the windows, counted towards the interior
+#pragma unroll
+  for (int w = 0; w < kMaxNw; ++w)
+#pragma unroll
+    for (int k = 0; k <= 2 * EXT; ++k) cb[w][k] = bottom ? a.cpad[w][2 * EXT - k] : a.cpad[w][k];
+  // ---- right-hand side rows j = -H .. NBE - 1: every load first, then the sums ----
+  constexpr int NR = (NBE + NWV - 1) / NWV;        // rows per wavefront
+  constexpr int NL = BWD ? 1 : 1 + 2 * (2 * EXT + 1);
+  float mu[NR][NL];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int j = i * NWV + wv;
+    const int fi = frame(j < NBE ? j : NBE - 1);
+    if (BWD) {
+      mu[i][0] = ld_f32(irs, (unsigned)fi * ldi_bytes, loff);
+    } else {
+#pragma unroll
+      for (int w = 0; w < kMaxNw; ++w) {
+#pragma unroll
+        for (int k = -EXT; k <= EXT; ++k) {   // b[i] += c_w[l + k] m_w[t] mu_w[t],  t = i - k
+          if (w == 0 && k != 0) continue;
+          const int t = fi - k;
+          const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+          const bool lv = w < nw && t >= 0 && t < T && (w == 0 || (mw != 0 && t >= mw && t < T - mw));
+          mu[i][w == 0 ? 0 : 1 + (w - 1) * (2 * EXT + 1) + k + EXT] =
+              ld_f32(irs, (unsigned)tc * ldi_bytes + (unsigned)(w < nw ? w : 0) * win_bytes, lv ? loff : kDrop);
+        }
+      }
+    }
+  }
+  for (int j = wv; j < H; j += NWV) lb[j][lane] = 0.0f;
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int j = i * NWV + wv;
+    float v = mu[i][0];
+    if (!BWD) {
+      v *= a.cpad[0][EXT];
+#pragma unroll
+      for (int w = 1; w < kMaxNw; ++w)
+#pragma unroll
+        for (int k = -EXT; k <= EXT; ++k) v = __builtin_fmaf(a.cpad[w][k + EXT], mu[i][1 + (w - 1) * (2 * EXT + 1) + k + EXT], v);
+    }
+    if (j < NBE) lb[H + j][lane] = v;
+  }
+  __syncthreads();
+  // ---- the taps: row j uses the table row of its end for j < E, the interior row otherwise; tap k in lane k ----
+  constexpr int NRZ = (NZ + NWV - 1) / NWV;
+  float tv[NRZ];
+#pragma unroll
+  for (int i = 0; i < NRZ; ++i) {
+    const int j = i * NWV + wv;
+    const int jc = j < NZ ? j : NZ - 1;
+    tv[i] = a.tap[(size_t)(jc < E ? (bottom ? 1 + E + jc : 1 + jc) : 0) * kTaps + (lane < kTaps ? lane : 0)];
+  }
+#pragma unroll
+  for (int i = 0; i < NRZ; ++i) {
+    const int j = i * NWV + wv;
+    const int jc = j < NZ ? j : NZ - 1;
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {  // tap k multiplies the right-hand side of the frame j - H + k from the end
+      const float tk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tv[i]), k));
+      if (k & 1) s1 = __builtin_fmaf(tk, lb[jc + k][lane], s1);
+      else s0 = __builtin_fmaf(tk, lb[jc + k][lane], s0);
+    }
+    if (j < NZ) lz[j][lane] = s0 + s1;
+  }
+  __syncthreads();
+  if (!lane_ok) return;
+#pragma unroll
+  for (int j0 = 0; j0 < EW; j0 += NWV) {
+    const int j = j0 + wv;
+    if (j >= EW) continue;
+    const int t = frame(j);
+    if (!BWD) {
+      obase[(size_t)t * p.ld_out] = lz[j][lane];
+    } else {
+#pragma unroll
+      for (int w = 0; w < kMaxNw; ++w) {
+        if (w >= nw) continue;
+        const bool lv = w == 0 || (mw != 0 && t >= mw && t < T - mw);
+        float gsum = 0.0f;
+#pragma unroll
+        for (int k = -EXT; k <= EXT; ++k) {  // z of the frame j + k from the end is z of frame t + k (first frames) or t - k (last)
+          if (w == 0 && k != 0) continue;
+          const int jj = j + k < 0 ? 0 : j + k;  // (beyond the end only where lv is false)
+          gsum = __builtin_fmaf(cb[w][k + EXT], lz[jj][lane], gsum);
+        }
+        obase[(size_t)t * p.ld_out + (size_t)w * sd] = lv ? gsum : 0.0f;
+      }
+    }
+  }
+}
+
+// ---- the tap table: once per (device, window set) ----
+struct Table {
+  float *dev = nullptr;
+  bool ok = false;
+};
+std::mutex g_mu;
+std::map<std::pair<int, std::vector<double>>, Table> g_tables;
+
+std::vector<double> key_of(const WinSet &ws) {
+  std::vector<double> k;
+  k.push_back(ws.nw);
+  for (int w = 0; w < ws.nw; ++w) {
+    k.push_back(ws.l[w]);
+    k.push_back(ws.u[w]);
+    for (int j = 0; j <= ws.l[w] + ws.u[w]; ++j) k.push_back(ws.c[ws.off[w] + j]);
+  }
+  return k;
+}
+
+// Builds the table with one exact forward solve of 1 + 2 E one-hot static-window inputs on a kTref-frame utterance (b = c_0 e_s, so
+// the trajectory is c_0 times column s of P^-1).  Synchronous (first use only); not while `st` is being captured.
+const Table *table_for(hipStream_t st, int device, const WinSet &ws) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto key = std::make_pair(device, key_of(ws));
+  auto it = g_tables.find(key);
+  if (it != g_tables.end()) return &it->second;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;  // (not cached: a later call outside the capture builds it)
+  }
+  Table tb;
+  const int S = kRows, T = kTref, D = ws.nw * S;
+  const double c0 = ws.c[ws.off[0]];
+  std::vector<double> means((size_t)T * D, 0.0), outh((size_t)T * S, 0.0);
+  auto src_frame = [&](int dcol) { return dcol == 0 ? T / 2 : (dcol <= kE ? dcol - 1 : T - 1 - (dcol - kE - 1)); };
+  for (int dcol = 0; dcol < S; ++dcol) means[(size_t)src_frame(dcol) * D + dcol] = 1.0 / c0;
+  double *dm = nullptr, *dout = nullptr;
+  bool good = hipMalloc(&dm, means.size() * 8) == hipSuccess && hipMalloc(&dout, outh.size() * 8) == hipSuccess;
+  if (good) good = hipMemcpyAsync(dm, means.data(), means.size() * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+  if (good) {
+    Problem q;
+    q.mean = dm;
+    q.var = nullptr;
+    q.grad_out = nullptr;
+    q.lengths = nullptr;
+    q.out = dout;
+    q.status = nullptr;
+    q.var_mode = MLPG_HIP_VAR_UNIT;
+    q.B = 1;
+    q.Tmax = T;
+    q.D = D;
+    q.sd = S;
+    q.ld_in = D;
+    q.ld_gout = 0;
+    q.ld_out = S;
+    q.ld_status = S;
+    good = dispatch_solve(st, MLPG_HIP_F64, MLPG_HIP_F64, MLPG_HIP_ALGO_GENERIC, false, q, ws, device) == 0;
+  }
+  if (good) good = hipMemcpyAsync(outh.data(), dout, outh.size() * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
+  if (good) good = hipStreamSynchronize(st) == hipSuccess;
+  if (good) {
+    // column dcol of outh = column src_frame(dcol) of P^-1 = (symmetry) that ROW
+    auto pinv = [&](int dcol, int s) -> double { return (s >= 0 && s < T) ? outh[(size_t)s * S + dcol] : 0.0; };
+    std::vector<float> tap((size_t)kRows * kTaps, 0.0f);
+    const int c = T / 2;
+    for (int k = 0; k < kTaps; ++k) tap[k] = (float)pinv(0, c - kH + k);
+    for (int t = 0; t < kE; ++t)
+      for (int k = 0; k < kTaps; ++k) {
+        tap[(size_t)(1 + t) * kTaps + k] = (float)pinv(1 + t, t - kH + k);
+        tap[(size_t)(1 + kE + t) * kTaps + k] = (float)pinv(1 + kE + t, (T - 1 - t) + kH - k);  // mirrored: counted from the end
+      }
+    // the decay the kernel relies on, checked on this window set's own numbers
+    const double g0 = std::abs(pinv(0, c)), tol = 0x1p-26 * g0;
+    double tail = 0.0;
+    for (int s = kH + 1; s < 2 * kH; ++s) tail += std::abs(pinv(0, c + s)) + std::abs(pinv(0, c - s));
+    bool ok = g0 > 0.0 && std::abs(pinv(0, c + kH + 1)) <= tol && std::abs(pinv(0, c - kH - 1)) <= tol && tail <= 4.0 * tol;
+    // the last rows of the end tables have reached the interior row
+    for (int k = 0; k < kTaps && ok; ++k) {
+      ok = std::abs((double)tap[(size_t)kE * kTaps + k] - (double)tap[k]) <= 64.0 * tol &&
+           std::abs((double)tap[(size_t)(2 * kE) * kTaps + k] - (double)tap[k]) <= 64.0 * tol;
+    }
+    for (float v : tap) ok = ok && std::isfinite(v);
+    if (ok) {
+      ok = hipMalloc(&tb.dev, tap.size() * sizeof(float)) == hipSuccess &&
+           hipMemcpy(tb.dev, tap.data(), tap.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    tb.ok = ok;
+  }
+  (void)hipGetLastError();
+  if (dm) (void)hipFree(dm);
+  if (dout) (void)hipFree(dout);
+  if (!good) return nullptr;  // a runtime failure is not a property of the window set: not cached
+  return &(g_tables[key] = tb);
+}
+
+}  // namespace fir
+
+// float32 in and out, unit variances, no ragged lengths, at least 2 E + 2 H frames, 1-3 windows of extent <= 2 the first of which is a
+// single tap (the static window), dense dims.
+bool fir_shape_supported(const Problem &p, const WinSet &ws, int in_dtype, int out_dtype) {
+  using namespace fir;
+  if (in_dtype != MLPG_HIP_F32 || out_dtype != MLPG_HIP_F32 || p.var_mode != MLPG_HIP_VAR_UNIT || p.lengths) return false;
+  if (ws.nw < 1 || ws.nw > kMaxNw || ws.mw > kEXT || ws.l[0] != 0 || ws.u[0] != 0 || ws.c[ws.off[0]] == 0.0) return false;
+  if (p.pitch && p.pitch != p.sd) return false;
+  if (p.Tmax < 2 * kE + 2 * kH || p.B < 1 || p.sd < 1) return false;
+  return rows_fit_buffer(p);
+}
+
+int launch_fir(hipStream_t st, bool backward, const Problem &p, const WinSet &ws, int device) {
+  using namespace fir;
+  const Table *tb = table_for(st, device, ws);
+  if (!tb || !tb->ok) return kFirNotApplicable;
+  Args a;
+  a.tap = tb->dev;
+  a.ndg = (p.sd + 63) / 64;
+  a.dgw = (p.sd + a.ndg - 1) / a.ndg;
+  a.nsg = p.B * a.ndg;
+  a.nt = (p.Tmax + kTT - 1) / kTT;
+  a.nw = ws.nw;
+  a.mw = ws.mw;
+  for (int w = 0; w < kMaxNw; ++w) {
+    a.narrow[w] = 0;
+    for (int j = 0; j <= 2 * kEXT; ++j) a.cpad[w][j] = 0.0f;
+    if (w >= ws.nw) continue;
+    a.narrow[w] = (ws.l[w] == 0 && ws.u[w] == 0) ? 1 : 0;
+    for (int k = -ws.l[w]; k <= ws.u[w]; ++k) a.cpad[w][k + kEXT] = (float)ws.c[ws.off[w] + ws.l[w] + k];
+  }
+  note_launch(kCountFir);
+  const long items = (long)a.nsg * a.nt;
+  const dim3 grid((unsigned)((items + kW - 1) / kW)), block(kW * 64), egrid((unsigned)(2 * a.nsg)), eblock(512);
+  if (backward) {
+    hipLaunchKernelGGL((fir_edge_kernel<true>), egrid, eblock, 0, st, p, a);
+    hipLaunchKernelGGL((fir_kernel<true>), grid, block, 0, st, p, a);
+  } else {
+    hipLaunchKernelGGL((fir_edge_kernel<false>), egrid, eblock, 0, st, p, a);
+    hipLaunchKernelGGL((fir_kernel<false>), grid, block, 0, st, p, a);
+  }
+  MLPG_HIP_CHECK(hipGetLastError());
+  // (P = c_0^2 I + a sum of squares is positive definite whatever the windows: every verdict is 0)
+  if (p.status) MLPG_HIP_CHECK(hipMemset2DAsync(p.status, (size_t)p.ld_status * sizeof(int32_t), 0, (size_t)p.sd * sizeof(int32_t), (size_t)p.B, st));
+  return 0;
+}
+
+}  // namespace mlpg

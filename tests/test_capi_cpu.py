@@ -241,7 +241,7 @@ def test_header_constants_match_the_python_binding():
     src = open(os.path.join(ROOT, "include", "mlpg_hip.h")).read()
     defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"^#define\s+MLPG_HIP_([A-Z0-9_]+)\s+\(?(-?\d+)\)?", src, re.M)}
     pairs = {"ALGO_AUTO": _hip.ALGO_AUTO, "ALGO_GENERIC": _hip.ALGO_GENERIC, "ALGO_WAVE": _hip.ALGO_WAVE, "ALGO_STRIP": _hip.ALGO_STRIP,
-             "ALGO_PIPE": _hip.ALGO_PIPE, "ALGO_CONST": _hip.ALGO_CONST, "ALGO_CHUNK": _hip.ALGO_CHUNK,
+             "ALGO_PIPE": _hip.ALGO_PIPE, "ALGO_CONST": _hip.ALGO_CONST, "ALGO_CHUNK": _hip.ALGO_CHUNK, "ALGO_FIR": _hip.ALGO_FIR,
              "F32": _hip.F32, "F64": _hip.F64, "VAR_FRAME": _hip.VAR_FRAME, "VAR_GLOBAL": _hip.VAR_GLOBAL, "VAR_UNIT": _hip.VAR_UNIT,
              "DIST_L2": _hip.DIST_L2, "DIST_SCALED_L2_NP": _hip.DIST_SCALED_L2_NP, "DIST_SCALED_L1_NP": _hip.DIST_SCALED_L1_NP,
              "DIST_SCALED_SQL2_NP": _hip.DIST_SCALED_SQL2_NP, "TIE_FIRST_MIN": _hip.TIE_FIRST_MIN, "TIE_DIAG_LAST": _hip.TIE_DIAG_LAST}
