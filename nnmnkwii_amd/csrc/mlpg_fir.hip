@@ -29,7 +29,7 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
 
 namespace fir {
 
-constexpr int kH = 24, kE = 24, kTaps = 2 * kH + 1, kRows = 1 + 2 * kE, kTT = 32, kEXT = 2, kTref = 160, kW = 4, kMaxNw = 3;
+constexpr int kH = 24, kE = 24, kTaps = 2 * kH + 1, kRows = 1 + 2 * kE, kTT = 32, kEXT = 2, kTref = 160, kW = 8, kMaxNw = 3;
 
 struct Args {
   const float *tap;  // [kRows][kTaps]: row 0 interior, 1..E rows t = 0..E-1, E+1..2E rows T-1 .. T-E with their taps in reverse order
@@ -40,6 +40,7 @@ struct Args {
 };
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
   const unsigned long long u = (unsigned long long)base;
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -52,7 +53,7 @@ __device__ __forceinline__ void st_f32(__amdgpu_buffer_rsrc_t rs, unsigned soff,
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, loff, soff, 0);
 }
 
-// fir_kernel: one wavefront = one tile of kTT frames of one (utterance, dim group), every row with the INTERIOR taps.
+// fir_tiles: one wavefront = one tile of kTT frames of one (utterance, dim group), every row with the INTERIOR taps.
 // Written for a wavefront that is alone on its SIMD (64 utterances x 16 tiles = one wavefront per SIMD of the chip):
 //   - branch-free: a frame outside the utterance is read from the nearest frame inside and enters with coefficient 0 (the
 //     coefficients are scalars selected per frame); a row that is not this kernel's is stored to an offset the buffer drops;
@@ -60,20 +61,21 @@ __device__ __forceinline__ void st_f32(__amdgpu_buffer_rsrc_t rs, unsigned soff,
 //     flight and the tile costs 84 round trips);
 //   - the taps sit in the lanes of one register and are read out one at a time (v_readlane): 49 scalars held live cost more scalar
 //     registers than there are, and the reloads from the kernel arguments that followed cost more than the arithmetic.
-template <bool BWD>
-__global__ __launch_bounds__(kW * 64, 2) void fir_kernel(const Problem p, const Args a) {
-  constexpr int H = kH, E = kE, TT = kTT, EXT = kEXT;
+template <bool BWD, int EXT>
+__device__ __forceinline__ void fir_tiles(const Problem &p, const Args &a, const unsigned blk) {
+  constexpr int H = kH, E = kE, TT = kTT;
   // FIR outputs of a tile: its own frames (forward); EXT more on either side (backward: W_w z needs the neighbours)
   constexpr int NO = BWD ? TT + 2 * EXT : TT;
   constexpr int NB = NO + 2 * H;                   // right-hand-side rows under the taps
   constexpr int NF = BWD ? NB : NB + 2 * EXT;      // frames read (forward: b[i] needs mu of i - EXT .. i + EXT)
-  constexpr int EW = BWD ? E + EXT : E;            // rows at either end that fir_edge_kernel writes
+  constexpr int EW = BWD ? E + EXT : E;            // rows at either end that fir_ends writes
   constexpr int FB = 14;                           // frames per batch of loads
-  static_assert(NF % FB == 0, "batches");
+  constexpr int NQ = (NF + FB - 1) / FB;
+  static_assert(NB % 2 == 0 && NO % 2 == 0, "row pairs");
   constexpr unsigned kDrop = 0x80000000u;          // an offset behind the buffer's end: the store is dropped
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long item = (long)blockIdx.x * kW + wv;
+  const long item = (long)blk * kW + wv;
   if (item >= (long)a.nsg * a.nt) return;
   const int g = (int)(item / a.nt), tile = (int)(item - (long)g * a.nt);
   const int b = g / a.ndg, dg = g - b * a.ndg;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(kW * 64, 2) void fir_kernel(const Problem p, const 
   const bool lane_ok = lane < nd;
   const int d = d0 + (lane_ok ? lane : nd - 1);
   const int t0 = tile * TT;
-  if (t0 + TT <= EW || t0 >= T - EW) return;  // every row of the tile belongs to fir_edge_kernel
+  if (t0 + TT <= EW || t0 >= T - EW) return;  // every row of the tile belongs to fir_ends
   const int nw = a.nw, mw = a.mw;
   const __amdgpu_buffer_rsrc_t irs = make_rsrc(BWD ? (const float *)p.grad_out + (size_t)b * T * p.ld_gout + d0
                                                    : (const float *)p.mean + (size_t)b * T * p.ld_in + d0);
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(kW * 64, 2) void fir_kernel(const Problem p, const 
 #pragma unroll
   for (int w = 0; w < kMaxNw; ++w)
 #pragma unroll
-    for (int k = 0; k <= 2 * EXT; ++k) cw[w][k] = a.cpad[w][k];
+    for (int k = 0; k <= 2 * EXT; ++k) cw[w][k] = a.cpad[w][k + kEXT - EXT];
   float bb[NB];  // the right-hand side under the taps: row ib <-> frame f_b + ib
   float out[NO];
 
@@ -123,13 +125,14 @@ __global__ __launch_bounds__(kW * 64, 2) void fir_kernel(const Problem p, const 
 #pragma unroll
     for (int i = 0; i < NB; ++i) bb[i] = 0.0f;
 #pragma unroll
-    for (int q = -1; q < NF / FB; ++q) {
-      if (q + 1 < NF / FB) {  // the loads of batch q + 1
+    for (int q = -1; q < NQ; ++q) {
+      if (q + 1 < NQ) {  // the loads of batch q + 1
         // (opaque: else the scalar offsets and masks of all 252 loads are computed at the top of the kernel and spill)
         int fq = f_first + (q + 1) * FB;
         asm volatile("" : "+s"(fq));
 #pragma unroll
         for (int s = 0; s < FB; ++s) {
+          if ((q + 1) * FB + s >= NF) continue;
           const int t = fq + s;
           const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
 #pragma unroll
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(kW * 64, 2) void fir_kernel(const Problem p, const 
 #pragma unroll
         for (int sl = 0; sl < FB; ++sl) {
           const int s = q * FB + sl;
+          if (s >= NF) continue;
 #pragma unroll
           for (int w = 0; w < kMaxNw; ++w) {
             const float m = mu[q & 1][sl][w];
@@ -165,13 +169,32 @@ __global__ __launch_bounds__(kW * 64, 2) void fir_kernel(const Problem p, const 
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  // The taps, two rows per instruction (v_pk_fma_f32): row pairs starting at an even row (be) and at an odd row (bo) are kept as
+  // register pairs; tap k of the output pair (2 j, 2 j + 1) multiplies the pair starting at row 2 j + k.
+  f32x2 be[NB / 2], bo[NB / 2 - 1], o2[NO / 2];
 #pragma unroll
-  for (int r = 0; r < NO; ++r) out[r] = 0.0f;
+  for (int i = 0; i < NB / 2; ++i) {
+    be[i] = f32x2{bb[2 * i], bb[2 * i + 1]};
+    asm volatile("" : "+v"(be[i]));
+  }
+#pragma unroll
+  for (int i = 0; i < NB / 2 - 1; ++i) {
+    bo[i] = f32x2{bb[2 * i + 1], bb[2 * i + 2]};
+    asm volatile("" : "+v"(bo[i]));
+  }
+#pragma unroll
+  for (int j = 0; j < NO / 2; ++j) o2[j] = f32x2{0.0f, 0.0f};
 #pragma unroll
   for (int k = 0; k < kTaps; ++k) {
     const float tk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tapv), k));
+    const f32x2 t2 = f32x2{tk, tk};
 #pragma unroll
-    for (int r = 0; r < NO; ++r) out[r] = __builtin_fmaf(tk, bb[r + k], out[r]);
+    for (int j = 0; j < NO / 2; ++j) o2[j] = __builtin_elementwise_fma(t2, (k & 1) ? bo[j + (k - 1) / 2] : be[j + k / 2], o2[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NO / 2; ++j) {
+    out[2 * j] = o2[j].x;
+    out[2 * j + 1] = o2[j].y;
   }
 
   // (opaque, and behind the first output: else the offsets and masks of every store are computed at the top of the kernel and spill)
@@ -206,21 +229,21 @@ __global__ __launch_bounds__(kW * 64, 2) void fir_kernel(const Problem p, const 
   }
 }
 
-// fir_edge_kernel: one workgroup per (utterance, dim group, end): the EW rows at that end, whose taps come from the table.
+// fir_ends: one workgroup per (utterance, dim group, end): the EW rows at that end, whose taps come from the table.
 // Rows are counted from the end (j = 0 is the first / last frame; the table's rows for the last frames are stored mirrored, so both
 // ends run the same code).  Eight wavefronts share the rows: right-hand side and filter outputs through LDS, H rows of zeros in front
 // of the right-hand side standing for the frames beyond the end.  No condition inside the loops.
-template <bool BWD>
-__global__ __launch_bounds__(512) void fir_edge_kernel(const Problem p, const Args a) {
-  constexpr int H = kH, E = kE, EXT = kEXT, NWV = 8;
+template <bool BWD, int EXT>
+__device__ __forceinline__ void fir_ends(const Problem &p, const Args &a, const unsigned blk) {
+  constexpr int H = kH, E = kE, NWV = kW;
   constexpr int EW = BWD ? E + EXT : E;            // rows written
   constexpr int NZ = BWD ? EW + EXT : EW;          // FIR outputs needed (backward: z up to EXT beyond the last gradient row)
   constexpr int NBE = NZ + H;                      // right-hand-side rows needed (towards the interior; nothing beyond the end)
   __shared__ float lb[H + NBE][64];                // right-hand side: row H + j <-> the frame j from the end
   __shared__ float lz[NZ][64];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int g = blockIdx.x >> 1;
-  const bool bottom = blockIdx.x & 1;
+  const int g = (int)(blk >> 1);
+  const bool bottom = blk & 1;
   const int b = g / a.ndg, dg = g - b * a.ndg;
   const int T = p.Tmax, sd = p.sd;
   const int d0 = dg * a.dgw;
@@ -239,7 +262,7 @@ __global__ __launch_bounds__(512) void fir_edge_kernel(const Problem p, const Ar
 #pragma unroll
   for (int w = 0; w < kMaxNw; ++w)
 #pragma unroll
-    for (int k = 0; k <= 2 * EXT; ++k) cb[w][k] = bottom ? a.cpad[w][2 * EXT - k] : a.cpad[w][k];
+    for (int k = 0; k <= 2 * EXT; ++k) cb[w][k] = bottom ? a.cpad[w][kEXT + EXT - k] : a.cpad[w][kEXT - EXT + k];
   // ---- right-hand side rows j = -H .. NBE - 1: every load first, then the sums ----
   constexpr int NR = (NBE + NWV - 1) / NWV;        // rows per wavefront
   constexpr int NL = BWD ? 1 : 1 + 2 * (2 * EXT + 1);
@@ -272,11 +295,11 @@ __global__ __launch_bounds__(512) void fir_edge_kernel(const Problem p, const Ar
     const int j = i * NWV + wv;
     float v = mu[i][0];
     if (!BWD) {
-      v *= a.cpad[0][EXT];
+      v *= a.cpad[0][kEXT];
 #pragma unroll
       for (int w = 1; w < kMaxNw; ++w)
 #pragma unroll
-        for (int k = -EXT; k <= EXT; ++k) v = __builtin_fmaf(a.cpad[w][k + EXT], mu[i][1 + (w - 1) * (2 * EXT + 1) + k + EXT], v);
+        for (int k = -EXT; k <= EXT; ++k) v = __builtin_fmaf(a.cpad[w][k + kEXT], mu[i][1 + (w - 1) * (2 * EXT + 1) + k + EXT], v);
     }
     if (j < NBE) lb[H + j][lane] = v;
   }
@@ -328,6 +351,15 @@ __global__ __launch_bounds__(512) void fir_edge_kernel(const Problem p, const Ar
       }
     }
   }
+}
+
+// One launch: the first 2 nsg workgroups take the ends (three dependent phases: they start first), the others eight tiles each.
+// 64 utterances x 500 frames: 128 + 128 workgroups of eight wavefronts, one per CU.
+template <bool BWD, int EXT>
+__global__ __launch_bounds__(kW * 64, 1) void fir_kernel(const Problem p, const Args a) {
+  const unsigned nends = 2u * (unsigned)a.nsg;
+  if (blockIdx.x < nends) fir_ends<BWD, EXT>(p, a, blockIdx.x);
+  else fir_tiles<BWD, EXT>(p, a, blockIdx.x - nends);
 }
 
 // ---- the tap table: once per (device, window set) ----
@@ -460,13 +492,13 @@ int launch_fir(hipStream_t st, bool backward, const Problem &p, const WinSet &ws
   }
   note_launch(kCountFir);
   const long items = (long)a.nsg * a.nt;
-  const dim3 grid((unsigned)((items + kW - 1) / kW)), block(kW * 64), egrid((unsigned)(2 * a.nsg)), eblock(512);
-  if (backward) {
-    hipLaunchKernelGGL((fir_edge_kernel<true>), egrid, eblock, 0, st, p, a);
-    hipLaunchKernelGGL((fir_kernel<true>), grid, block, 0, st, p, a);
+  const dim3 grid((unsigned)(2 * a.nsg + (items + kW - 1) / kW)), block(kW * 64);
+  if (ws.mw <= 1) {  // (extent 0 or 1: the instance with 3 instead of 5 taps per window)
+    if (backward) hipLaunchKernelGGL((fir_kernel<true, 1>), grid, block, 0, st, p, a);
+    else hipLaunchKernelGGL((fir_kernel<false, 1>), grid, block, 0, st, p, a);
   } else {
-    hipLaunchKernelGGL((fir_edge_kernel<false>), egrid, eblock, 0, st, p, a);
-    hipLaunchKernelGGL((fir_kernel<false>), grid, block, 0, st, p, a);
+    if (backward) hipLaunchKernelGGL((fir_kernel<true, 2>), grid, block, 0, st, p, a);
+    else hipLaunchKernelGGL((fir_kernel<false, 2>), grid, block, 0, st, p, a);
   }
   MLPG_HIP_CHECK(hipGetLastError());
   // (P = c_0^2 I + a sum of squares is positive definite whatever the windows: every verdict is 0)

@@ -8,7 +8,8 @@ W3 = [(0, 0, np.array([1.0])), (1, 1, np.array([-0.5, 0.0, 0.5])), (1, 1, np.arr
 B, T, sd = (int(a) for a in (sys.argv[1:4] or [64, 500, 60]))
 m = torch.rand(B, T, 3 * sd, dtype=torch.float32, device="cuda")
 g = torch.randn(B, T, sd, dtype=torch.float32, device="cuda")
+ALGOS = [int(x) for x in (sys.argv[4:] or [7])]
 for _ in range(20):
-    _hip.forward(m, None, W3, None, algo=7, want_status=False)
-    _hip.backward(None, g, W3, 3 * sd, out_dtype=torch.float32, algo=7, want_status=False)
+    _hip.forward(m, None, W3, None, algo=ALGOS[0], want_status=False)
+    _hip.backward(None, g, W3, 3 * sd, out_dtype=torch.float32, algo=ALGOS[0], want_status=False)
 torch.cuda.synchronize()
