@@ -223,7 +223,7 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     }
     algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
   }
-  if (algo == MLPG_HIP_ALGO_AUTO && fir_shape_supported(p, ws, in_dtype, out_dtype)) {
+  if (algo == MLPG_HIP_ALGO_AUTO && fir_shape_supported(p, ws, in_dtype, out_dtype) && fir_preferred(p, backward)) {
     const int rc = launch_fir(st, backward, p, ws, device);
     if (rc != kFirNotApplicable) return rc;
   }

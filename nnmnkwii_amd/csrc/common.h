@@ -103,6 +103,7 @@ int launch_chunk(hipStream_t s, int dtype, int out_dtype, bool backward, const P
 // fast enough (or its tap table cannot be built now: stream capture)
 constexpr int kFirNotApplicable = -2000;
 bool fir_shape_supported(const Problem &p, const WinSet &w, int in_dtype, int out_dtype);
+bool fir_preferred(const Problem &p, bool backward);
 int launch_fir(hipStream_t s, bool backward, const Problem &p, const WinSet &w, int device);
 int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,
                      int ncols, void *dst, long ld_dst);

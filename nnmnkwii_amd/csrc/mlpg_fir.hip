@@ -471,6 +471,12 @@ bool fir_shape_supported(const Problem &p, const WinSet &ws, int in_dtype, int o
   return rows_fit_buffer(p);
 }
 
+// Measured (profiles/r04_notes.md section 11): backward it is the fastest kernel at 64 and at 256 utterances; forward the
+// constant-coefficient kernel (one workgroup per sequence) overtakes it once there are sequences enough to fill the chip with those.
+bool fir_preferred(const Problem &p, bool backward) {
+  return backward || (long)p.B * ((p.sd + 63) / 64) < 256;
+}
+
 int launch_fir(hipStream_t st, bool backward, const Problem &p, const WinSet &ws, int device) {
   using namespace fir;
   const Table *tb = table_for(st, device, ws);

@@ -299,7 +299,7 @@ def _run(only, quick, device_index):
         # the two kernels alone (unit variances, float32), wave-per-system vs strip
         md = means.detach()
         god = torch.rand(B, T, D // 3, device=dev)
-        for name, algo in (("wave", 2), ("strip", 3)):
+        for name, algo in (("wave", 2), ("strip", 3), ("fir", 7)):
             kf = gpu_time(lambda: _hip.forward(md, None, WINDOWS, algo=algo, want_status=False), steps=20)
             kb = gpu_time(lambda: _hip.backward(None, god, WINDOWS, D, out_dtype=torch.float32, algo=algo, want_status=False), steps=20)
             emit(path="c3-kernels-" + name, ms_forward=kf, ms_backward=kb, ms=kf + kb, alg_bytes=by, GBps=by / (kf + kb) / 1e6)
