@@ -95,6 +95,11 @@ void mlpg_hip_shutdown(void);
  * workspace: caller-owned device memory, 128-byte aligned, >= mlpg_hip_unit_mse_workspace_bytes(B, D, nw) bytes,
  * zeroed ONCE by the caller before its first use (the kernel leaves its arrival counter zero); one workspace per stream
  * that may run the call concurrently.  The call allocates nothing and is capturable into a HIP graph.
+ * Float32 batches without lengths, Tmax >= 96, 1-3 windows of extent <= 2 the first of which is a single tap, given a workspace of
+ * mlpg_hip_unit_mse_workspace_bytes_t(B, Tmax, D, nw) bytes: the step runs in the FIR form (MLPG_HIP_ALGO_FIR) as TWO launches --
+ * forward + loss terms + d loss / d y into the workspace, then backward + the loss sum (fixed order, bitwise repeatable) -- with no
+ * limit on Tmax; the first call for a window set builds the tap table (synchronous, not capturable: warm up before capturing).
+ * With the smaller workspace of mlpg_hip_unit_mse_workspace_bytes the call behaves as before.
  */
 int mlpg_hip_unit_mse_step(int device, void *stream, int dtype, const void *mean, const void *target,
                            const int32_t *lengths, int B, int Tmax, int D, int num_windows,
@@ -102,6 +107,7 @@ int mlpg_hip_unit_mse_step(int device, void *stream, int dtype, const void *mean
                            double n_elems, void *y_out, void *grad_mean, double *loss, int32_t *status,
                            void *workspace, size_t workspace_bytes);
 size_t mlpg_hip_unit_mse_workspace_bytes(int B, int D, int num_windows);
+size_t mlpg_hip_unit_mse_workspace_bytes_t(int B, int Tmax, int D, int num_windows);
 
 /*
  * Measurement aid, not part of the reference's interface: a plain streaming copy of nbytes (a multiple of 16; both

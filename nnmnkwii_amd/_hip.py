@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 F32, F64 = 0, 1
-ABI_VERSION = 11               # mlpg_hip_abi_version() of the library this binding was written for
+ABI_VERSION = 12               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE, ALGO_STRIP, ALGO_PIPE, ALGO_CONST, ALGO_CHUNK, ALGO_FIR = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -53,6 +53,7 @@ EXPORTS = (
     "mlpg_hip_stream_copy",
     "mlpg_hip_unit_mse_step",
     "mlpg_hip_unit_mse_workspace_bytes",
+    "mlpg_hip_unit_mse_workspace_bytes_t",
 )
 
 
@@ -170,6 +171,8 @@ def lib():
                                              ctypes.c_size_t]
         L.mlpg_hip_unit_mse_workspace_bytes.restype = ctypes.c_size_t
         L.mlpg_hip_unit_mse_workspace_bytes.argtypes = [ci, ci, ci]
+        L.mlpg_hip_unit_mse_workspace_bytes_t.restype = ctypes.c_size_t
+        L.mlpg_hip_unit_mse_workspace_bytes_t.argtypes = [ci, ci, ci, ci]
         L.mlpg_hip_stream_copy.restype = ci
         L.mlpg_hip_stream_copy.argtypes = [ci, vp, vp, vp, ctypes.c_size_t]
         if L.mlpg_hip_abi_version() != ABI_VERSION:
@@ -726,7 +729,8 @@ def unit_mse_step(mean, target, windows, lengths=None, n_elems=None, want_y=Fals
     y = torch.empty_like(target) if want_y else None
     loss = torch.empty((), dtype=torch.float64, device=mean.device)
     status = torch.empty((B * sd,), dtype=torch.int32, device=mean.device) if want_status else None
-    need = int(lib().mlpg_hip_unit_mse_workspace_bytes(B, D, nw))
+    # (the _t form: with room for the FIR form's dy buffer, which float32 batches without lengths of T >= 96 take)
+    need = int(lib().mlpg_hip_unit_mse_workspace_bytes_t(B, T, D, nw))
     stream = torch.cuda.current_stream(mean.device)
     key = (mean.device.index, stream.cuda_stream)
     ws = _MSE_WORKSPACE.get(key)

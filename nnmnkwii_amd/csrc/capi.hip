@@ -333,7 +333,7 @@ using namespace mlpg;
 
 extern "C" {
 
-__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 11; }
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 12; }
 
 __attribute__((visibility("default"))) long long mlpg_hip_launch_count(int kind) {
   return kind >= 0 && kind < kCountKinds ? g_launches[kind].load() : -1;
@@ -661,10 +661,6 @@ __attribute__((visibility("default"))) int mlpg_hip_unit_mse_step(int device, vo
     set_error("unit_mse_step: NULL loss pointer");
     return MLPG_HIP_EINVAL;
   }
-  if (!unit_mse_supported(Tmax > 0 ? Tmax : 1, ws)) {
-    set_error("unit_mse_step: needs window extents <= 1 and T <= 1024 (T=%d, half-bandwidth %d)", Tmax, ws.q);
-    return MLPG_HIP_EINVAL;
-  }
   DeviceGuard g(device);
   if (!g.ok) {
     set_error("cannot select device %d", device);
@@ -677,11 +673,6 @@ __attribute__((visibility("default"))) int mlpg_hip_unit_mse_step(int device, vo
   }
   if (!mean || !target || !grad_mean) {
     set_error("NULL data pointer");
-    return MLPG_HIP_EINVAL;
-  }
-  if (!workspace || workspace_bytes < unit_mse_workspace_bytes(B, D / num_windows) || ((uintptr_t)workspace & 127)) {
-    set_error("unit_mse_step: workspace of %zu bytes (128-byte aligned) needed, see mlpg_hip_unit_mse_workspace_bytes",
-              unit_mse_workspace_bytes(B, D / num_windows));
     return MLPG_HIP_EINVAL;
   }
   Problem p;
@@ -700,12 +691,33 @@ __attribute__((visibility("default"))) int mlpg_hip_unit_mse_step(int device, vo
   p.ld_gout = 0;
   p.ld_out = D;
   p.ld_status = D / num_windows;
+  // float32 batches without lengths, given the larger workspace (mlpg_hip_unit_mse_workspace_bytes_t): the FIR form, two launches
+  if (dtype == MLPG_HIP_F32 && fir_shape_supported(p, ws, dtype, dtype) && workspace && !((uintptr_t)workspace & 127) &&
+      workspace_bytes >= fir_mse_workspace_bytes(B, Tmax, p.sd)) {
+    const int rc = launch_fir_mse(st, p, ws, device, target, y_out, n_elems, loss, workspace);
+    if (rc != kFirNotApplicable) return rc;
+  }
+  if (!unit_mse_supported(Tmax, ws)) {
+    set_error("unit_mse_step: needs window extents <= 1 and T <= 1024 (T=%d, half-bandwidth %d), or a float32 batch without lengths "
+              "of T >= 96 with the workspace of mlpg_hip_unit_mse_workspace_bytes_t", Tmax, ws.q);
+    return MLPG_HIP_EINVAL;
+  }
+  if (!workspace || workspace_bytes < unit_mse_workspace_bytes(B, D / num_windows) || ((uintptr_t)workspace & 127)) {
+    set_error("unit_mse_step: workspace of %zu bytes (128-byte aligned) needed, see mlpg_hip_unit_mse_workspace_bytes",
+              unit_mse_workspace_bytes(B, D / num_windows));
+    return MLPG_HIP_EINVAL;
+  }
   return launch_unit_mse(st, dtype, p, ws, target, y_out, n_elems, loss, workspace);
 }
 
 __attribute__((visibility("default"))) size_t mlpg_hip_unit_mse_workspace_bytes(int B, int D, int num_windows) {
   if (B < 0 || D < 0 || num_windows < 1) return 0;
   return unit_mse_workspace_bytes(B, D / num_windows);
+}
+
+__attribute__((visibility("default"))) size_t mlpg_hip_unit_mse_workspace_bytes_t(int B, int Tmax, int D, int num_windows) {
+  if (B < 0 || Tmax < 0 || D < 0 || num_windows < 1) return 0;
+  return std::max(unit_mse_workspace_bytes(B, D / num_windows), fir_mse_workspace_bytes(B, Tmax, D / num_windows));
 }
 
 __attribute__((visibility("default"))) int mlpg_hip_stream_copy(int device, void *stream, const void *src, void *dst,

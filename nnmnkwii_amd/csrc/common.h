@@ -105,6 +105,9 @@ constexpr int kFirNotApplicable = -2000;
 bool fir_shape_supported(const Problem &p, const WinSet &w, int in_dtype, int out_dtype);
 bool fir_preferred(const Problem &p, bool backward);
 int launch_fir(hipStream_t s, bool backward, const Problem &p, const WinSet &w, int device);
+size_t fir_mse_workspace_bytes(int B, int Tmax, int sd);
+int launch_fir_mse(hipStream_t s, const Problem &p, const WinSet &w, int device, const void *target, void *y_out, double n_elems,
+                   double *loss, void *workspace);
 int launch_copy_cols(hipStream_t s, int dtype, const void *src, long ld_src, const int32_t *lengths, int B, int Tmax,
                      int ncols, void *dst, long ld_dst);
 int launch_stream_copy(hipStream_t s, const void *src, void *dst, size_t nbytes);

@@ -37,6 +37,16 @@ struct Args {
   int nw, mw;
   int narrow[kMaxNw];
   float cpad[kMaxNw][2 * kEXT + 1];  // window coefficients, zero padded to [-2, 2]
+  // the training step (MSE instances): forward writes dy = scale (y - target) and one partial sum of (y - target)^2 per wavefront,
+  // backward reads dy; its last workgroup adds the partials up in a fixed order
+  const float *target;  // (B, T, sd)
+  float *dy;            // (B, T, sd)
+  double *partials;     // one per wavefront of the forward launch
+  double *loss;
+  float scale;          // 2 / n_elems
+  double inv_n;         // 1 / n_elems
+  int npart;
+  int y_given;          // forward: p.out holds y_out (else the trajectory is not stored)
 };
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -61,7 +71,13 @@ __device__ __forceinline__ void st_f32(__amdgpu_buffer_rsrc_t rs, unsigned soff,
 //     flight and the tile costs 84 round trips);
 //   - the taps sit in the lanes of one register and are read out one at a time (v_readlane): 49 scalars held live cost more scalar
 //     registers than there are, and the reloads from the kernel arguments that followed cost more than the arithmetic.
-template <bool BWD, int EXT>
+__device__ __forceinline__ double wave_sum(double v) {  // lanes added in a fixed order
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <bool BWD, int EXT, bool MSE>
 __device__ __forceinline__ void fir_tiles(const Problem &p, const Args &a, const unsigned blk) {
   constexpr int H = kH, E = kE, TT = kTT;
   // FIR outputs of a tile: its own frames (forward); EXT more on either side (backward: W_w z needs the neighbours)
@@ -76,7 +92,11 @@ __device__ __forceinline__ void fir_tiles(const Problem &p, const Args &a, const
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long item = (long)blk * kW + wv;
-  if (item >= (long)a.nsg * a.nt) return;
+  double *const part = a.partials + (size_t)blockIdx.x * kW + wv;  // (MSE, forward: every wavefront of the launch writes its own)
+  if (item >= (long)a.nsg * a.nt) {
+    if (MSE && !BWD && lane == 0) *part = 0.0;
+    return;
+  }
   const int g = (int)(item / a.nt), tile = (int)(item - (long)g * a.nt);
   const int b = g / a.ndg, dg = g - b * a.ndg;
   const int T = p.Tmax, sd = p.sd;
@@ -85,7 +105,10 @@ __device__ __forceinline__ void fir_tiles(const Problem &p, const Args &a, const
   const bool lane_ok = lane < nd;
   const int d = d0 + (lane_ok ? lane : nd - 1);
   const int t0 = tile * TT;
-  if (t0 + TT <= EW || t0 >= T - EW) return;  // every row of the tile belongs to fir_ends
+  if (t0 + TT <= EW || t0 >= T - EW) {  // every row of the tile belongs to fir_ends
+    if (MSE && !BWD && lane == 0) *part = 0.0;
+    return;
+  }
   const int nw = a.nw, mw = a.mw;
   const __amdgpu_buffer_rsrc_t irs = make_rsrc(BWD ? (const float *)p.grad_out + (size_t)b * T * p.ld_gout + d0
                                                    : (const float *)p.mean + (size_t)b * T * p.ld_in + d0);
@@ -200,7 +223,34 @@ __device__ __forceinline__ void fir_tiles(const Problem &p, const Args &a, const
   // (opaque, and behind the first output: else the offsets and masks of every store are computed at the top of the kernel and spill)
   int t0e = t0;
   asm volatile("" : "+s"(t0e), "+v"(out[0]));
-  if (!BWD) {
+  if (!BWD && MSE) {
+    // y is stored if asked for; dy = scale (y - target) to the step's buffer; (y - target)^2 summed over this tile's own rows
+    const __amdgpu_buffer_rsrc_t trs = make_rsrc(a.target + (size_t)b * T * sd + d0);
+    const __amdgpu_buffer_rsrc_t drs = make_rsrc(a.dy + (size_t)b * T * sd + d0);
+    const unsigned yoff = a.y_given ? soff_ok : kDrop;
+    float tg[TT];
+#pragma unroll
+    for (int r = 0; r < TT; ++r) {
+      const int t = t0e + r;
+      tg[r] = ld_f32(trs, (unsigned)(t < T ? t : 0) * win_bytes, (unsigned)(t - EW) < (unsigned)(T - 2 * EW) ? soff_ok : kDrop);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float ls = 0.0f;
+#pragma unroll
+    for (int r = 0; r < TT; ++r) {
+      const int t = t0e + r;
+      const bool mine = (unsigned)(t - EW) < (unsigned)(T - 2 * EW);
+      const unsigned so = mine ? soff_ok : kDrop;
+      const float e = out[r] - tg[r];
+      const float em = so == kDrop ? 0.0f : e;
+      st_f32(ors, (unsigned)(t < T ? t : 0) * ldo_bytes, mine ? yoff : kDrop, out[r]);
+      st_f32(drs, (unsigned)(t < T ? t : 0) * win_bytes, so, a.scale * e);
+      ls = __builtin_fmaf(em, em, ls);
+      if (r % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    const double tot = wave_sum((double)ls);
+    if (lane == 0) *part = tot;
+  } else if (!BWD) {
 #pragma unroll
     for (int r = 0; r < TT; ++r) {
       const int t = t0e + r;
@@ -233,7 +283,7 @@ __device__ __forceinline__ void fir_tiles(const Problem &p, const Args &a, const
 // Rows are counted from the end (j = 0 is the first / last frame; the table's rows for the last frames are stored mirrored, so both
 // ends run the same code).  Eight wavefronts share the rows: right-hand side and filter outputs through LDS, H rows of zeros in front
 // of the right-hand side standing for the frames beyond the end.  No condition inside the loops.
-template <bool BWD, int EXT>
+template <bool BWD, int EXT, bool MSE>
 __device__ __forceinline__ void fir_ends(const Problem &p, const Args &a, const unsigned blk) {
   constexpr int H = kH, E = kE, NWV = kW;
   constexpr int EW = BWD ? E + EXT : E;            // rows written
@@ -327,6 +377,26 @@ __device__ __forceinline__ void fir_ends(const Problem &p, const Args &a, const 
     if (j < NZ) lz[j][lane] = s0 + s1;
   }
   __syncthreads();
+  if (MSE && !BWD) {
+    float ls = 0.0f;
+#pragma unroll
+    for (int j0 = 0; j0 < EW; j0 += NWV) {
+      const int j = j0 + wv;
+      if (j >= EW) continue;
+      const int t = frame(j);
+      if (lane_ok) {
+        const float y = lz[j][lane];
+        const size_t at = ((size_t)b * T + t) * sd + d;
+        const float e = y - a.target[at];
+        if (a.y_given) obase[(size_t)t * p.ld_out] = y;
+        a.dy[at] = a.scale * e;
+        ls = __builtin_fmaf(e, e, ls);
+      }
+    }
+    const double tot = wave_sum((double)ls);
+    if (lane == 0) a.partials[(size_t)blockIdx.x * kW + wv] = tot;
+    return;
+  }
   if (!lane_ok) return;
 #pragma unroll
   for (int j0 = 0; j0 < EW; j0 += NWV) {
@@ -355,11 +425,21 @@ __device__ __forceinline__ void fir_ends(const Problem &p, const Args &a, const 
 
 // One launch: the first 2 nsg workgroups take the ends (three dependent phases: they start first), the others eight tiles each.
 // 64 utterances x 500 frames: 128 + 128 workgroups of eight wavefronts, one per CU.
-template <bool BWD, int EXT>
+// MSE (the training step, mlpg_hip_unit_mse_step): see Args; the backward launch has one more workgroup, which adds up the loss.
+template <bool BWD, int EXT, bool MSE>
 __global__ __launch_bounds__(kW * 64, 1) void fir_kernel(const Problem p, const Args a) {
   const unsigned nends = 2u * (unsigned)a.nsg;
-  if (blockIdx.x < nends) fir_ends<BWD, EXT>(p, a, blockIdx.x);
-  else fir_tiles<BWD, EXT>(p, a, blockIdx.x - nends);
+  if (MSE && BWD && blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x < 64) {
+      double s = 0.0;
+      for (int i = (int)threadIdx.x; i < a.npart; i += 64) s += a.partials[i];
+      s = wave_sum(s);
+      if (threadIdx.x == 0) *a.loss = s * a.inv_n;
+    }
+    return;
+  }
+  if (blockIdx.x < nends) fir_ends<BWD, EXT, MSE>(p, a, blockIdx.x);
+  else fir_tiles<BWD, EXT, MSE>(p, a, blockIdx.x - nends);
 }
 
 // ---- the tap table: once per (device, window set) ----
@@ -477,12 +557,9 @@ bool fir_preferred(const Problem &p, bool backward) {
   return backward || (long)p.B * ((p.sd + 63) / 64) < 256;
 }
 
-int launch_fir(hipStream_t st, bool backward, const Problem &p, const WinSet &ws, int device) {
-  using namespace fir;
-  const Table *tb = table_for(st, device, ws);
-  if (!tb || !tb->ok) return kFirNotApplicable;
-  Args a;
-  a.tap = tb->dev;
+namespace fir {
+void fill_args(Args &a, const float *tap, const Problem &p, const WinSet &ws) {
+  a.tap = tap;
   a.ndg = (p.sd + 63) / 64;
   a.dgw = (p.sd + a.ndg - 1) / a.ndg;
   a.nsg = p.B * a.ndg;
@@ -496,15 +573,80 @@ int launch_fir(hipStream_t st, bool backward, const Problem &p, const WinSet &ws
     a.narrow[w] = (ws.l[w] == 0 && ws.u[w] == 0) ? 1 : 0;
     for (int k = -ws.l[w]; k <= ws.u[w]; ++k) a.cpad[w][k + kEXT] = (float)ws.c[ws.off[w] + ws.l[w] + k];
   }
+  a.target = nullptr;
+  a.dy = nullptr;
+  a.partials = nullptr;
+  a.loss = nullptr;
+  a.scale = 0.0f;
+  a.inv_n = 0.0;
+  a.npart = 0;
+  a.y_given = 1;
+}
+unsigned grid_of(const Args &a) { return (unsigned)(2 * a.nsg + ((long)a.nsg * a.nt + kW - 1) / kW); }
+size_t align128(size_t n) { return (n + 127) / 128 * 128; }
+}  // namespace fir
+
+// The training step's workspace in this form: [128 bytes: the wave-per-system kernel's counter, untouched][one double per wavefront of
+// the forward launch][dy, (B, Tmax, sd) float32].
+size_t fir_mse_workspace_bytes(int B, int Tmax, int sd) {
+  using namespace fir;
+  const long ndg = (sd + 63) / 64, nsg = B * ndg, nt = (Tmax + kTT - 1) / kTT;
+  const size_t npart = (size_t)(2 * nsg + (nsg * nt + kW - 1) / kW) * kW;
+  return 128 + align128(npart * sizeof(double)) + align128((size_t)B * Tmax * sd * sizeof(float));
+}
+
+// forward + MSE + backward of mlpg_hip_unit_mse_step as two launches (p: mean, ld_in = D; out = grad_mean, ld_out = D).
+int launch_fir_mse(hipStream_t st, const Problem &p, const WinSet &ws, int device, const void *target, void *y_out, double n_elems,
+                   double *loss, void *workspace) {
+  using namespace fir;
+  const Table *tb = table_for(st, device, ws);
+  if (!tb || !tb->ok) return kFirNotApplicable;
+  Args a;
+  fill_args(a, tb->dev, p, ws);
+  const unsigned nblk = grid_of(a);
+  a.npart = (int)(nblk * kW);
+  a.target = (const float *)target;
+  a.partials = (double *)((char *)workspace + 128);
+  a.dy = (float *)((char *)workspace + 128 + align128((size_t)a.npart * sizeof(double)));
+  a.loss = loss;
+  a.scale = (float)(2.0 / n_elems);
+  a.inv_n = 1.0 / n_elems;
+  a.y_given = y_out ? 1 : 0;
+  Problem pf = p, pb = p;
+  pf.out = y_out;
+  pf.ld_out = p.sd;
+  pb.mean = nullptr;
+  pb.grad_out = a.dy;
+  pb.ld_gout = p.sd;
   note_launch(kCountFir);
-  const long items = (long)a.nsg * a.nt;
-  const dim3 grid((unsigned)(2 * a.nsg + (items + kW - 1) / kW)), block(kW * 64);
-  if (ws.mw <= 1) {  // (extent 0 or 1: the instance with 3 instead of 5 taps per window)
-    if (backward) hipLaunchKernelGGL((fir_kernel<true, 1>), grid, block, 0, st, p, a);
-    else hipLaunchKernelGGL((fir_kernel<false, 1>), grid, block, 0, st, p, a);
+  note_launch(kCountFir);
+  const dim3 block(kW * 64);
+  if (ws.mw <= 1) {
+    hipLaunchKernelGGL((fir_kernel<false, 1, true>), dim3(nblk), block, 0, st, pf, a);
+    hipLaunchKernelGGL((fir_kernel<true, 1, true>), dim3(nblk + 1), block, 0, st, pb, a);
   } else {
-    if (backward) hipLaunchKernelGGL((fir_kernel<true, 2>), grid, block, 0, st, p, a);
-    else hipLaunchKernelGGL((fir_kernel<false, 2>), grid, block, 0, st, p, a);
+    hipLaunchKernelGGL((fir_kernel<false, 2, true>), dim3(nblk), block, 0, st, pf, a);
+    hipLaunchKernelGGL((fir_kernel<true, 2, true>), dim3(nblk + 1), block, 0, st, pb, a);
+  }
+  MLPG_HIP_CHECK(hipGetLastError());
+  if (p.status) MLPG_HIP_CHECK(hipMemset2DAsync(p.status, (size_t)p.ld_status * sizeof(int32_t), 0, (size_t)p.sd * sizeof(int32_t), (size_t)p.B, st));
+  return 0;
+}
+
+int launch_fir(hipStream_t st, bool backward, const Problem &p, const WinSet &ws, int device) {
+  using namespace fir;
+  const Table *tb = table_for(st, device, ws);
+  if (!tb || !tb->ok) return kFirNotApplicable;
+  Args a;
+  fill_args(a, tb->dev, p, ws);
+  note_launch(kCountFir);
+  const dim3 grid(grid_of(a)), block(kW * 64);
+  if (ws.mw <= 1) {  // (extent 0 or 1: the instance with 3 instead of 5 taps per window)
+    if (backward) hipLaunchKernelGGL((fir_kernel<true, 1, false>), grid, block, 0, st, p, a);
+    else hipLaunchKernelGGL((fir_kernel<false, 1, false>), grid, block, 0, st, p, a);
+  } else {
+    if (backward) hipLaunchKernelGGL((fir_kernel<true, 2, false>), grid, block, 0, st, p, a);
+    else hipLaunchKernelGGL((fir_kernel<false, 2, false>), grid, block, 0, st, p, a);
   }
   MLPG_HIP_CHECK(hipGetLastError());
   // (P = c_0^2 I + a sum of squares is positive definite whatever the windows: every verdict is 0)

@@ -31,7 +31,7 @@ def test_exports_match_header(L):
     assert declared == set(_hip.EXPORTS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.mlpg_hip_abi_version() == _hip.ABI_VERSION == 11
+    assert L.mlpg_hip_abi_version() == _hip.ABI_VERSION == 12
 
 
 def test_argument_validation_without_gpu(L):
@@ -190,7 +190,7 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, env=env)
     assert out.returncode == 0, out.stdout
-    assert out.stdout.split() == ["11", "5", "3"], out.stdout
+    assert out.stdout.split() == ["12", "5", "3"], out.stdout
 
 
 def test_host_chunk_plan_deals_round_robin_and_covers_the_batch():
