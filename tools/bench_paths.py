@@ -321,6 +321,8 @@ def _run(only, quick, device_index):
 
         ms_fused = gpu_time(step_fused, steps=20)
         ms_fused_kernel = gpu_time(lambda: _hip.unit_mse_step(md, target, WINDOWS), steps=20)
+        full = torch.full((B,), T, dtype=torch.int32, device=dev)     # (a lengths vector keeps the call on the one-launch kernel)
+        ms_one_launch = gpu_time(lambda: _hip.unit_mse_step(md, target, WINDOWS, lengths=full), steps=20)
         ms_fused_graph = None
         try:
             torch.cuda.synchronize()
@@ -339,9 +341,10 @@ def _run(only, quick, device_index):
             ms_fused_graph = gpu_time(g2.replay, steps=20)
         except Exception as e:  # noqa: BLE001
             ms_fused_graph = "capture failed: %s" % str(e)[:120]
-        emit(path="c3-fused-unit-mse-step", ms=ms_fused_kernel, ms_autograd_eager=ms_fused, ms_hip_graph_replay=ms_fused_graph,
+        emit(path="c3-fused-unit-mse-step", ms=ms_fused_kernel, ms_one_launch_kernel=ms_one_launch, ms_autograd_eager=ms_fused, ms_hip_graph_replay=ms_fused_graph,
              frames_per_s=B * T / ms_fused_kernel * 1e3, alg_bytes=by + 4.0 * 60 * B * T, GBps=(by + 4.0 * 60 * B * T) / ms_fused_kernel / 1e6,
-             note="ms = one mlpg_hip_unit_mse_step call (one kernel, nothing allocated): forward + MSE loss + backward of config 3; "
+             note="ms = one mlpg_hip_unit_mse_step call (float32 without lengths: the FIR form, two launches, nothing allocated; "
+                  "ms_one_launch_kernel: the wave-per-system kernel that takes the call when lengths are given): forward + MSE loss + backward of config 3; "
                   "ms_autograd_eager / ms_hip_graph_replay = the same through autograd.unit_variance_mlpg_mse_loss(...).backward()")
         emit(path="c3-unit-variance-autograd-fwd+bwd", ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by,
              GBps=by / ms / 1e6, ms_hip_graph_replay=ms_graph,
