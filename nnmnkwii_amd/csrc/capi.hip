@@ -373,6 +373,7 @@ __attribute__((visibility("default"))) void mlpg_hip_shutdown(void) {
     delete g_side[d];
     g_side[d] = nullptr;
   }
+  fir_shutdown();
   host_api_shutdown();
   if (prev >= 0) (void)hipSetDevice(prev);
 }

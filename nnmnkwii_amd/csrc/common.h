@@ -104,6 +104,7 @@ int launch_chunk(hipStream_t s, int dtype, int out_dtype, bool backward, const P
 constexpr int kFirNotApplicable = -2000;
 bool fir_shape_supported(const Problem &p, const WinSet &w, int in_dtype, int out_dtype);
 bool fir_preferred(const Problem &p, bool backward);
+void fir_shutdown();
 int launch_fir(hipStream_t s, bool backward, const Problem &p, const WinSet &w, int device);
 size_t fir_mse_workspace_bytes(int B, int Tmax, int sd);
 int launch_fir_mse(hipStream_t s, const Problem &p, const WinSet &w, int device, const void *target, void *y_out, double n_elems,

@@ -553,6 +553,17 @@ bool fir_shape_supported(const Problem &p, const WinSet &ws, int in_dtype, int o
 
 // Measured (profiles/r04_notes.md section 11): backward it is the fastest kernel at 64 and at 256 utterances; forward the
 // constant-coefficient kernel (one workgroup per sequence) overtakes it once there are sequences enough to fill the chip with those.
+// mlpg_hip_shutdown: the tap tables
+void fir_shutdown() {
+  std::lock_guard<std::mutex> lk(fir::g_mu);
+  for (auto &kv : fir::g_tables) {
+    if (!kv.second.dev) continue;
+    (void)hipSetDevice(kv.first.first);
+    (void)hipFree(kv.second.dev);
+  }
+  fir::g_tables.clear();
+}
+
 bool fir_preferred(const Problem &p, bool backward) {
   return backward || (long)p.B * ((p.sd + 63) / 64) < 256;
 }
