@@ -12,7 +12,9 @@
 // not decay to 2^-26 within 24 taps is refused and the other kernels take the call.
 // Backward (autograd/_impl/mlpg.py:145-172: R^T grad): z = P^-1 grad_out by the same table (P^-1 is symmetric), then
 // grad[t, w] = m_w[t] sum_k c_w[l + k] z[t + k].
-// Float32 in, float32 out, float32 arithmetic (the reference's is a float32 GEMM over 3 T terms; here 49 terms in four partial sums).
+// Float32 in, float32 out, float32 arithmetic (the reference's is a float32 GEMM over 3 T terms; here 49 terms per row, two rows per
+// v_pk_fma_f32).  One launch: the first 2 nsg workgroups take the ends, the others eight tiles each (fir_kernel at the end of the device
+// code).  The MSE instances are the training step mlpg_hip_unit_mse_step in this form (launch_fir_mse): two launches.
 #include <algorithm>
 #include <cmath>
 #include <map>
@@ -35,7 +37,6 @@ struct Args {
   const float *tap;  // [kRows][kTaps]: row 0 interior, 1..E rows t = 0..E-1, E+1..2E rows T-1 .. T-E with their taps in reverse order
   int ndg, dgw, nsg, nt;  // dim groups per utterance, dims per group, (utterance, dim group) pairs, tiles per utterance
   int nw, mw;
-  int narrow[kMaxNw];
   float cpad[kMaxNw][2 * kEXT + 1];  // window coefficients, zero padded to [-2, 2]
   // the training step (MSE instances): forward writes dy = scale (y - target) and one partial sum of (y - target)^2 per wavefront,
   // backward reads dy; its last workgroup adds the partials up in a fixed order
@@ -49,7 +50,6 @@ struct Args {
   int y_given;          // forward: p.out holds y_out (else the trajectory is not stored)
 };
 
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
   const unsigned long long u = (unsigned long long)base;
@@ -578,10 +578,8 @@ void fill_args(Args &a, const float *tap, const Problem &p, const WinSet &ws) {
   a.nw = ws.nw;
   a.mw = ws.mw;
   for (int w = 0; w < kMaxNw; ++w) {
-    a.narrow[w] = 0;
     for (int j = 0; j <= 2 * kEXT; ++j) a.cpad[w][j] = 0.0f;
     if (w >= ws.nw) continue;
-    a.narrow[w] = (ws.l[w] == 0 && ws.u[w] == 0) ? 1 : 0;
     for (int k = -ws.l[w]; k <= ws.u[w]; ++k) a.cpad[w][k + kEXT] = (float)ws.c[ws.off[w] + ws.l[w] + k];
   }
   a.target = nullptr;
