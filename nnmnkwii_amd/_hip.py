@@ -713,7 +713,9 @@ _MSE_WORKSPACE_RETIRED = []   # outgrown workspaces stay allocated: a captured g
 
 def unit_mse_step(mean, target, windows, lengths=None, n_elems=None, want_y=False, want_status=False):
     """Fused unit-variance MLPG + MSE training step on device tensors (mlpg_hip_unit_mse_step): mean (B, T, D), target
-    (B, T, D / nw), float32 or float64.  Returns (loss float64 0-dim tensor, grad_mean (B, T, D), y or None, status or None)."""
+    (B, T, D / nw), float32 or float64.  Returns (loss float64 0-dim tensor, grad_mean (B, T, D), y or None, status or None).
+    One launch (the wave-per-system kernel: window extents <= 1, T <= 1024), or two in the FIR form (float32, no lengths, T >= 96,
+    window extents <= 2, any T)."""
     torch = torch_mod()
     assert mean.is_cuda and mean.dim() == 3 and mean.is_contiguous() and target.is_contiguous()
     B, T, D = mean.shape
