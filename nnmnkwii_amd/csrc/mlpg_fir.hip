@@ -235,10 +235,12 @@ __device__ __forceinline__ void fir_tiles(const Problem &p, const Args &a, const
       tg[r] = ld_f32(trs, (unsigned)(t < T ? t : 0) * win_bytes, (unsigned)(t - EW) < (unsigned)(T - 2 * EW) ? soff_ok : kDrop);
     }
     __builtin_amdgcn_sched_barrier(0);
+    int t0f = t0e;  // (opaque again: else the 32 row masks of the loads above are kept in scalar registers for the stores, and spill)
+    asm volatile("" : "+s"(t0f));
     float ls = 0.0f;
 #pragma unroll
     for (int r = 0; r < TT; ++r) {
-      const int t = t0e + r;
+      const int t = t0f + r;
       const bool mine = (unsigned)(t - EW) < (unsigned)(T - 2 * EW);
       const unsigned so = mine ? soff_ok : kDrop;
       const float e = out[r] - tg[r];
