@@ -51,6 +51,9 @@ struct Args {
 };
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+// Raw buffer access: address = base + soff (scalar: the frame's row) + loff (per lane: the dim).  The hardware checks loff -- not soff --
+// against the descriptor's 2^31 - 1 bytes; the kernels use that as their mask: with loff = 0x80000000 a load returns 0 and a store is
+// dropped, without a branch and without a select on the data (rows_fit_buffer keeps every real offset below 2^31).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
   const unsigned long long u = (unsigned long long)base;
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -63,6 +66,12 @@ __device__ __forceinline__ void st_f32(__amdgpu_buffer_rsrc_t rs, unsigned soff,
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, loff, soff, 0);
 }
 
+__device__ __forceinline__ double wave_sum(double v) {  // lanes added in a fixed order
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 // fir_tiles: one wavefront = one tile of kTT frames of one (utterance, dim group), every row with the INTERIOR taps.
 // Written for a wavefront that is alone on its SIMD (64 utterances x 16 tiles = one wavefront per SIMD of the chip):
 //   - branch-free: a frame outside the utterance is read from the nearest frame inside and enters with coefficient 0 (the
@@ -71,12 +80,6 @@ __device__ __forceinline__ void st_f32(__amdgpu_buffer_rsrc_t rs, unsigned soff,
 //     flight and the tile costs 84 round trips);
 //   - the taps sit in the lanes of one register and are read out one at a time (v_readlane): 49 scalars held live cost more scalar
 //     registers than there are, and the reloads from the kernel arguments that followed cost more than the arithmetic.
-__device__ __forceinline__ double wave_sum(double v) {  // lanes added in a fixed order
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
 template <bool BWD, int EXT, bool MSE>
 __device__ __forceinline__ void fir_tiles(const Problem &p, const Args &a, const unsigned blk) {
   constexpr int H = kH, E = kE, TT = kTT;
