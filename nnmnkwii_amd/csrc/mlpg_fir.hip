@@ -17,6 +17,7 @@
 // code).  The MSE instances are the training step mlpg_hip_unit_mse_step in this form (launch_fir_mse): two launches.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -284,6 +285,213 @@ __device__ __forceinline__ void fir_tiles(const Problem &p, const Args &a, const
   }
 }
 
+// fir_tiles_shared (round 5: the forward launches' tile form, see shared_tiles(); parity 73 tests + 2 368 soak cases on the GPU,
+// numpy model of its index logic: tools/experimental/fir_shared/model.py): the eight tiles of a workgroup are eight
+// consecutive tiles of ONE (utterance, dim group) and share the right-hand side through LDS.  Phase A: wavefront v forms rows
+// [v RPW, (v + 1) RPW) of the NROW = 8 * 32 + 2 H (+ 2 EXT backward) rows the group needs -- 40 frames x nw loads and 38 x 7 products
+// instead of 84 x nw and 82 x 7 per tile; phase B: every wavefront reads its 80 (84) rows back as register PAIRS (rows are 256 bytes
+// apart: ds_read2st64_b32 returns rows r, r + 1 in one instruction, so the even and the odd pairs cost no copies) and runs the taps.
+template <bool BWD, int EXT, bool MSE>
+__device__ __forceinline__ void fir_tiles_shared(const Problem &p, const Args &a, const unsigned blk) {
+  constexpr int H = kH, E = kE, TT = kTT, NWV = kW;
+  constexpr int NO = BWD ? TT + 2 * EXT : TT;
+  constexpr int NB = NO + 2 * H;                   // right-hand-side rows under the taps of one tile
+  constexpr int XB = BWD ? EXT : 0;
+  constexpr int NROW = NWV * TT + 2 * H + 2 * XB;  // rows the group shares: frames F0 - H - XB .. F0 + 8 TT + H + XB - 1
+  constexpr int RPW = (NROW + NWV - 1) / NWV;      // rows per wavefront in phase A
+  constexpr int NFA = BWD ? RPW : RPW + 2 * EXT;   // frames a wavefront reads in phase A
+  constexpr int EW = BWD ? E + EXT : E;
+  constexpr int FB = 14;
+  constexpr int NQ = (NFA + FB - 1) / FB;
+  static_assert(NB % 2 == 0 && NO % 2 == 0, "row pairs");
+  constexpr unsigned kDrop = 0x80000000u;
+  __shared__ float lb[RPW * NWV][64];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ngt = (a.nt + NWV - 1) / NWV;          // groups of eight tiles per (utterance, dim group)
+  const int g = (int)(blk / (unsigned)ngt), grp = (int)(blk - (unsigned)g * (unsigned)ngt);
+  double *const part = a.partials + (size_t)blockIdx.x * kW + wv;
+  const int b = g / a.ndg, dg = g - b * a.ndg;
+  const int T = p.Tmax, sd = p.sd;
+  const int d0 = dg * a.dgw;
+  const int nd = sd - d0 < a.dgw ? sd - d0 : a.dgw;
+  const bool lane_ok = lane < nd;
+  const int d = d0 + (lane_ok ? lane : nd - 1);
+  const int F0 = grp * NWV * TT;
+  const int tile = grp * NWV + wv;
+  const int t0 = tile * TT;
+  const int nw = a.nw, mw = a.mw;
+  const __amdgpu_buffer_rsrc_t irs = make_rsrc(BWD ? (const float *)p.grad_out + (size_t)b * T * p.ld_gout + d0
+                                                   : (const float *)p.mean + (size_t)b * T * p.ld_in + d0);
+  const __amdgpu_buffer_rsrc_t ors = make_rsrc((float *)p.out + (size_t)b * T * p.ld_out + d0);
+  const unsigned loff = (unsigned)(d - d0) * 4u;
+  const unsigned soff_ok = lane_ok ? loff : kDrop;
+  const unsigned ldi_bytes = (unsigned)(BWD ? p.ld_gout : p.ld_in) * 4u, ldo_bytes = (unsigned)p.ld_out * 4u, win_bytes = (unsigned)sd * 4u;
+  const float tapv = a.tap[lane < kTaps ? lane : 0];
+  int lo[kMaxNw];
+  unsigned span[kMaxNw];
+#pragma unroll
+  for (int w = 0; w < kMaxNw; ++w) {
+    lo[w] = w == 0 ? 0 : mw;
+    span[w] = w >= nw ? 0u : (w == 0 ? (unsigned)T : (mw != 0 && T > 2 * mw ? (unsigned)(T - 2 * mw) : 0u));
+  }
+  float cw[kMaxNw][2 * EXT + 1];
+#pragma unroll
+  for (int w = 0; w < kMaxNw; ++w)
+#pragma unroll
+    for (int k = 0; k <= 2 * EXT; ++k) cw[w][k] = a.cpad[w][k + kEXT - EXT];
+
+  // ---- phase A: rows [wv RPW, (wv + 1) RPW) of the shared right-hand side; row r <-> frame F0 - H - XB + r ----
+  {
+    const int fA = F0 - H - XB + wv * RPW;         // frame of this wavefront's first row
+    const int f_first = fA - (BWD ? 0 : EXT);      // first frame read
+    if (BWD) {
+      float v[RPW];
+#pragma unroll
+      for (int s = 0; s < RPW; ++s) {
+        const int t = f_first + s;
+        const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        v[s] = ld_f32(irs, (unsigned)tc * ldi_bytes, (unsigned)t < (unsigned)T ? loff : kDrop);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < RPW; ++s) lb[wv * RPW + s][lane] = v[s];
+    } else {
+      float bbA[RPW];
+      float mu[2][FB][kMaxNw];
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) bbA[i] = 0.0f;
+#pragma unroll
+      for (int q = -1; q < NQ; ++q) {
+        if (q + 1 < NQ) {
+          int fq = f_first + (q + 1) * FB;
+          asm volatile("" : "+s"(fq));
+#pragma unroll
+          for (int s = 0; s < FB; ++s) {
+            if ((q + 1) * FB + s >= NFA) continue;
+            const int t = fq + s;
+            const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+#pragma unroll
+            for (int w = 0; w < kMaxNw; ++w) {
+              const bool lv = (unsigned)(t - lo[w]) < span[w];
+              mu[(q + 1) & 1][s][w] = ld_f32(irs, (unsigned)tc * ldi_bytes + (unsigned)(w < nw ? w : 0) * win_bytes, lv ? loff : kDrop);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (q >= 0) {
+#pragma unroll
+          for (int sl = 0; sl < FB; ++sl) {
+            const int s = q * FB + sl;
+            if (s >= NFA) continue;
+#pragma unroll
+            for (int w = 0; w < kMaxNw; ++w) {
+              const float m = mu[q & 1][sl][w];
+#pragma unroll
+              for (int k = -EXT; k <= EXT; ++k) {
+                const int ib = s - EXT + k;
+                if (ib < 0 || ib >= RPW) continue;
+                if (w == 0 && k != 0) continue;
+                bbA[ib] = __builtin_fmaf(cw[w][k + EXT], m, bbA[ib]);
+              }
+            }
+            // the row this frame completes goes to LDS (a store: nothing for the compiler to sink)
+            if (s - 2 * EXT >= 0 && s - 2 * EXT < RPW) lb[wv * RPW + s - 2 * EXT][lane] = bbA[s - 2 * EXT];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tile >= a.nt || t0 + TT <= EW || t0 >= T - EW) {  // no such tile, or every row of it belongs to fir_ends
+    if (MSE && !BWD && lane == 0) *part = 0.0;
+    return;
+  }
+
+  // ---- phase B: this tile's NB rows start at shared row wv TT; pairs from even and from odd rows ----
+  float out[NO];
+  f32x2 be[NB / 2], bo[NB / 2 - 1], o2[NO / 2];
+#pragma unroll
+  for (int i = 0; i < NB / 2; ++i) be[i] = f32x2{lb[wv * TT + 2 * i][lane], lb[wv * TT + 2 * i + 1][lane]};
+#pragma unroll
+  for (int i = 0; i < NB / 2 - 1; ++i) bo[i] = f32x2{lb[wv * TT + 2 * i + 1][lane], lb[wv * TT + 2 * i + 2][lane]};
+#pragma unroll
+  for (int j = 0; j < NO / 2; ++j) o2[j] = f32x2{0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < kTaps; ++k) {
+    const float tk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tapv), k));
+    const f32x2 t2 = f32x2{tk, tk};
+#pragma unroll
+    for (int j = 0; j < NO / 2; ++j) o2[j] = __builtin_elementwise_fma(t2, (k & 1) ? bo[j + (k - 1) / 2] : be[j + k / 2], o2[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NO / 2; ++j) {
+    out[2 * j] = o2[j].x;
+    out[2 * j + 1] = o2[j].y;
+  }
+
+  // (opaque, and behind the first output: else the offsets and masks of every store are computed at the top of the kernel and spill)
+  int t0e = t0;
+  asm volatile("" : "+s"(t0e), "+v"(out[0]));
+  if (!BWD && MSE) {
+    // y is stored if asked for; dy = scale (y - target) to the step's buffer; (y - target)^2 summed over this tile's own rows
+    const __amdgpu_buffer_rsrc_t trs = make_rsrc(a.target + (size_t)b * T * sd + d0);
+    const __amdgpu_buffer_rsrc_t drs = make_rsrc(a.dy + (size_t)b * T * sd + d0);
+    const unsigned yoff = a.y_given ? soff_ok : kDrop;
+    float tg[TT];
+#pragma unroll
+    for (int r = 0; r < TT; ++r) {
+      const int t = t0e + r;
+      tg[r] = ld_f32(trs, (unsigned)(t < T ? t : 0) * win_bytes, (unsigned)(t - EW) < (unsigned)(T - 2 * EW) ? soff_ok : kDrop);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int t0f = t0e;
+    asm volatile("" : "+s"(t0f));
+    float ls = 0.0f;
+#pragma unroll
+    for (int r = 0; r < TT; ++r) {
+      const int t = t0f + r;
+      const bool mine = (unsigned)(t - EW) < (unsigned)(T - 2 * EW);
+      const unsigned so = mine ? soff_ok : kDrop;
+      const float e = out[r] - tg[r];
+      const float em = so == kDrop ? 0.0f : e;
+      st_f32(ors, (unsigned)(t < T ? t : 0) * ldo_bytes, mine ? yoff : kDrop, out[r]);
+      st_f32(drs, (unsigned)(t < T ? t : 0) * win_bytes, so, a.scale * e);
+      ls = __builtin_fmaf(em, em, ls);
+      if (r % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    const double tot = wave_sum((double)ls);
+    if (lane == 0) *part = tot;
+  } else if (!BWD) {
+#pragma unroll
+    for (int r = 0; r < TT; ++r) {
+      const int t = t0e + r;
+      st_f32(ors, (unsigned)(t < T ? t : 0) * ldo_bytes, (unsigned)(t - EW) < (unsigned)(T - 2 * EW) ? soff_ok : kDrop, out[r]);
+      if (r % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // (else every offset is computed up front and the scalars spill)
+    }
+  } else {
+    // grad[t, w] = m_w[t] sum_k c_w[l + k] z[t + k];  z of frame t0 + r + k is out[r + EXT + k]
+#pragma unroll
+    for (int r = 0; r < TT; ++r) {
+      const int t = t0e + r;
+      const bool mine = (unsigned)(t - EW) < (unsigned)(T - 2 * EW);
+#pragma unroll
+      for (int w = 0; w < kMaxNw; ++w) {
+        const bool lv = (unsigned)(t - lo[w]) < span[w];
+        float gsum = 0.0f;
+#pragma unroll
+        for (int k = -EXT; k <= EXT; ++k) {
+          if (w == 0 && k != 0) continue;
+          gsum = __builtin_fmaf(cw[w][k + EXT], out[r + EXT + k], gsum);
+        }
+        st_f32(ors, (unsigned)(t < T ? t : 0) * ldo_bytes + (unsigned)(w < nw ? w : 0) * win_bytes, (mine && w < nw) ? soff_ok : kDrop, lv ? gsum : 0.0f);
+      }
+      if (r % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // (else every offset is computed up front and the scalars spill)
+    }
+  }
+}
+
 // fir_ends: one workgroup per (utterance, dim group, end): the EW rows at that end, whose taps come from the table.
 // Rows are counted from the end (j = 0 is the first / last frame; the table's rows for the last frames are stored mirrored, so both
 // ends run the same code).  Eight wavefronts share the rows: right-hand side and filter outputs through LDS, H rows of zeros in front
@@ -431,7 +639,7 @@ __device__ __forceinline__ void fir_ends(const Problem &p, const Args &a, const 
 // One launch: the first 2 nsg workgroups take the ends (three dependent phases: they start first), the others eight tiles each.
 // 64 utterances x 500 frames: 128 + 128 workgroups of eight wavefronts, one per CU.
 // MSE (the training step, mlpg_hip_unit_mse_step): see Args; the backward launch has one more workgroup, which adds up the loss.
-template <bool BWD, int EXT, bool MSE>
+template <bool BWD, int EXT, bool MSE, bool SHARED = false>
 __global__ __launch_bounds__(kW * 64, 1) void fir_kernel(const Problem p, const Args a) {
   const unsigned nends = 2u * (unsigned)a.nsg;
   if (MSE && BWD && blockIdx.x == gridDim.x - 1) {
@@ -444,6 +652,7 @@ __global__ __launch_bounds__(kW * 64, 1) void fir_kernel(const Problem p, const 
     return;
   }
   if (blockIdx.x < nends) fir_ends<BWD, EXT, MSE>(p, a, blockIdx.x);
+  else if (SHARED) fir_tiles_shared<BWD, EXT, MSE>(p, a, blockIdx.x - nends);
   else fir_tiles<BWD, EXT, MSE>(p, a, blockIdx.x - nends);
 }
 
@@ -596,7 +805,22 @@ void fill_args(Args &a, const float *tap, const Problem &p, const WinSet &ws) {
   a.npart = 0;
   a.y_given = 1;
 }
-unsigned grid_of(const Args &a) { return (unsigned)(2 * a.nsg + ((long)a.nsg * a.nt + kW - 1) / kW); }
+// Which tile form a launch takes.  Measured in round 5 (profiles/r05_notes.md; config 3 / 256 x 1000 x 60, kernel durations):
+// the tiles of a workgroup sharing the right-hand side through LDS (fir_tiles_shared) take the forward pass from 17.0 to 13.5 us
+// / 0.083 to 0.072 ms, the backward pass gains nothing (13.9 -> 13.7 us) or loses (0.062 -> 0.066 ms): its right-hand side is one
+// row per frame, there is little to share.  Default: forward shared, backward not.  MLPG_FIR_SHARED=0 / 1 forces one form for
+// both (A/B runs).
+bool shared_tiles(bool backward) {
+  static const int mode = [] {
+    const char *e = std::getenv("MLPG_FIR_SHARED");
+    return !e ? -1 : (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1));
+  }();
+  return mode < 0 ? !backward : mode == 1;
+}
+unsigned grid_of(const Args &a, bool shared) {
+  if (shared) return (unsigned)(2 * a.nsg + (long)a.nsg * ((a.nt + kW - 1) / kW));
+  return (unsigned)(2 * a.nsg + ((long)a.nsg * a.nt + kW - 1) / kW);
+}
 size_t align128(size_t n) { return (n + 127) / 128 * 128; }
 }  // namespace fir
 
@@ -605,7 +829,7 @@ size_t align128(size_t n) { return (n + 127) / 128 * 128; }
 size_t fir_mse_workspace_bytes(int B, int Tmax, int sd) {
   using namespace fir;
   const long ndg = (sd + 63) / 64, nsg = B * ndg, nt = (Tmax + kTT - 1) / kTT;
-  const size_t npart = (size_t)(2 * nsg + (nsg * nt + kW - 1) / kW) * kW;
+  const size_t npart = (size_t)(2 * nsg + nsg * ((nt + kW - 1) / kW)) * kW;  // (the larger of the two tile mappings)
   return 128 + align128(npart * sizeof(double)) + align128((size_t)B * Tmax * sd * sizeof(float));
 }
 
@@ -617,8 +841,9 @@ int launch_fir_mse(hipStream_t st, const Problem &p, const WinSet &ws, int devic
   if (!tb || !tb->ok) return kFirNotApplicable;
   Args a;
   fill_args(a, tb->dev, p, ws);
-  const unsigned nblk = grid_of(a);
-  a.npart = (int)(nblk * kW);
+  const bool shf = shared_tiles(false), shb = shared_tiles(true);
+  const unsigned nblk = grid_of(a, shf), nblk_b = grid_of(a, shb);
+  a.npart = (int)(nblk * kW);  // one partial sum per wavefront of the FORWARD launch
   a.target = (const float *)target;
   a.partials = (double *)((char *)workspace + 128);
   a.dy = (float *)((char *)workspace + 128 + align128((size_t)a.npart * sizeof(double)));
@@ -635,12 +860,17 @@ int launch_fir_mse(hipStream_t st, const Problem &p, const WinSet &ws, int devic
   note_launch(kCountFir);
   note_launch(kCountFir);
   const dim3 block(kW * 64);
+  // (the backward launch's last workgroup adds up the forward launch's partial sums)
   if (ws.mw <= 1) {
-    hipLaunchKernelGGL((fir_kernel<false, 1, true>), dim3(nblk), block, 0, st, pf, a);
-    hipLaunchKernelGGL((fir_kernel<true, 1, true>), dim3(nblk + 1), block, 0, st, pb, a);
+    if (shf) hipLaunchKernelGGL((fir_kernel<false, 1, true, true>), dim3(nblk), block, 0, st, pf, a);
+    else hipLaunchKernelGGL((fir_kernel<false, 1, true, false>), dim3(nblk), block, 0, st, pf, a);
+    if (shb) hipLaunchKernelGGL((fir_kernel<true, 1, true, true>), dim3(nblk_b + 1), block, 0, st, pb, a);
+    else hipLaunchKernelGGL((fir_kernel<true, 1, true, false>), dim3(nblk_b + 1), block, 0, st, pb, a);
   } else {
-    hipLaunchKernelGGL((fir_kernel<false, 2, true>), dim3(nblk), block, 0, st, pf, a);
-    hipLaunchKernelGGL((fir_kernel<true, 2, true>), dim3(nblk + 1), block, 0, st, pb, a);
+    if (shf) hipLaunchKernelGGL((fir_kernel<false, 2, true, true>), dim3(nblk), block, 0, st, pf, a);
+    else hipLaunchKernelGGL((fir_kernel<false, 2, true, false>), dim3(nblk), block, 0, st, pf, a);
+    if (shb) hipLaunchKernelGGL((fir_kernel<true, 2, true, true>), dim3(nblk_b + 1), block, 0, st, pb, a);
+    else hipLaunchKernelGGL((fir_kernel<true, 2, true, false>), dim3(nblk_b + 1), block, 0, st, pb, a);
   }
   MLPG_HIP_CHECK(hipGetLastError());
   if (p.status) MLPG_HIP_CHECK(hipMemset2DAsync(p.status, (size_t)p.ld_status * sizeof(int32_t), 0, (size_t)p.sd * sizeof(int32_t), (size_t)p.B, st));
@@ -654,8 +884,17 @@ int launch_fir(hipStream_t st, bool backward, const Problem &p, const WinSet &ws
   Args a;
   fill_args(a, tb->dev, p, ws);
   note_launch(kCountFir);
-  const dim3 grid(grid_of(a)), block(kW * 64);
-  if (ws.mw <= 1) {  // (extent 0 or 1: the instance with 3 instead of 5 taps per window)
+  const bool shared = shared_tiles(backward);
+  const dim3 grid(grid_of(a, shared)), block(kW * 64);
+  if (shared) {
+    if (ws.mw <= 1) {
+      if (backward) hipLaunchKernelGGL((fir_kernel<true, 1, false, true>), grid, block, 0, st, p, a);
+      else hipLaunchKernelGGL((fir_kernel<false, 1, false, true>), grid, block, 0, st, p, a);
+    } else {
+      if (backward) hipLaunchKernelGGL((fir_kernel<true, 2, false, true>), grid, block, 0, st, p, a);
+      else hipLaunchKernelGGL((fir_kernel<false, 2, false, true>), grid, block, 0, st, p, a);
+    }
+  } else if (ws.mw <= 1) {  // (extent 0 or 1: the instance with 3 instead of 5 taps per window)
     if (backward) hipLaunchKernelGGL((fir_kernel<true, 1, false>), grid, block, 0, st, p, a);
     else hipLaunchKernelGGL((fir_kernel<false, 1, false>), grid, block, 0, st, p, a);
   } else {

@@ -43,6 +43,8 @@
 #pragma once
 #include <string.h>
 
+#include <type_traits>
+
 #include <mutex>
 #include <vector>
 #include "assemble.h"
@@ -93,6 +95,26 @@ constexpr int kCtrlLine = 32;
 #endif
 #ifndef MLPG_STRIP_BWD_FRAME_MAJOR
 #define MLPG_STRIP_BWD_FRAME_MAJOR 1  // backward epilogue frame by frame (three adjacent row stores, ring of variance loads)
+#endif
+#ifndef MLPG_STRIP_BWD_KEEP
+#define MLPG_STRIP_BWD_KEEP 1  // backward, float32 inputs, per-frame variances: the 51 precisions of a chunk (float32 values: 1/var is
+                               // formed in float32, _mlpg.py:188) stay in registers from the assembly to the epilogue -- no second
+                               // pass over the variances, no second division (round 5)
+#endif
+#ifndef MLPG_STRIP_BWD_KARG
+#define MLPG_STRIP_BWD_KARG 1  // backward, three windows: window coefficients by placed scalar loads from the argument segment (karg_f64x6)
+#endif
+#ifndef MLPG_STRIP_BWD_KEEP0
+#define MLPG_STRIP_BWD_KEEP0 1  // ... wavefront 0 too (it runs levels 2 and 3 meanwhile and has no 51 registers to spare: it reads
+                                // its chunk's variances again)
+#endif
+#ifndef MLPG_STRIP_BWD_EARLY0
+#define MLPG_STRIP_BWD_EARLY0 0  // MLPG_STRIP_BWD_EARLY for wavefront 0 (requested behind its publish)
+#endif
+#ifndef MLPG_STRIP_BWD_EARLY
+#define MLPG_STRIP_BWD_EARLY 8  // backward, float64 inputs: the variance rows of the epilogue's first n frames are requested as soon as
+                                // level 1 is done (into the registers the ring has left), so that they travel while the strip waits for
+                                // its neighbours; the other 17 - n frames are requested in front of the first store as before (round 5)
 #endif
 #ifndef MLPG_STRIP_PREFETCH
 #define MLPG_STRIP_PREFETCH 0  // frames of the NEXT item's chunk touched (LDS-DMA loads into a dummy LDS line: no register is
@@ -335,6 +357,45 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
   return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
 }
 
+// Window coefficients straight from the kernel-argument segment, as scalar loads PLACED by the caller (backward
+// kernels, round 5).  The arguments by value are preloaded into scalar registers at kernel entry and live from there to
+// their last use; the backward instances need the six products per window in the stream AND the three coefficients per
+// window in the epilogue, together with the descriptors and the item loop's state more than the 100 scalar registers
+// there are, and the allocator's answer was to park them in lanes of a vector register and fetch them back (v_readlane)
+// in front of every use -- some 1 300 extra vector instructions per chunk.  An `asm volatile` load is neither hoisted nor
+// shared: the coefficients occupy registers from here to their last use in the same phase, and the scalar cache answers.
+typedef __attribute__((ext_vector_type(8))) unsigned u32x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ double mk_f64(unsigned lo, unsigned hi) {
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// doubles [first, first + 6) of the argument segment at byte offset `off`
+template <unsigned OFF>
+__device__ __forceinline__ void karg_f64x6(double (&d)[6]) {
+  const unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  u32x8 a;
+  u32x4 b;
+  asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b)
+               : "s"(kp), "n"(OFF), "n"(OFF + 32));
+  d[0] = mk_f64(a[0], a[1]); d[1] = mk_f64(a[2], a[3]); d[2] = mk_f64(a[4], a[5]); d[3] = mk_f64(a[6], a[7]);
+  d[4] = mk_f64(b[0], b[1]); d[5] = mk_f64(b[2], b[3]);
+}
+template <unsigned OFF>
+__device__ __forceinline__ void karg_f64x3(double (&d)[3]) {
+  const unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  u32x4 a;
+  u32x2 b;
+  asm volatile("s_load_dwordx4 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b)
+               : "s"(kp), "n"(OFF), "n"(OFF + 16));
+  d[0] = mk_f64(a[0], a[1]); d[1] = mk_f64(a[2], a[3]); d[2] = mk_f64(b[0], b[1]);
+}
+// byte offset of Args::wc in the argument segment of strip_kernel(Problem, WinSet, Args)
+constexpr unsigned kKargWs = (unsigned)((sizeof(Problem) + alignof(WinSet) - 1) / alignof(WinSet) * alignof(WinSet));
+constexpr unsigned kKargArgs = (unsigned)((kKargWs + sizeof(WinSet) + alignof(Args) - 1) / alignof(Args) * alignof(Args));
+constexpr unsigned kKargWc = kKargArgs + (unsigned)__builtin_offsetof(Args, wc);
+
 // A load whose result nobody wants (MLPG_STRIP_PREFETCH): it brings the row's lines into L2.  An LDS-DMA load into a
 // throw-away LDS line, so that no register is written (a register destination would have to stay reserved until the
 // data lands -- as inline assembly with a dead destination it silently overwrote whatever the allocator put there
@@ -553,13 +614,15 @@ template <typename TIN>
 struct RingDepth { static constexpr int value = MLPG_STRIP_RING_F64; };   // frames of loads in flight per wavefront (float64: 36 loads, 18 KB)
 template <>
 struct RingDepth<float> { static constexpr int value = MLPG_STRIP_RING_F32; };  // float32 values take half the registers
-template <typename TIN, bool BWD, int VM, bool EDGE, int NW, bool MULTI = false>
+template <typename TIN, bool BWD, int VM, bool EDGE, int NW, bool MULTI = false, bool KEEP = false>
 __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, __amdgpu_buffer_rsrc_t vrs,
                                                    __amdgpu_buffer_rsrc_t grs, const TIN *__restrict__ vglob,
                                                    unsigned loff, long ldi, long ldg, int sd, int f0, int T, int mw,
                                                    const double (*wc)[9], const double one, double (&Pd)[kM], double (&P1)[kM],
                                                    double (&P2)[kM], double (&rhs)[kM], double &ca, double &cb,
-                                                   double &cc, double (&rec)[kRec]) {
+                                                   double &cc, double (&rec)[kRec], float (&tk)[kM + 1][NW]) {
+  // KEEP (backward, float32 inputs): tk[i + 1][w] = the precision of frame f0 + i in window w as the assembly used it
+  // (dead frames 0), i = -1 .. kM-1: what the epilogue multiplies the gradient rows with
   // No zero-fill: every accumulator is ASSIGNED by the first contribution that reaches it (window 0 of the frame
   // noted below), so that a row costs no register before its first frame arrives.
   const unsigned ldi_bytes = (unsigned)ldi * (unsigned)sizeof(TIN), win_bytes = (unsigned)sd * (unsigned)sizeof(TIN);
@@ -584,13 +647,23 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
   constexpr int kRing = RingDepth<TIN>::value;
   TIN rv[kRing][NW], rm[kRing][NW];
   auto load_frame = [&](TIN (&v)[NW], TIN (&m)[NW], const int i) __attribute__((always_inline)) {
+    // BWD: the frame's row offset as an opaque scalar.  Left transparent, the 18 multiples i * ldi_bytes (and their EDGE
+    // variants) are loop invariants of the persistent item loop: hoisted, they occupy scalar registers through the whole
+    // kernel, and the backward instances -- which carry the epilogue's scalars as well -- then re-read the window
+    // coefficients from spilled lanes (v_readlane) in front of every use in the stream below.
+    unsigned frame_off = (unsigned)(f0 + i) * ldi_bytes;
+    if (BWD && !EDGE) asm volatile("" : "+s"(frame_off));
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       int t = f0 + i;
-      if (EDGE) t = t < cl[w] ? cl[w] : (t >= ch[w] ? ch[w] - 1 : t);
+      if (EDGE) {
+        t = t < cl[w] ? cl[w] : (t >= ch[w] ? ch[w] - 1 : t);
+        frame_off = (unsigned)t * ldi_bytes;
+        if (BWD) asm volatile("" : "+s"(frame_off));
+      }
       // MULTI: `sd` is this LANE's window pitch (the static dim of its stream), so the window offset is part of the
       // lane offset; otherwise it is wave-uniform and rides in the scalar offset
-      const unsigned soff = MULTI ? (unsigned)t * ldi_bytes : (unsigned)t * ldi_bytes + (unsigned)w * win_bytes;
+      const unsigned soff = MULTI ? frame_off : frame_off + (unsigned)w * win_bytes;
       const unsigned voff = MULTI ? loff + (unsigned)w * win_bytes : loff;
 #ifdef MLPG_STRIP_FAKE_LOADS  // timing experiment only: no memory traffic, opaque per-lane values instead
       (void)soff;
@@ -609,6 +682,7 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
     for (int w = 0; w < NW; ++w) {
       double tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[w]) : k[w].tau_glob;
       if (EDGE) tau *= (t >= lo[w] && t < hi[w]) ? 1.0 : 0.0;  // wave-uniform weight
+      if (KEEP && i < kM) tk[i + 1][w] = (float)tau;  // exact: a float32 reciprocal, or 0
       double tm = 0.0;
       if (!BWD) tm = tau * (double)m[w];
       const bool first = w == 0;  // first contribution to: Pd, rhs of row t+1; P1 of row t; P2 of row t-1
@@ -977,7 +1051,11 @@ __device__ __forceinline__ void backsub(const double (&Pd)[kM], const double (&P
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------
-template <typename TIN, typename TOUT, bool BWD, int VM, bool MULTI = false>
+// NW3: the launch has exactly three windows (the usual static / delta / delta-delta set): level 1 is the streamed
+// assemble_eliminate and the backward epilogue the frame-major one, and nothing of the window-major forms for other window
+// counts is compiled into the kernel (round 5: those forms alone cost the backward instances ~280 spilled scalar
+// registers and 20 k instructions of code); NW3 = false serves one, two or more than three windows.
+template <typename TIN, typename TOUT, bool BWD, int VM, bool MULTI = false, bool NW3 = true>
 __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem p, WinSet ws, Args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   double *lds_rec = (double *)smem;                                  // [kW][kRec][64]   (level 1 -> 2)
@@ -1029,7 +1107,7 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
     d = ls.dout;
   }
   const int f0 = (r * kW + wv) * kM;
-  const int nw = ws.nw, mw = ws.mw;
+  const int nw = NW3 ? 3 : ws.nw, mw = ws.mw;
 
   TOUT *out_b = (TOUT *)p.out + (size_t)b * Tmax * ldo;
 
@@ -1075,7 +1153,40 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
   double Pd[kM], P1[kM], P2[kM], rhs[kM], ca, cb, cc;
   double rec[kRec];
   bool bad = false;
-  if (MLPG_STRIP_STREAM == 2 && nw == 3 && MLPG_STRIP_ABLATE < 2) {
+  // Backward epilogue inputs (frame-major form, three windows): the precisions of the frames f0-1 .. f0+kM-1.
+  //   float32 inputs (kKeepTau): kept from the assembly in tk[][] -- float32 values, 51 registers;
+  //   float64 inputs: the variance rows are read a second time; those of the first kEarly frames are requested right
+  //   after level 1 (early_issue(): the ring's registers are free then), so that they travel while the strip waits
+  //   for its neighbours, the rest in front of the epilogue's first store.
+  constexpr bool kKeepTau = NW3 && BWD && VM == MLPG_HIP_VAR_FRAME && sizeof(TIN) == 4 && MLPG_STRIP_BWD_KEEP && !MULTI;
+  constexpr int kEpi = kM + 1;
+  constexpr int kEarly = (NW3 && BWD && VM == MLPG_HIP_VAR_FRAME && sizeof(TIN) == 8 && MLPG_STRIP_BWD_FRAME_MAJOR) ? MLPG_STRIP_BWD_EARLY : 0;
+  // the tail is instantiated per role only where the roles differ in what they keep (otherwise once, behind the roles:
+  // two copies of the epilogue cost scalar registers that the streamed level 1 then spills)
+  constexpr bool kSplitTail = kKeepTau && !MLPG_STRIP_BWD_KEEP0;
+  constexpr int kEarly0 = kSplitTail ? MLPG_STRIP_BWD_EARLY0 : kEarly;  // wavefront 0 (runs levels 2-3 meanwhile)
+  static_assert(kEarly >= 0 && kEarly <= kEpi && kEarly0 >= 0 && kEarly0 <= kEpi, "MLPG_STRIP_BWD_EARLY");
+  float tk[kEpi][3];
+  TIN tv[kEpi][3];
+  auto ldf = [&](TIN (&v)[3], const int i) __attribute__((always_inline)) {
+    if (VM != MLPG_HIP_VAR_FRAME) return;
+    int t = f0 + i;
+    t = t < 0 ? 0 : (t >= T ? T - 1 : t);  // in bounds (T >= 1 here); a row that is not live is not used
+    const unsigned ldi_b = (unsigned)ldi * (unsigned)sizeof(TIN), win_b = (unsigned)sd * (unsigned)sizeof(TIN);
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      v[w] = ld_row<TIN>(vrs, (unsigned)t * ldi_b + (unsigned)w * win_b, loff);  // (only the NW3 kernel comes here)
+    }
+  };
+  auto early_issue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int sl = 0; sl < kEarly; ++sl) ldf(tv[sl], sl - 1);
+  };
+  auto early_issue0 = [&]() __attribute__((always_inline)) {  // wavefront 0
+#pragma unroll
+    for (int sl = 0; sl < kEarly0; ++sl) ldf(tv[sl], sl - 1);
+  };
+  if (MLPG_STRIP_STREAM == 2 && NW3 && MLPG_STRIP_ABLATE < 2) {
     // three windows: the streamed level 1 with the halo handed over through LDS.  Every chunk of an active strip runs
     // it, also one behind the utterance's end (all weights 0, identity rows): its predecessor expects its hand-over.
     // Slots in the tail of the staging area (free until level 3): slot w = what wavefront w consumes; wavefront 0
@@ -1090,10 +1201,26 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
   } else
   if (f0 < T) {
     const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < T - mw;
-    if (MLPG_STRIP_STREAM == 1 && nw == 3 && MLPG_STRIP_ABLATE < 2) {
+    if (MLPG_STRIP_STREAM == 1 && NW3 && MLPG_STRIP_ABLATE < 2) {
       // the usual three windows: assembly and elimination streamed in frame order
-      if (interior) bad = assemble_eliminate<TIN, BWD, VM, false, 3, MULTI>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
-      else bad = assemble_eliminate<TIN, BWD, VM, true, 3, MULTI>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
+      double wcl[3][9];
+      const double (*wcs)[9] = a.wc;
+      if (BWD && MLPG_STRIP_BWD_KARG) {
+        // the six coefficient products per window the backward stream uses (entries 3 .. 8), fetched here
+        double c6[3][6];
+        karg_f64x6<kKargWc + 0 * 72 + 24>(c6[0]);
+        karg_f64x6<kKargWc + 1 * 72 + 24>(c6[1]);
+        karg_f64x6<kKargWc + 2 * 72 + 24>(c6[2]);
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          wcl[w][0] = wcl[w][1] = wcl[w][2] = 0.0;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) wcl[w][3 + q] = c6[w][q];
+        }
+        wcs = wcl;
+      }
+      if (interior) bad = assemble_eliminate<TIN, BWD, VM, false, 3, MULTI, kKeepTau>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, wcs, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec, tk);
+      else bad = assemble_eliminate<TIN, BWD, VM, true, 3, MULTI, kKeepTau>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, wcs, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec, tk);
       STRIP_TICK(1);
 #ifdef MLPG_STRIP_TRACE
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1122,10 +1249,15 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
 #pragma unroll
     for (int k = 0; k < kRec; ++k) rec[k] = 0.0;
     rec[rD11] = rec[rD22] = 1.0;
+    if (kKeepTau) {
+#pragma unroll
+      for (int i = 0; i < kEpi; ++i) tk[i][0] = tk[i][1] = tk[i][2] = 0.0f;
+    }
   }
   if (bad) rec[rD11] = __builtin_nan("");  // poisons every later level: the system is reported, not solved
 #pragma unroll
   for (int k = 0; k < kRec; ++k) lds_rec[(wv * kRec + k) * 64 + lane] = rec[k];
+  if (kEarly > 0 && wv != 0) early_issue();  // (wavefront 0: behind level 3 -- its chain has no registers to spare)
   STRIP_TICK(2);
   __syncthreads();
   STRIP_TICK(3);
@@ -1135,6 +1267,249 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
   // that meet at the same barriers.  Wavefront 0 parks g and l2 of its own chunk in LDS for the duration: its
   // chains then run out of registers, not out of scratch.
   int timed_out = 0;
+  // ---- the item's tail: level-1 back-substitution, verdict marks, output.  A lambda, called at the end of BOTH role
+  // branches below (the roles meet at the same barriers), so that what the epilogue keeps in registers across levels 2-3
+  // is a per-role matter: wavefront 0 runs the chain and has no register to spare, wavefronts 1 .. kW-1 only wait.
+  //   USE_TK: the precisions kept from the assembly (float32 inputs);  NEARLY: variance rows already requested (float64)
+  auto tail = [&](auto use_tk_c, auto nearly_c) __attribute__((always_inline)) {
+  constexpr bool kUseTk = decltype(use_tk_c)::value;
+  constexpr int kNEarly = decltype(nearly_c)::value;
+  STRIP_TICK(10);
+  __syncthreads();
+  STRIP_TICK(11);
+#ifdef MLPG_STRIP_TRACE
+  tr2 = (long long)__builtin_amdgcn_s_memrealtime();   // level 3 done
+#endif
+
+  // ---- level-1 back-substitution and output ----
+  const V2 ul = {lds_u[(wv * 2) * 64 + lane], lds_u[(wv * 2 + 1) * 64 + lane]};
+  const V2 uo = {lds_u[((wv + 1) * 2) * 64 + lane], lds_u[((wv + 1) * 2 + 1) * 64 + lane]};
+  const double sx = lds_u[(kW * 2) * 64 + lane];
+  const bool sys_bad = !(sx == sx) || !(uo.x == uo.x) || !(ul.x == ul.x);  // NaN: some pivot of this system failed
+  const int ntk = MLPG_STRIP_PREFETCH ? __builtin_amdgcn_readfirstlane(lds_misc[5]) : 0;
+  asm volatile("" ::: "memory");
+  if (MLPG_STRIP_PREFETCH) {
+    // the next item of this workgroup is known: touch the first frames of this wavefront's chunk of it, so that they
+    // travel from HBM while this item back-substitutes and stores
+    // (issued AFTER this item's last LDS reads: the compiler orders every LDS access behind outstanding LDS-DMA loads)
+    if (ntk < cur_lim) {
+      int g2, r2;
+      ticket_item<MULTI>(a, ntk, cur_lst, g2, r2);
+      const int b2 = g2 / a.ndg, dg2 = g2 - b2 * a.ndg;
+      int T2 = p.lengths ? p.lengths[b2] : Tmax;
+      T2 = T2 < 0 ? 0 : (T2 > Tmax ? Tmax : T2);
+      const int fn = (r2 * kW + wv) * kM;
+      if (r2 < R && fn < T2) {
+        const int dn0 = dg2 * a.dgw;
+        const int nd2 = sd - dn0 < a.dgw ? sd - dn0 : a.dgw;
+        const unsigned loff2 = (unsigned)(lane < nd2 ? lane : nd2 - 1) * (unsigned)sizeof(TIN);
+        const __amdgpu_buffer_rsrc_t mr = make_rsrc(BWD ? (const TIN *)p.out : (const TIN *)p.mean + (size_t)b2 * Tmax * ldi + dn0);
+        const __amdgpu_buffer_rsrc_t vr =
+            make_rsrc(VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)b2 * Tmax * ldi + dn0 : (const TIN *)p.out);
+        const unsigned lb = (unsigned)ldi * (unsigned)sizeof(TIN), wb = (unsigned)sd * (unsigned)sizeof(TIN);
+        void *dummy = (void *)(lds_misc + 16 + wv * 64);
+#pragma unroll
+        for (int q = 0; q < (MLPG_STRIP_PREFETCH > 100 ? 0 : MLPG_STRIP_PREFETCH); ++q) {
+          int t = fn - 1 + q;
+          t = t < 0 ? 0 : (t >= T2 ? T2 - 1 : t);
+#pragma unroll
+          for (int w = 0; w < 3; ++w) {
+            if (w < nw) {
+              const unsigned so = (unsigned)t * lb + (unsigned)w * wb;
+              if (VM == MLPG_HIP_VAR_FRAME) touch_row(vr, so, loff2, dummy);
+              if (!BWD) touch_row(mr, so, loff2, dummy);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (MLPG_STRIP_ABLATE < 2) backsub(Pd, P1, P2, rhs, ca, cb, cc, ul, uo);
+  STRIP_TICK(12);
+
+  // Verdict.  Strip 0 writes status 0; a strip that met a failing pivot (its own levels 1-2, or a level-3 block in
+  // its window: every failure is inside the window of at least the strip that holds it) or a time-out only marks
+  // its lanes in the utterance's mask -- the strips far away never learn of it now that level 3 is windowed.
+  // verdict_kernel (next launch on the stream) turns the marks into the reference's status and zero columns.
+  if (wv == 0) {
+    const int to = __builtin_amdgcn_readfirstlane(timed_out);
+    const unsigned long long m = to ? ~0ull : __ballot(sys_bad && lane_ok);
+    if (m != 0ull && lane == 0) {
+      int *line = a.ctrl + (1 + kMaxLists + g) * kCtrlLine;
+      __hip_atomic_fetch_or(line + 2, (int)(unsigned)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_or(line + 3, (int)(unsigned)(m >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (to) __hip_atomic_store(line + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#if !defined(MLPG_STRIP_TIMING) && !defined(MLPG_STRIP_TRACE)
+    if (r == 0 && lane_ok && p.status) p.status[(size_t)b * p.ld_status + dstat] = 0;
+#endif
+  }
+  const bool zero_out = sys_bad || timed_out;
+
+#ifndef MLPG_STRIP_TIMING
+  if (!lane_ok) return;
+#endif
+  if (!BWD) {
+#pragma unroll
+    for (int i = 0; i < kM; ++i) {
+      const int t = f0 + i;
+#if MLPG_STRIP_NT_STORES
+      if (t < Tmax) __builtin_nontemporal_store((t < T && !zero_out) ? (TOUT)rhs[i] : (TOUT)0, &out_b[(size_t)t * ldo + d]);
+#else
+      if (t < Tmax) out_b[(size_t)t * ldo + d] = (t < T && !zero_out) ? (TOUT)rhs[i] : (TOUT)0;
+#endif
+    }
+  } else {
+    // grad[t, w*sd+d] = tau_w[t] * (cm x[t-1] + c0 x[t] + cp x[t+1])  (paramgen/_mlpg.py:202-281).  The row whose
+    // right neighbour lives in the next chunk is written by that chunk: this wavefront writes rows f0-1 .. f0+14,
+    // and row f0+15 only if it is the utterance's last frame or padding.
+    // The variances are read again here (the 51 reciprocals of the assembly are not kept).  All of a window's 17
+    // loads are issued before its stores, and the next window's before this window's arithmetic: written as
+    // load -> reciprocal -> store per row, the compiler cannot move a load above the preceding store (the two
+    // pointers may alias) and the epilogue becomes 51 round trips.
+    const unsigned ldi_bytes = (unsigned)ldi * (unsigned)sizeof(TIN), win_bytes = (unsigned)sd * (unsigned)sizeof(TIN);
+    auto load_w = [&](TIN (&v)[kM + 1], const int w) __attribute__((always_inline)) {
+      if (VM != MLPG_HIP_VAR_FRAME) return;
+#pragma unroll
+      for (int i = -1; i < kM; ++i) {
+        int t = f0 + i;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);  // in bounds; a row that is not live is not used
+        v[i + 1] = ld_row<TIN>(vrs, (unsigned)t * ldi_bytes + (unsigned)w * win_bytes, loff);
+      }
+    };
+    auto emit_w = [&](const TIN (&v)[kM + 1], const int w) __attribute__((always_inline)) {
+      const double cm = a.wc[w][0], c0 = a.wc[w][1], cp = a.wc[w][2];
+      double tau_glob = 1.0;
+      if (VM == MLPG_HIP_VAR_GLOBAL) tau_glob = tau_of<TIN>(vglob[w * sd]);
+      TOUT *ow = out_b + (size_t)w * sd + d;
+#pragma unroll
+      for (int i = -1; i < kM; ++i) {
+        const int t = f0 + i;
+        if (t < 0 || t >= Tmax) continue;
+        if (t >= T) {
+          if (i >= 0) ow[(size_t)t * ldo] = (TOUT)0;
+          continue;
+        }
+        if (i == -1 && f0 >= T) continue;          // (cannot happen in an active chunk; keeps the rule explicit)
+        if (i == kM - 1 && t != T - 1) continue;    // the next chunk writes it
+        const bool lv = w ? (mw != 0 && t >= mw && t < T - mw) : true;
+        double tau = 0.0;
+        if (lv) tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[i + 1]) : tau_glob;
+        const double xm = (i == -1) ? ul.x : ((i == 0) ? ul.y : rhs[i > 0 ? i - 1 : 0]);
+        const double x0 = (i == -1) ? ul.y : rhs[i >= 0 ? i : 0];
+        const double xp = (i == kM - 1) ? 0.0 : rhs[i + 1];
+        const double gval = tau * (cm * xm + c0 * x0 + cp * xp);
+        ow[(size_t)t * ldo] = zero_out ? (TOUT)0 : (TOUT)gval;
+      }
+    };
+    if (MLPG_STRIP_BWD_FRAME_MAJOR && NW3) {
+      // Frame-major epilogue (round 3): per frame three reciprocals and THREE ADJACENT 480-byte stores -- the wavefront writes its 17 gradient rows as one contiguous 24 KB run in
+      // address order (window-major, the three blocks of a row were written 16 rows of stores apart).
+      // All 51 variance loads are issued before the first store: loads and stores share one in-order counter on this
+      // chip, so a load queued behind stores waits for the stores' acknowledgements (a ring of loads refilled between
+      // the stores ran at one store latency per six frames: 19 k cycles for this epilogue, as long as level 1).
+      double tg[3] = {1.0, 1.0, 1.0};
+      if (VM == MLPG_HIP_VAR_GLOBAL) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) tg[w] = tau_of<TIN>(vglob[w * sd]);
+      }
+      // the three coefficients per window (entries 0 .. 2 of wc[w]), fetched here (see karg_f64x6)
+      double we[3][3];
+      if (MLPG_STRIP_BWD_KARG) {
+        karg_f64x3<kKargWc + 0 * 72>(we[0]);
+        karg_f64x3<kKargWc + 1 * 72>(we[1]);
+        karg_f64x3<kKargWc + 2 * 72>(we[2]);
+      } else {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { we[w][0] = a.wc[w][0]; we[w][1] = a.wc[w][1]; we[w][2] = a.wc[w][2]; }
+      }
+      auto emitf = [&](const int sl) __attribute__((always_inline)) {
+        const int i = sl - 1;
+        const int t = f0 + i;
+        if (t < 0 || t >= Tmax) return;
+        TOUT *orow = out_b + (size_t)t * ldo + d;
+        auto put = [&](const int w, const TOUT val) __attribute__((always_inline)) {
+#ifdef MLPG_STRIP_BWD_NOSTORE  // timing experiment only
+          if (val == (TOUT)123.456) orow[(size_t)w * sd] = val;
+          return;
+#endif
+#if MLPG_STRIP_NT_STORES
+          __builtin_nontemporal_store(val, orow + (size_t)w * sd);
+#else
+          orow[(size_t)w * sd] = val;
+#endif
+        };
+        if (t >= T) {
+          if (i >= 0) { put(0, (TOUT)0); put(1, (TOUT)0); put(2, (TOUT)0); }
+          return;
+        }
+        if (i == -1 && f0 >= T) return;
+        if (i == kM - 1 && t != T - 1) return;  // the next chunk writes it
+        const double xm = (i == -1) ? ul.x : ((i == 0) ? ul.y : rhs[i > 0 ? i - 1 : 0]);
+        const double x0 = (i == -1) ? ul.y : rhs[i >= 0 ? i : 0];
+        const double xp = (i == kM - 1) ? 0.0 : rhs[i + 1];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const bool lv = w ? (mw != 0 && t >= mw && t < T - mw) : true;
+          double tau = 0.0;
+          if (kUseTk) {
+            // dead frames were kept as 0.  The opaque copy keeps the widening HERE: left to itself the optimiser widens all
+            // 51 values right behind the assembly and carries them as doubles (102 registers) across levels 2 and 3
+            float tf = tk[sl][w];
+            asm volatile("" : "+v"(tf));
+            tau = (double)tf;
+          }
+          else if (lv) tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(tv[sl][w]) : tg[w];
+          const double gval = tau * (we[w][0] * xm + we[w][1] * x0 + we[w][2] * xp);
+          put(w, zero_out ? (TOUT)0 : (TOUT)gval);
+        }
+      };
+      if (!kUseTk) {
+#pragma unroll
+        for (int sl = kNEarly; sl < kEpi; ++sl) ldf(tv[sl], sl - 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#define STRIP_EPI(S)                                                        \
+      emitf((S));                                                             \
+      __builtin_amdgcn_sched_barrier(0);
+      STRIP_EPI(0) STRIP_EPI(1) STRIP_EPI(2) STRIP_EPI(3) STRIP_EPI(4) STRIP_EPI(5) STRIP_EPI(6) STRIP_EPI(7) STRIP_EPI(8)
+      STRIP_EPI(9) STRIP_EPI(10) STRIP_EPI(11) STRIP_EPI(12) STRIP_EPI(13) STRIP_EPI(14) STRIP_EPI(15) STRIP_EPI(16)
+#undef STRIP_EPI
+    } else {
+    TIN tvA[kM + 1], tvB[kM + 1];
+      load_w(tvA, 0);
+      for (int w = 0; w < nw; w += 2) {
+        if (w + 1 < nw) load_w(tvB, w + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        emit_w(tvA, w);
+        __builtin_amdgcn_sched_barrier(0);
+        if (w + 1 < nw) {
+          if (w + 2 < nw) load_w(tvA, w + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          emit_w(tvB, w + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    }
+#ifdef MLPG_STRIP_TIMING
+  // profiling build only: phase cycle counts of wavefront 0 of strips 0..15 of utterances 0..7 overwrite the head of
+  // the status array (run bench.py --no-check with MLPG_DUMP_STATUS=1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STRIP_TICK(13);
+  if (wv == 0 && lane == 0 && p.status && b < 8 && r < 16 && dg == 0)
+  {
+    for (int k = 0; k < 16; ++k) p.status[(b * 16 + r) * 16 + k] = (int)tq[k];
+  }
+#endif
+#ifdef MLPG_STRIP_TRACE
+  if (wv == 0 && lane == 0 && p.status && (g * R + r) * 4 + 3 < p.B * p.ld_status) {
+    int *tp = p.status + (g * R + r) * 4;
+    tp[0] = (int)(tr0 & 0x3FFFFFFF); tp[1] = (int)(tra - tr0) | ((int)(tr1 - tr0) << 16); tp[2] = (int)(tr2 - tr0);
+    tp[3] = (int)((long long)__builtin_amdgcn_s_memrealtime() - tr0) | (xcd << 24) | (phase << 28);
+  }
+#endif
+  };  // tail
   if (wv == 0) {
 #pragma unroll
     for (int i = 0; i < kN; ++i) {
@@ -1146,7 +1521,7 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
     // level-1 records; with the handed-over halo (MLPG_STRIP_STREAM == 2) the separator entries D11, D12, D22, F1, F2
     // of chunks 0 .. kW-2 still lack what the next chunk's first two frames add to them: slot j of the hand-over area
     // (rows behind the utterance's end are identity rows: their sums vanish)
-    const bool halo = MLPG_STRIP_STREAM == 2 && nw == 3 && MLPG_STRIP_ABLATE < 2;
+    const bool halo = MLPG_STRIP_STREAM == 2 && NW3 && MLPG_STRIP_ABLATE < 2;
     const double *lds_yr = lds_stage + (size_t)kW * kRec * 64 + lane;
     auto R_ = [&](int j, int k) __attribute__((always_inline)) {
       double v = lds_rec[(j * kRec + k) * 64 + lane];
@@ -1443,6 +1818,9 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
       lds_misc[5] = tkn;
       lds_misc[6] = 1;
     }
+    // wavefront 0's share of the early variance rows: only now has it registers to receive them (levels 2 and 3 are done);
+    // they travel during the two back-substitutions
+    if (kEarly0 > 0) early_issue0();
     // ---- back-substitution of level 2 ----
     double *up = lds_u + lane;
     up[0] = sprev.x; up[64] = sprev.y;
@@ -1463,6 +1841,7 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
       rhs[i] = lds_park[i * 64 + lane];
       P2[i] = lds_park[(kN + i) * 64 + lane];
     }
+    if (kSplitTail) tail(std::integral_constant<bool, kKeepTau && MLPG_STRIP_BWD_KEEP0>{}, std::integral_constant<int, kEarly0>{});
   } else {
     __syncthreads();  // (S2)
     // wavefronts 1..3: stage the records (kStage rows per batch) through LDS; the loads of batch k+1 are issued into
@@ -1524,231 +1903,9 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
         }
       }
     }
+    if (kSplitTail) tail(std::integral_constant<bool, kKeepTau>{}, std::integral_constant<int, kEarly>{});
   }
-  STRIP_TICK(10);
-  __syncthreads();
-  STRIP_TICK(11);
-#ifdef MLPG_STRIP_TRACE
-  tr2 = (long long)__builtin_amdgcn_s_memrealtime();   // level 3 done
-#endif
-
-  // ---- level-1 back-substitution and output ----
-  const V2 ul = {lds_u[(wv * 2) * 64 + lane], lds_u[(wv * 2 + 1) * 64 + lane]};
-  const V2 uo = {lds_u[((wv + 1) * 2) * 64 + lane], lds_u[((wv + 1) * 2 + 1) * 64 + lane]};
-  const double sx = lds_u[(kW * 2) * 64 + lane];
-  const bool sys_bad = !(sx == sx) || !(uo.x == uo.x) || !(ul.x == ul.x);  // NaN: some pivot of this system failed
-  const int ntk = MLPG_STRIP_PREFETCH ? __builtin_amdgcn_readfirstlane(lds_misc[5]) : 0;
-  asm volatile("" ::: "memory");
-  if (MLPG_STRIP_PREFETCH) {
-    // the next item of this workgroup is known: touch the first frames of this wavefront's chunk of it, so that they
-    // travel from HBM while this item back-substitutes and stores
-    // (issued AFTER this item's last LDS reads: the compiler orders every LDS access behind outstanding LDS-DMA loads)
-    if (ntk < cur_lim) {
-      int g2, r2;
-      ticket_item<MULTI>(a, ntk, cur_lst, g2, r2);
-      const int b2 = g2 / a.ndg, dg2 = g2 - b2 * a.ndg;
-      int T2 = p.lengths ? p.lengths[b2] : Tmax;
-      T2 = T2 < 0 ? 0 : (T2 > Tmax ? Tmax : T2);
-      const int fn = (r2 * kW + wv) * kM;
-      if (r2 < R && fn < T2) {
-        const int dn0 = dg2 * a.dgw;
-        const int nd2 = sd - dn0 < a.dgw ? sd - dn0 : a.dgw;
-        const unsigned loff2 = (unsigned)(lane < nd2 ? lane : nd2 - 1) * (unsigned)sizeof(TIN);
-        const __amdgpu_buffer_rsrc_t mr = make_rsrc(BWD ? (const TIN *)p.out : (const TIN *)p.mean + (size_t)b2 * Tmax * ldi + dn0);
-        const __amdgpu_buffer_rsrc_t vr =
-            make_rsrc(VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)b2 * Tmax * ldi + dn0 : (const TIN *)p.out);
-        const unsigned lb = (unsigned)ldi * (unsigned)sizeof(TIN), wb = (unsigned)sd * (unsigned)sizeof(TIN);
-        void *dummy = (void *)(lds_misc + 16 + wv * 64);
-#pragma unroll
-        for (int q = 0; q < (MLPG_STRIP_PREFETCH > 100 ? 0 : MLPG_STRIP_PREFETCH); ++q) {
-          int t = fn - 1 + q;
-          t = t < 0 ? 0 : (t >= T2 ? T2 - 1 : t);
-#pragma unroll
-          for (int w = 0; w < 3; ++w) {
-            if (w < nw) {
-              const unsigned so = (unsigned)t * lb + (unsigned)w * wb;
-              if (VM == MLPG_HIP_VAR_FRAME) touch_row(vr, so, loff2, dummy);
-              if (!BWD) touch_row(mr, so, loff2, dummy);
-            }
-          }
-        }
-      }
-    }
-  }
-  if (MLPG_STRIP_ABLATE < 2) backsub(Pd, P1, P2, rhs, ca, cb, cc, ul, uo);
-  STRIP_TICK(12);
-
-  // Verdict.  Strip 0 writes status 0; a strip that met a failing pivot (its own levels 1-2, or a level-3 block in
-  // its window: every failure is inside the window of at least the strip that holds it) or a time-out only marks
-  // its lanes in the utterance's mask -- the strips far away never learn of it now that level 3 is windowed.
-  // verdict_kernel (next launch on the stream) turns the marks into the reference's status and zero columns.
-  if (wv == 0) {
-    const int to = __builtin_amdgcn_readfirstlane(timed_out);
-    const unsigned long long m = to ? ~0ull : __ballot(sys_bad && lane_ok);
-    if (m != 0ull && lane == 0) {
-      int *line = a.ctrl + (1 + kMaxLists + g) * kCtrlLine;
-      __hip_atomic_fetch_or(line + 2, (int)(unsigned)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_or(line + 3, (int)(unsigned)(m >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (to) __hip_atomic_store(line + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#if !defined(MLPG_STRIP_TIMING) && !defined(MLPG_STRIP_TRACE)
-    if (r == 0 && lane_ok && p.status) p.status[(size_t)b * p.ld_status + dstat] = 0;
-#endif
-  }
-  const bool zero_out = sys_bad || timed_out;
-
-#ifndef MLPG_STRIP_TIMING
-  if (!lane_ok) return;
-#endif
-  if (!BWD) {
-#pragma unroll
-    for (int i = 0; i < kM; ++i) {
-      const int t = f0 + i;
-#if MLPG_STRIP_NT_STORES
-      if (t < Tmax) __builtin_nontemporal_store((t < T && !zero_out) ? (TOUT)rhs[i] : (TOUT)0, &out_b[(size_t)t * ldo + d]);
-#else
-      if (t < Tmax) out_b[(size_t)t * ldo + d] = (t < T && !zero_out) ? (TOUT)rhs[i] : (TOUT)0;
-#endif
-    }
-  } else {
-    // grad[t, w*sd+d] = tau_w[t] * (cm x[t-1] + c0 x[t] + cp x[t+1])  (paramgen/_mlpg.py:202-281).  The row whose
-    // right neighbour lives in the next chunk is written by that chunk: this wavefront writes rows f0-1 .. f0+14,
-    // and row f0+15 only if it is the utterance's last frame or padding.
-    // The variances are read again here (the 51 reciprocals of the assembly are not kept).  All of a window's 17
-    // loads are issued before its stores, and the next window's before this window's arithmetic: written as
-    // load -> reciprocal -> store per row, the compiler cannot move a load above the preceding store (the two
-    // pointers may alias) and the epilogue becomes 51 round trips.
-    const unsigned ldi_bytes = (unsigned)ldi * (unsigned)sizeof(TIN), win_bytes = (unsigned)sd * (unsigned)sizeof(TIN);
-    auto load_w = [&](TIN (&v)[kM + 1], const int w) __attribute__((always_inline)) {
-      if (VM != MLPG_HIP_VAR_FRAME) return;
-#pragma unroll
-      for (int i = -1; i < kM; ++i) {
-        int t = f0 + i;
-        t = t < 0 ? 0 : (t >= T ? T - 1 : t);  // in bounds; a row that is not live is not used
-        v[i + 1] = ld_row<TIN>(vrs, (unsigned)t * ldi_bytes + (unsigned)w * win_bytes, loff);
-      }
-    };
-    auto emit_w = [&](const TIN (&v)[kM + 1], const int w) __attribute__((always_inline)) {
-      const double cm = a.wc[w][0], c0 = a.wc[w][1], cp = a.wc[w][2];
-      double tau_glob = 1.0;
-      if (VM == MLPG_HIP_VAR_GLOBAL) tau_glob = tau_of<TIN>(vglob[w * sd]);
-      TOUT *ow = out_b + (size_t)w * sd + d;
-#pragma unroll
-      for (int i = -1; i < kM; ++i) {
-        const int t = f0 + i;
-        if (t < 0 || t >= Tmax) continue;
-        if (t >= T) {
-          if (i >= 0) ow[(size_t)t * ldo] = (TOUT)0;
-          continue;
-        }
-        if (i == -1 && f0 >= T) continue;          // (cannot happen in an active chunk; keeps the rule explicit)
-        if (i == kM - 1 && t != T - 1) continue;    // the next chunk writes it
-        const bool lv = w ? (mw != 0 && t >= mw && t < T - mw) : true;
-        double tau = 0.0;
-        if (lv) tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[i + 1]) : tau_glob;
-        const double xm = (i == -1) ? ul.x : ((i == 0) ? ul.y : rhs[i > 0 ? i - 1 : 0]);
-        const double x0 = (i == -1) ? ul.y : rhs[i >= 0 ? i : 0];
-        const double xp = (i == kM - 1) ? 0.0 : rhs[i + 1];
-        const double gval = tau * (cm * xm + c0 * x0 + cp * xp);
-        ow[(size_t)t * ldo] = zero_out ? (TOUT)0 : (TOUT)gval;
-      }
-    };
-    if (MLPG_STRIP_BWD_FRAME_MAJOR && nw == 3) {
-      // Frame-major epilogue (round 3): per frame three reciprocals and THREE ADJACENT 480-byte stores -- the wavefront writes its 17 gradient rows as one contiguous 24 KB run in
-      // address order (window-major, the three blocks of a row were written 16 rows of stores apart).
-      // All 51 variance loads are issued before the first store: loads and stores share one in-order counter on this
-      // chip, so a load queued behind stores waits for the stores' acknowledgements (a ring of loads refilled between
-      // the stores ran at one store latency per six frames: 19 k cycles for this epilogue, as long as level 1).
-      constexpr int kEpi = kM + 1;
-      TIN tv[kEpi][3];
-      auto ldf = [&](TIN (&v)[3], const int i) __attribute__((always_inline)) {
-        if (VM != MLPG_HIP_VAR_FRAME) return;
-        int t = f0 + i;
-        t = t < 0 ? 0 : (t >= T ? T - 1 : t);  // in bounds; a row that is not live is not used
-#pragma unroll
-        for (int w = 0; w < 3; ++w) v[w] = ld_row<TIN>(vrs, (unsigned)t * ldi_bytes + (unsigned)w * win_bytes, loff);
-      };
-      double tg[3] = {1.0, 1.0, 1.0};
-      if (VM == MLPG_HIP_VAR_GLOBAL) {
-#pragma unroll
-        for (int w = 0; w < 3; ++w) tg[w] = tau_of<TIN>(vglob[w * sd]);
-      }
-      auto emitf = [&](const TIN (&v)[3], const int i) __attribute__((always_inline)) {
-        const int t = f0 + i;
-        if (t < 0 || t >= Tmax) return;
-        TOUT *orow = out_b + (size_t)t * ldo + d;
-        auto put = [&](const int w, const TOUT val) __attribute__((always_inline)) {
-#ifdef MLPG_STRIP_BWD_NOSTORE  // timing experiment only
-          if (val == (TOUT)123.456) orow[(size_t)w * sd] = val;
-          return;
-#endif
-#if MLPG_STRIP_NT_STORES
-          __builtin_nontemporal_store(val, orow + (size_t)w * sd);
-#else
-          orow[(size_t)w * sd] = val;
-#endif
-        };
-        if (t >= T) {
-          if (i >= 0) { put(0, (TOUT)0); put(1, (TOUT)0); put(2, (TOUT)0); }
-          return;
-        }
-        if (i == -1 && f0 >= T) return;
-        if (i == kM - 1 && t != T - 1) return;  // the next chunk writes it
-        const double xm = (i == -1) ? ul.x : ((i == 0) ? ul.y : rhs[i > 0 ? i - 1 : 0]);
-        const double x0 = (i == -1) ? ul.y : rhs[i >= 0 ? i : 0];
-        const double xp = (i == kM - 1) ? 0.0 : rhs[i + 1];
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          const bool lv = w ? (mw != 0 && t >= mw && t < T - mw) : true;
-          double tau = 0.0;
-          if (lv) tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[w]) : tg[w];
-          const double gval = tau * (a.wc[w][0] * xm + a.wc[w][1] * x0 + a.wc[w][2] * xp);
-          put(w, zero_out ? (TOUT)0 : (TOUT)gval);
-        }
-      };
-#pragma unroll
-      for (int sl = 0; sl < kEpi; ++sl) ldf(tv[sl], sl - 1);
-      __builtin_amdgcn_sched_barrier(0);
-#define STRIP_EPI(S)                                                        \
-      emitf(tv[(S)], (S)-1);                                                  \
-      __builtin_amdgcn_sched_barrier(0);
-      STRIP_EPI(0) STRIP_EPI(1) STRIP_EPI(2) STRIP_EPI(3) STRIP_EPI(4) STRIP_EPI(5) STRIP_EPI(6) STRIP_EPI(7) STRIP_EPI(8)
-      STRIP_EPI(9) STRIP_EPI(10) STRIP_EPI(11) STRIP_EPI(12) STRIP_EPI(13) STRIP_EPI(14) STRIP_EPI(15) STRIP_EPI(16)
-#undef STRIP_EPI
-    } else {
-    TIN tvA[kM + 1], tvB[kM + 1];
-      load_w(tvA, 0);
-      for (int w = 0; w < nw; w += 2) {
-        if (w + 1 < nw) load_w(tvB, w + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        emit_w(tvA, w);
-        __builtin_amdgcn_sched_barrier(0);
-        if (w + 1 < nw) {
-          if (w + 2 < nw) load_w(tvA, w + 2);
-          __builtin_amdgcn_sched_barrier(0);
-          emit_w(tvB, w + 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    }
-#ifdef MLPG_STRIP_TIMING
-  // profiling build only: phase cycle counts of wavefront 0 of strips 0..15 of utterances 0..7 overwrite the head of
-  // the status array (run bench.py --no-check with MLPG_DUMP_STATUS=1)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  STRIP_TICK(13);
-  if (wv == 0 && lane == 0 && p.status && b < 8 && r < 16 && dg == 0)
-  {
-    for (int k = 0; k < 16; ++k) p.status[(b * 16 + r) * 16 + k] = (int)tq[k];
-  }
-#endif
-#ifdef MLPG_STRIP_TRACE
-  if (wv == 0 && lane == 0 && p.status && (g * R + r) * 4 + 3 < p.B * p.ld_status) {
-    int *tp = p.status + (g * R + r) * 4;
-    tp[0] = (int)(tr0 & 0x3FFFFFFF); tp[1] = (int)(tra - tr0) | ((int)(tr1 - tr0) << 16); tp[2] = (int)(tr2 - tr0);
-    tp[3] = (int)((long long)__builtin_amdgcn_s_memrealtime() - tr0) | (xcd << 24) | (phase << 28);
-  }
-#endif
+  if (!kSplitTail) tail(std::false_type{}, std::integral_constant<int, kEarly>{});
   };  // body
 
 #ifndef MLPG_STRIP_STAGGER
@@ -1948,12 +2105,19 @@ int launch_impl(hipStream_t st, const Problem &p, const WinSet &ws, void *scratc
   };
   if constexpr (MULTI) {
     // several streams side by side on the lanes: forward, per-frame variances, three windows (the caller checked)
-    return go(strip_kernel<TIN, TOUT, false, MLPG_HIP_VAR_FRAME, true>);
+    return go(strip_kernel<TIN, TOUT, false, MLPG_HIP_VAR_FRAME, true, true>);
   } else {
+    if (ws.nw == 3) {
+      switch (p.var_mode) {
+        case MLPG_HIP_VAR_FRAME: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_FRAME, false, true>);
+        case MLPG_HIP_VAR_GLOBAL: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_GLOBAL, false, true>);
+        default: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_UNIT, false, true>);
+      }
+    }
     switch (p.var_mode) {
-      case MLPG_HIP_VAR_FRAME: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_FRAME>);
-      case MLPG_HIP_VAR_GLOBAL: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_GLOBAL>);
-      default: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_UNIT>);
+      case MLPG_HIP_VAR_FRAME: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_FRAME, false, false>);
+      case MLPG_HIP_VAR_GLOBAL: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_GLOBAL, false, false>);
+      default: return go(strip_kernel<TIN, TOUT, BWD, MLPG_HIP_VAR_UNIT, false, false>);
     }
   }
 }

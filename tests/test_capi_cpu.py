@@ -247,20 +247,3 @@ def test_header_constants_match_the_python_binding():
              "DIST_SCALED_SQL2_NP": _hip.DIST_SCALED_SQL2_NP, "TIE_FIRST_MIN": _hip.TIE_FIRST_MIN, "TIE_DIAG_LAST": _hip.TIE_DIAG_LAST}
     for name, val in pairs.items():
         assert defs.get(name) == val, (name, defs.get(name), val)
-
-
-def test_experimental_fir_patch_still_applies():
-    """tools/experimental/fir_shared/mlpg_fir_shared.patch is kept against the current csrc/mlpg_fir.hip (it is to be tried on the GPU
-    next; a patch that has rotted would cost that round its first minutes).  Skipped outside a git checkout."""
-    import shutil
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    patch = os.path.join(root, "tools", "experimental", "fir_shared", "mlpg_fir_shared.patch")
-    if not os.path.exists(patch):
-        pytest.skip("the patch was applied or removed")
-    if shutil.which("git") is None or not os.path.isdir(os.path.join(root, ".git")):
-        pytest.skip("not a git checkout")
-    r = subprocess.run(["git", "apply", "--check", patch], cwd=root, capture_output=True, text=True)
-    if r.returncode != 0 and subprocess.run(["git", "apply", "--check", "-R", patch], cwd=root, capture_output=True).returncode == 0:
-        return      # already applied to the working tree
-    assert r.returncode == 0, r.stderr
