@@ -18,7 +18,10 @@ namespace {
 #ifndef MLPG_STRIP_W
 #define MLPG_STRIP_W 4
 #endif
-constexpr int kStripFrames = 16 * MLPG_STRIP_W;   // strip::kW * strip::kM
+#ifndef MLPG_STRIP_M
+#define MLPG_STRIP_M 16
+#endif
+constexpr int kStripFrames = MLPG_STRIP_M * MLPG_STRIP_W;   // strip::kW * strip::kM
 constexpr int kMaxStrips = 256;    // strips of one utterance must be able to be resident together (2 per CU)
 constexpr int kRecBytes = 14 * 64 * 8;
 constexpr int kStripNotResident = kStripMultiNotResident;  // = strip::kNotResident (mlpg_strip_impl.h)

@@ -69,12 +69,22 @@ namespace strip {
 #ifndef MLPG_STRIP_W
 #define MLPG_STRIP_W 4   // 8: 128-frame strips, one workgroup of 8 wavefronts per CU (experiment; mlpg_strip.hip must match)
 #endif
+#ifndef MLPG_STRIP_M
+#define MLPG_STRIP_M 16  // 8: the 8-frame-chunk experiment of round 5 (profiles/r05_notes.md); mlpg_strip.hip must match
+#endif
+#ifndef MLPG_STRIP_WGS
+#define MLPG_STRIP_WGS (MLPG_STRIP_W <= 4 ? 2 : 1)  // workgroups per CU the kernel is compiled for (register budget 512 / (W/4 * WGS))
+#endif
 constexpr int kW = MLPG_STRIP_W;  // chunks (wavefronts) per strip (workgroup)
-constexpr int kM = 16;       // frames per chunk
+constexpr int kM = MLPG_STRIP_M;  // frames per chunk
 constexpr int kN = kM - 2;   // interior frames of a chunk; frames kN, kN+1 are its separator
 constexpr int kRec = 14;     // doubles per lane in a level-1 / level-2 record
-constexpr int kStage = kW > 6 ? 8 : 6;  // records of level 3 staged in LDS per batch (even, >= kW)
-constexpr int kPark = 2 * kN;  // doubles per lane that wavefront 0 parks in LDS while it runs levels 2 and 3
+#ifndef MLPG_STRIP_STAGE
+#define MLPG_STRIP_STAGE (MLPG_STRIP_W > 6 ? 8 : 6)
+#endif
+constexpr int kStage = MLPG_STRIP_STAGE;  // records of level 3 staged in LDS per batch (even, >= kW)
+constexpr bool kParkOn = kM >= 16;  // (an 8-frame chunk's factor stays in registers)
+constexpr int kPark = kParkOn ? 2 * kN : 0;  // doubles per lane that wavefront 0 parks in LDS while it runs levels 2 and 3
 constexpr int kFac = 10;     // doubles per lane kept per eliminated separator of level 2
 constexpr int kSpinLimit = 1 << 20;
 
@@ -231,7 +241,7 @@ constexpr size_t kLdsU = (size_t)(kW + 1) * 2 * 64 * 8;
 constexpr size_t kLdsMisc = 64 + kW * 256;  // control words + a throw-away line per wavefront (MLPG_STRIP_PREFETCH)
 constexpr size_t kLdsBytes = kLdsStage + kLdsPark + kLdsFac + kLdsU + kLdsMisc;
 static_assert(kW * kRec <= kStage * kRec, "level-1 records must fit the staging area");
-static_assert(kLdsBytes <= (kW <= 4 ? 80 : 160) * 1024, "two workgroups of 4 wavefronts per CU, or one of 8");
+static_assert(kLdsBytes <= 160 * 1024 / MLPG_STRIP_WGS, "MLPG_STRIP_WGS workgroups per CU must fit the 160 KB of LDS");
 
 __device__ __forceinline__ double fast_rcp(double d) {
   double x = __builtin_amdgcn_rcp(d);
@@ -311,7 +321,7 @@ __device__ __forceinline__ double ld_agent(const double *p) {
 // batch k+1 are in flight while batch k is accumulated, so that only the first batch's memory latency
 // is exposed (left to itself the compiler issues a window's loads, waits, computes, and only then
 // touches the next window).  Small batches because the accumulators already take 128 registers.
-constexpr int kNB = 6;                // batches per window (even: every window starts in the same register set)
+constexpr int kNB = kM == 16 ? 6 : 2;  // batches per window (even: every window starts in the same register set)
 constexpr int kHB = (kM + 2) / kNB;   // frames per batch
 static_assert(kHB * kNB == kM + 2, "batches must tile the 18 frames");
 
@@ -517,10 +527,12 @@ __device__ __forceinline__ void assemble(__amdgpu_buffer_rsrc_t mrs, __amdgpu_bu
     // the six batches alternate between the two register sets; the window ends with the next window's batch 0 in
     // flight in set A.  sched_barrier pins the issue order: next batch's loads, then this batch's arithmetic.
 #define STRIP_STEP(H, RVX, RMX, RVY, RMY)                                                                      \
-    load_batch<TIN, BWD, VM, EDGE, (H) + 1>(RVY, RMY, mrs, vrs, woff, loff, ldi_bytes, f0, cl, ch);             \
+    if ((H) + 1 < kNB) {                                                                                          \
+    load_batch<TIN, BWD, VM, EDGE, ((H) + 1 < kNB ? (H) + 1 : 0)>(RVY, RMY, mrs, vrs, woff, loff, ldi_bytes, f0, cl, ch);             \
     __builtin_amdgcn_sched_barrier(0);                                                                          \
     accumulate<TIN, BWD, VM, EDGE, (H)>(RVX, RMX, k, f0, lo, hi, Pd, P1, P2, rhs, ca, cb, cc);                  \
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    }
     STRIP_STEP(0, rvA, rmA, rvB, rmB)
     STRIP_STEP(1, rvB, rmB, rvA, rmA)
     STRIP_STEP(2, rvA, rmA, rvB, rmB)
@@ -529,7 +541,7 @@ __device__ __forceinline__ void assemble(__amdgpu_buffer_rsrc_t mrs, __amdgpu_bu
 #undef STRIP_STEP
     if (w + 1 < nw) load_batch<TIN, BWD, VM, EDGE, 0>(rvA, rmA, mrs, vrs, woff + win_bytes, loff, ldi_bytes, f0, clo(w + 1), chi(w + 1));
     __builtin_amdgcn_sched_barrier(0);
-    accumulate<TIN, BWD, VM, EDGE, 5>(rvB, rmB, k, f0, lo, hi, Pd, P1, P2, rhs, ca, cb, cc);
+    accumulate<TIN, BWD, VM, EDGE, kNB - 1>(rvB, rmB, k, f0, lo, hi, Pd, P1, P2, rhs, ca, cb, cc);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (EDGE) {
@@ -787,12 +799,14 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
   // elimination's dependent chain with the next frame's accumulation; two per SIMD did not care)
 #define STRIP_SB(bit) do { if (!((MLPG_STRIP_SCHED_RELAX) & (bit))) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define STRIP_STEP(S)                                                                   \
+  if ((S) < kM + 2) {                                                                   \
   accumulate_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1);                            \
   STRIP_SB(1);                                                                          \
   if ((S) + kRing < kM + 2) { load_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1 + kRing); } \
   STRIP_SB(2);                                                                          \
   if ((S)-2 >= 0 && (S)-2 < kN) { elim_row((S)-2); }                                    \
-  STRIP_SB(4);
+  STRIP_SB(4);                                                                          \
+  }
   STRIP_STEP(0) STRIP_STEP(1) STRIP_STEP(2) STRIP_STEP(3) STRIP_STEP(4) STRIP_STEP(5)
   STRIP_STEP(6) STRIP_STEP(7) STRIP_STEP(8) STRIP_STEP(9) STRIP_STEP(10) STRIP_STEP(11)
   STRIP_STEP(12) STRIP_STEP(13) STRIP_STEP(14) STRIP_STEP(15) STRIP_STEP(16) STRIP_STEP(17)
@@ -990,6 +1004,7 @@ __device__ __forceinline__ bool assemble_eliminate_halo(const int last, double *
   // elimination's dependent chain with the next frame's accumulation; two per SIMD did not care)
 #define STRIP_SB(bit) do { if (!((MLPG_STRIP_SCHED_RELAX) & (bit))) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define STRIP_STEP(S)                                                                   \
+  if ((S) < kM + 2) {                                                                   \
   accumulate_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1);                            \
   STRIP_SB(1);                                                                          \
   if ((S) + kRing < kM + 2) { load_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1 + kRing); } \
@@ -999,7 +1014,8 @@ __device__ __forceinline__ bool assemble_eliminate_halo(const int last, double *
     for (int q = 0; q < 5; ++q) lds_yb[(slot_out * 5 + q) * 64 + lane] = (BWD && (q == 2 || q == 4)) ? 0.0 : y[q]; \
   }                                                                                     \
   if ((S)-2 >= 0 && (S)-2 < kN) { elim_row((S)-2); }                                    \
-  STRIP_SB(4);
+  STRIP_SB(4);                                                                          \
+  }
   STRIP_STEP(0) STRIP_STEP(1) STRIP_STEP(2) STRIP_STEP(3) STRIP_STEP(4) STRIP_STEP(5)
   STRIP_STEP(6) STRIP_STEP(7) STRIP_STEP(8) STRIP_STEP(9) STRIP_STEP(10) STRIP_STEP(11)
   STRIP_STEP(12) STRIP_STEP(13) STRIP_STEP(14) STRIP_STEP(15) STRIP_STEP(16) STRIP_STEP(17)
@@ -1056,7 +1072,7 @@ __device__ __forceinline__ void backsub(const double (&Pd)[kM], const double (&P
 // counts is compiled into the kernel (round 5: those forms alone cost the backward instances ~280 spilled scalar
 // registers and 20 k instructions of code); NW3 = false serves one, two or more than three windows.
 template <typename TIN, typename TOUT, bool BWD, int VM, bool MULTI = false, bool NW3 = true>
-__global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem p, WinSet ws, Args a) {
+__global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem p, WinSet ws, Args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   double *lds_rec = (double *)smem;                                  // [kW][kRec][64]   (level 1 -> 2)
   double *lds_stage = (double *)smem;                                // [kStage][kRec][64] (level 3), same bytes
@@ -1470,8 +1486,10 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
       }
       __builtin_amdgcn_sched_barrier(0);
 #define STRIP_EPI(S)                                                        \
+      if ((S) < kEpi) {                                                       \
       emitf((S));                                                             \
-      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);                                      \
+      }
       STRIP_EPI(0) STRIP_EPI(1) STRIP_EPI(2) STRIP_EPI(3) STRIP_EPI(4) STRIP_EPI(5) STRIP_EPI(6) STRIP_EPI(7) STRIP_EPI(8)
       STRIP_EPI(9) STRIP_EPI(10) STRIP_EPI(11) STRIP_EPI(12) STRIP_EPI(13) STRIP_EPI(14) STRIP_EPI(15) STRIP_EPI(16)
 #undef STRIP_EPI
@@ -1511,10 +1529,12 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
 #endif
   };  // tail
   if (wv == 0) {
+    if (kParkOn) {
 #pragma unroll
-    for (int i = 0; i < kN; ++i) {
-      lds_park[i * 64 + lane] = rhs[i];
-      lds_park[(kN + i) * 64 + lane] = P2[i];
+      for (int i = 0; i < kN; ++i) {
+        lds_park[i * 64 + lane] = rhs[i];
+        lds_park[(kN + i) * 64 + lane] = P2[i];
+      }
     }
     S2 E_s = {1.0, 0.0, 1.0};
     V2 g_s = {0.0, 0.0};
@@ -1600,7 +1620,7 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
         if (lane == 0) lds_misc[3] = route;
       }
       const int kwin = route ? route : kLocal;
-      if (route && route <= kLocal) {
+      if (route && route <= kLocal && 2 * route + 1 <= kStage) {
         // the narrow windows' sweep takes this strip's own record from here (the last place of the staged order),
         // not from HBM.  (lds_rec, the same bytes, has been consumed by level 2.)
         const Window w = local_window(r, Ract, route);
@@ -1836,10 +1856,12 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
       up[((j + 1) * 2) * 64] = uj.x; up[((j + 1) * 2 + 1) * 64] = uj.y;
       un = uj;
     }
+    if (kParkOn) {
 #pragma unroll
-    for (int i = 0; i < kN; ++i) {
-      rhs[i] = lds_park[i * 64 + lane];
-      P2[i] = lds_park[(kN + i) * 64 + lane];
+      for (int i = 0; i < kN; ++i) {
+        rhs[i] = lds_park[i * 64 + lane];
+        P2[i] = lds_park[(kN + i) * 64 + lane];
+      }
     }
     if (kSplitTail) tail(std::integral_constant<bool, kKeepTau && MLPG_STRIP_BWD_KEEP0>{}, std::integral_constant<int, kEarly0>{});
   } else {
@@ -1893,7 +1915,7 @@ __global__ __launch_bounds__(kW * 64, kW <= 4 ? 2 : 1) void strip_kernel(Problem
         skip_own = false;
         stage(0, Ract - 1);
       } else {
-        skip_own = route <= kLocal;  // only the narrow (single-batch) windows have this strip's own record in LDS already
+        skip_own = route <= kLocal && 2 * route + 1 <= kStage;  // only the narrow (single-batch) windows have this strip's own record in LDS already
         stage(w.lo, w.hiE);
         __syncthreads();  // (S2b) wavefront 0's decision: is the window enough?
         if (!__builtin_amdgcn_readfirstlane(lds_misc[2])) {
