@@ -707,8 +707,38 @@ def gather_path(src, path, path_len, Tout):
     return out
 
 
-_MSE_WORKSPACE = {}
-_MSE_WORKSPACE_RETIRED = []   # outgrown workspaces stay allocated: a captured graph may still replay kernels that use them
+_MSE_WORKSPACE = {}           # (device, stream) -> [tensor, used inside a stream capture]
+_MSE_WORKSPACE_RETIRED = []   # outgrown workspaces a captured graph may still replay kernels on (only those: see below)
+_MSE_NEED = {}                # (B, T, D, nw, with FIR dy buffer) -> bytes (mlpg_hip_unit_mse_workspace_bytes[_t])
+
+
+def _mse_workspace(device, B, T, D, nw, fir_form):
+    """The per-(device, stream) workspace of mlpg_hip_unit_mse_step.  Zeroed once (the kernel leaves its arrival counter
+    zero); grown geometrically (length-bucketed or ascending batches would otherwise reallocate at almost every new
+    maximum); the FIR form's dy buffer (B * T * sd floats) is only asked for by batches that can take that form; an
+    outgrown buffer is kept alive only if a stream capture has used it (a graph may still replay kernels on it)."""
+    torch = torch_mod()
+    nk = (B, T, D, nw, fir_form)
+    need = _MSE_NEED.get(nk)
+    if need is None:
+        L = lib()
+        need = int(L.mlpg_hip_unit_mse_workspace_bytes_t(B, T, D, nw) if fir_form else L.mlpg_hip_unit_mse_workspace_bytes(B, D, nw))
+        if len(_MSE_NEED) > 4096:
+            _MSE_NEED.clear()
+        _MSE_NEED[nk] = need
+    stream = torch.cuda.current_stream(device)
+    key = (device.index, stream.cuda_stream)
+    ent = _MSE_WORKSPACE.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ent is None or ent[0].numel() < need:
+        size = need if ent is None else max(need, ent[0].numel() * 3 // 2)
+        if ent is not None and ent[1]:
+            _MSE_WORKSPACE_RETIRED.append(ent[0])
+        ent = [torch.zeros((size + 4095) // 4096 * 4096, dtype=torch.uint8, device=device), False]
+        _MSE_WORKSPACE[key] = ent
+    if capturing:
+        ent[1] = True
+    return ent[0], stream
 
 
 def unit_mse_step(mean, target, windows, lengths=None, n_elems=None, want_y=False, want_status=False):
@@ -731,19 +761,9 @@ def unit_mse_step(mean, target, windows, lengths=None, n_elems=None, want_y=Fals
     y = torch.empty_like(target) if want_y else None
     loss = torch.empty((), dtype=torch.float64, device=mean.device)
     status = torch.empty((B * sd,), dtype=torch.int32, device=mean.device) if want_status else None
-    # (the _t form: with room for the FIR form's dy buffer, which float32 batches without lengths of T >= 96 take)
-    need = int(lib().mlpg_hip_unit_mse_workspace_bytes_t(B, T, D, nw))
-    stream = torch.cuda.current_stream(mean.device)
-    key = (mean.device.index, stream.cuda_stream)
-    ws = _MSE_WORKSPACE.get(key)
-    if ws is None or ws.numel() < need:
-        # zeroed once; the kernel leaves its arrival counter zero.  One per (device, stream): concurrent streams do not share
-        # it; allocated on first use outside any capture (warm up a step before capturing it into a graph).
-        if ws is not None:
-            _MSE_WORKSPACE_RETIRED.append(ws)
-        ws = torch.zeros((need + 4095) // 4096 * 4096, dtype=torch.uint8, device=mean.device)
-        _MSE_WORKSPACE[key] = ws
-    rc = lib().mlpg_hip_unit_mse_step(mean.device.index, _stream(mean.device), _dt(mean), _p(mean), _p(target), _p(lengths),
+    # (the FIR form -- float32 batches without lengths of T >= 96 -- needs room for its dy buffer)
+    ws, stream = _mse_workspace(mean.device, B, T, D, nw, mean.dtype == torch.float32 and lengths is None and T >= 96)
+    rc = lib().mlpg_hip_unit_mse_step(mean.device.index, ctypes.c_void_p(stream.cuda_stream), _dt(mean), _p(mean), _p(target), _p(lengths),
                                       B, T, D, nw, _np(wl), _np(wu), _np(wc), float(n_elems), _p(y), _p(grad), _p(loss),
                                       _p(status), _p(ws), ws.numel())
     _check(rc, "mlpg_hip_unit_mse_step")

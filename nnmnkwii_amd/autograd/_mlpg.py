@@ -281,15 +281,22 @@ class _UnitVarianceMLPGWindows(Function):
 
 
 def _fused_step_applies(windows, means, target):
-    """What mlpg_hip_unit_mse_step accepts (csrc/mlpg_wave_fused.hip unit_mse_supported) and what the fused node can
-    differentiate: T <= 1024, window extents <= 1, no gradient wanted for the target."""
+    """What mlpg_hip_unit_mse_step accepts (csrc/capi.hip: the FIR form for float32 batches of T >= 96 with window extents
+    <= 2 and a single-tap static window, any length; otherwise the one-launch kernel, csrc/mlpg_wave_fused.hip
+    unit_mse_supported: T <= 1024, window extents <= 1) and what the fused node can differentiate: no gradient wanted for
+    the target."""
     if torch.is_tensor(target) and target.requires_grad:
         return False
-    if means.shape[-2] > 1024:
-        return False
     if isinstance(windows, _hip.PackedWindows):          # (l[], u[], coeff[], nw): what _identify_R hands back
-        return bool((np.asarray(windows[0]) <= 1).all() and (np.asarray(windows[1]) <= 1).all())
-    return all(int(l) <= 1 and int(u) <= 1 for l, u, _ in windows)
+        ls, us = np.asarray(windows[0]), np.asarray(windows[1])
+    else:
+        ls, us = np.asarray([int(l) for l, _, _ in windows]), np.asarray([int(u) for _, u, _ in windows])
+    ext = int(max(ls.max(), us.max())) if len(ls) else 0
+    T = means.shape[-2]
+    if ext <= 1 and T <= 1024:
+        return True
+    fir = means.dtype == torch.float32 and T >= 96 and ext <= 2 and 1 <= len(ls) <= 3 and int(ls[0]) == 0 and int(us[0]) == 0
+    return bool(fir)
 
 
 def unit_variance_mlpg_mse_loss(R_or_windows, means, target):
@@ -297,8 +304,8 @@ def unit_variance_mlpg_mse_loss(R_or_windows, means, target):
     (:class:`UnitVarianceMLPGMSELoss`).  The first argument is either the matrix ``R`` from
     :func:`nnmnkwii_amd.paramgen.unit_variance_mlpg_matrix` (recognised by content, as in
     :func:`unit_variance_mlpg`) or the window list itself.  Falls back to the two-node form -- same value, same
-    gradients -- for a foreign ``R``, for T > 1024 or window extents > 1 (the fused kernel's limits) and when
-    ``target`` wants a gradient.  The loss lives on ``means.device`` (as in the eager form)."""
+    gradients -- for a foreign ``R``, outside the step's limits (float32 batches of 96 frames and more: window extents <= 2;
+    otherwise T <= 1024 and window extents <= 1) and when ``target`` wants a gradient.  The loss lives on ``means.device`` (as in the eager form)."""
     if torch.is_tensor(R_or_windows):
         ident = _identify_R(R_or_windows)
         if ident is None or means.shape[-2] != R_or_windows.shape[0]:

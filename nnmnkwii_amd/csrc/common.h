@@ -94,6 +94,9 @@ bool const_supported(const Problem &p, const WinSet &w);
 bool const_scratch_fresh(int device, hipStream_t stream, unsigned long long gen);
 // unit variances: true if this (device, stream) last built its table from the same key on the same scratch allocation
 bool const_unit_table_cached(int device, hipStream_t stream, unsigned long long gen, bool fresh, const double *key, int n);
+// strip kernel: do the workgroups of a launch on the current device spread evenly over eight XCDs (HW_REG_XCC_ID)?  Probed once
+// per device with a small kernel (mlpg_strip.hip); false while `st` is being captured and the device has not been probed yet.
+bool strip_xcd_lists_ok(hipStream_t st);
 bool const_preferred(const Problem &p, const WinSet &w);
 int launch_const(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
 bool chunk_supported(const Problem &p, const WinSet &w);

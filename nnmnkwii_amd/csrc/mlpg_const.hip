@@ -31,6 +31,9 @@ bool const_unit_table_cached(int device, hipStream_t stream, unsigned long long 
   struct Entry {
     unsigned long long gen = 0;
     std::vector<double> key;
+    bool captured = false;  // a capture ran on this (device, stream): its graph holds THIS stream's scratch table and rewrites
+                            // it (fresh = 1) on every replay, on whatever stream and without passing through here -- the host
+                            // can no longer know what the table holds, so the device-side key check runs on every launch again
   };
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, Entry> seen;
@@ -40,9 +43,11 @@ bool const_unit_table_cached(int device, hipStream_t stream, unsigned long long 
   Entry &e = seen[{device, stream}];
   // (the table is shared with the global-variance launches of this stream: any of those in between rewrites it, and the
   // device-side key would notice -- the host-side one cannot, so a global-variance launch forgets the entry, see below)
-  const bool same = !fresh && !capturing && e.gen == gen && (int)e.key.size() == n && std::equal(e.key.begin(), e.key.end(), key);
+  if (capturing) e.captured = true;
+  const bool same = !fresh && !capturing && !e.captured && e.gen == gen && (int)e.key.size() == n && std::equal(e.key.begin(), e.key.end(), key);
   e.gen = capturing ? 0ull : gen;
-  e.key.assign(key, key + n);
+  if (n > 0) e.key.assign(key, key + n);
+  else e.key.clear();
   if (capturing) e.key.clear();
   return same;
 }

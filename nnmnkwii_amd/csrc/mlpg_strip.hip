@@ -89,6 +89,53 @@ void *strip_scratch(hipStream_t st, int device, size_t nsg, int R, bool *zero_ct
 }
 }  // namespace
 
+// ---- XCC_ID probe ----
+// Long utterances (more strips than a work list may hold) are dealt to all eight per-XCD lists in blocks, and a strip that
+// waits for its whole utterance then needs EVERY list to be drawn by somebody.  A workgroup draws from the list of the XCD
+// it runs on and helps the others only once its own is exhausted, so on a device whose workgroups do not land on eight XCDs
+// in roughly equal numbers (CPX / DPX / QPX partitions, parts with fewer XCDs) some lists would have no home workgroups and
+// the waiting ones would spin on strips nobody draws.  Asked of the hardware itself, once per device: a grid of small
+// workgroups, each adding one to the counter of its HW_REG_XCC_ID.
+namespace {
+__global__ void xcc_probe_kernel(int *hist) {
+  if (threadIdx.x == 0) atomicAdd(hist + (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7), 1);
+}
+}  // namespace
+bool strip_xcd_lists_ok(hipStream_t st) {
+  static std::mutex mu;
+  static std::map<int, bool> seen;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = seen.find(dev);
+  if (it != seen.end()) return it->second;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return false;  // (not cached: the first launch outside a capture probes)
+  }
+  bool ok = false, probed = false;
+  int *d = nullptr;
+  int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int kBlocks = 4096;
+  if (hipMalloc(&d, sizeof(h)) == hipSuccess) {
+    // (the default stream: synchronous with respect to the caller's work only through this function's own waits)
+    if (hipMemset(d, 0, sizeof(h)) == hipSuccess) {
+      hipLaunchKernelGGL(xcc_probe_kernel, dim3(kBlocks), dim3(64), 0, 0, d);
+      if (hipGetLastError() == hipSuccess && hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+        int lo = h[0], hi = h[0];
+        for (int k = 1; k < 8; ++k) { lo = h[k] < lo ? h[k] : lo; hi = h[k] > hi ? h[k] : hi; }
+        ok = lo > 0 && 2 * lo >= hi;
+        probed = true;
+      }
+    }
+    (void)hipFree(d);
+  }
+  (void)hipGetLastError();
+  if (probed) seen[dev] = ok;  // (a runtime failure -- e.g. another stream's capture forbids the allocation -- is not cached)
+  return ok;
+}
+
 int launch_strip(hipStream_t st, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &ws,
                  int device) {
   const int R = (p.Tmax + kStripFrames - 1) / kStripFrames;

@@ -2110,7 +2110,10 @@ int launch_impl(hipStream_t st, const Problem &p, const WinSet &ws, void *scratc
     a.nb = 1;
     a.bs = R;
     a.nlists = 1;
-    if (nitems >= 512 && cap >= 1 && (R <= cap || !MULTI)) {
+    // (an utterance spread over several lists needs every list to have home workgroups: only on a device whose workgroups
+    // land on eight XCDs in equal shares -- strip_xcd_lists_ok(), probed once per device; otherwise such launches keep ONE
+    // list, which holds whole utterances and depends on no placement)
+    if (nitems >= 512 && cap >= 1 && (R <= cap || (!MULTI && strip_xcd_lists_ok(st)))) {
       a.nlists = kMaxLists;
       a.nb = (R + cap - 1) / cap;
       a.bs = (R + a.nb - 1) / a.nb;

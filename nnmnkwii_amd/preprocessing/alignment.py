@@ -17,6 +17,18 @@ def _default_dist(x, y):
     return norm(x - y)
 
 
+_warned = set()
+
+
+def _warn_once(key, msg):
+    """One RuntimeWarning per process and kind: the host-cost route is correct but 1000x slower than the device-side costs,
+    and falling onto it silently is how a typo in `dist` turns a millisecond into minutes."""
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 def _resolve_dist(dist):
     """Map a ``dist`` callable onto a local cost the HIP kernel evaluates: (dist_kind, dist_scale).
 
@@ -48,7 +60,9 @@ def _resolve_dist(dist):
     probes = [(rng.randn(D), rng.randn(D)) for D in (1, 5, 25) for _ in range(3)]
     try:
         vals = np.asarray([float(dist(x, y)) for x, y in probes])
-    except Exception:        # a callable that does not like the probes: it is simply called per cell
+    except Exception as e:   # a callable that does not like the probes: it is simply called per cell
+        _warn_once("probe", "DTWAligner: `dist` raised %s on the probe frames; it will be called once per window cell on the "
+                            "host (reference speed) instead of being evaluated on the GPU" % type(e).__name__)
         return None
     for kind, form in forms:
         ratios = vals / np.asarray([form(x, y) for x, y in probes])
@@ -110,6 +124,13 @@ class DTWAligner(object):
         tie = _hip.TIE_FIRST_MIN if getattr(self, "tie_rule", "first") == "first" else _hip.TIE_DIAG_LAST
         dev = _hip.require_gpu()
         if resolved is None:
+            _warn_once("callable", "DTWAligner: `dist` is none of the distances the kernel evaluates itself (Euclidean, city-block, "
+                                   "squared Euclidean, or a positive multiple such as metrics.melcd): the local costs are evaluated "
+                                   "on the host, one Python call per window cell, as upstream fastdtw does")
+            if getattr(self, "devices", None) is not None:
+                _warn_once("devices", "DTWAligner: `devices` is ignored for a host-evaluated `dist` (the DP runs on the current GPU)")
+            if self.verbose > 0:
+                print("DTWAligner: host-evaluated local costs (dist = %r)" % (self.dist,))
             return self._paths_callable(X, Y, tie, dev)
         dist_kind, dist_scale = resolved
         devices = getattr(self, "devices", None)

@@ -140,6 +140,22 @@ def test_dtw_custom_dist_is_evaluated_on_the_host_and_needs_the_gpu_for_the_rest
     assert d.radius == 1 and d.verbose == 0 and callable(d.dist) and d.tie_rule == "first"
 
 
+def test_dtw_broken_dist_warns_instead_of_falling_back_silently():
+    """a `dist` that raises on the probe frames used to be swallowed (and the alignment silently went the
+    per-cell host route); now it says so, once per process."""
+    import warnings
+    from nnmnkwii_amd.preprocessing import alignment as A
+    A._warned.discard("probe")
+
+    def broken(x, y):
+        raise ValueError("typo")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert A._resolve_dist(broken) is None
+        assert A._resolve_dist(broken) is None
+    assert len([x for x in w if issubclass(x.category, RuntimeWarning) and "probe frames" in str(x.message)]) == 1
+
+
 def test_compat_install_provides_the_reference_names():
     """nnmnkwii_amd.compat: user code written against ``nnmnkwii`` resolves to the HIP path (no GPU needed to import)."""
     import sys

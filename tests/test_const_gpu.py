@@ -183,3 +183,43 @@ def test_const_unit_table_is_reused_and_invalidated_correctly():
         sel = [0, 1, 77, 199]
         yo, _, rc = O.mlpg_batch(M_[sel], np.ones(nw * sd) if var is None else var, windows)
         assert rc == 0 and rel_err(ys[sel].reshape(-1, sd), yo.reshape(-1, sd)) <= TOL64, (wname, T, mode)
+
+
+def test_const_unit_table_survives_graph_replays_on_the_same_stream():
+    """a captured launch bakes the capture stream's scratch table into its graph and rebuilds it on every
+    replay without passing through the host; an eager unit-variance call on that stream afterwards must not trust the
+    host-side 'same as last time' shortcut.  Sequence: eager A, capture B, eager A, replay B, eager A -- all against the
+    oracle."""
+    import torch
+    from nnmnkwii_amd import _hip
+    rng = np.random.RandomState(31)
+    sd = 40
+    wA, wB = WINDOW_SETS["std3"], WINDOW_SETS["asym2"]
+    MA = rng.randn(200, 150, len(wA) * sd)
+    MB = rng.randn(200, 97, len(wB) * sd)
+    refA, _, rcA = O.mlpg_batch(MA[:3], np.ones(len(wA) * sd), wA)
+    refB, _, rcB = O.mlpg_batch(MB[:3], np.ones(len(wB) * sd), wB)
+    assert rcA == 0 and rcB == 0
+    s = torch.cuda.Stream()
+    mA, mB = torch.from_numpy(MA).cuda(), torch.from_numpy(MB).cuda()
+    torch.cuda.synchronize()
+
+    def eager_a():
+        with torch.cuda.stream(s):
+            y, _ = _hip.forward(mA, None, wA, None, algo=_hip.ALGO_CONST)
+        s.synchronize()
+        return y[:3].cpu().numpy()
+
+    assert rel_err(eager_a().reshape(-1, sd), refA.reshape(-1, sd)) <= TOL64
+    with torch.cuda.stream(s):
+        _hip.forward(mB, None, wB, None, algo=_hip.ALGO_CONST, want_status=False)   # warm-up: scratch grown outside the capture
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        yB, _ = _hip.forward(mB, None, wB, None, algo=_hip.ALGO_CONST, want_status=False)
+    assert rel_err(eager_a().reshape(-1, sd), refA.reshape(-1, sd)) <= TOL64
+    for _ in range(2):
+        g.replay()
+        torch.cuda.synchronize()
+        assert rel_err(yB[:3].cpu().numpy().reshape(-1, sd), refB.reshape(-1, sd)) <= TOL64
+        assert rel_err(eager_a().reshape(-1, sd), refA.reshape(-1, sd)) <= TOL64
