@@ -192,13 +192,20 @@ def torch_mod():
     return torch
 
 
+_gpu_ok = False   # torch.cuda.is_available() has been seen True and the library is loaded (neither changes afterwards)
+
+
 def require_gpu(device=None):
     """Return a torch.device for the GPU to use, or raise (no CPU fallback)."""
+    global _gpu_ok
+    if _gpu_ok and device is not None and device.__class__.__name__ == "device" and device.type == "cuda" and device.index is not None:
+        return device            # the hot path: a tensor's own device (torch.cuda.is_available() alone costs microseconds)
     torch = torch_mod()
     lib()
     if not torch.cuda.is_available():
         raise HipExtensionError("nnmnkwii_amd needs an AMD GPU (torch.cuda.is_available() is False); "
                                 "there is no CPU fallback")
+    _gpu_ok = True
     if device is None:
         return torch.device("cuda", torch.cuda.current_device())
     device = torch.device(device)
@@ -211,7 +218,23 @@ def require_gpu(device=None):
 
 class PackedWindows(tuple):
     """(int32 l[], int32 u[], float64 coeff[], num_windows): what pack_windows returns; pass it instead of the window
-    list to skip the packing in a hot loop."""
+    list to skip the packing in a hot loop.  `ptrs()`: the three host addresses as ints (computed once: numpy's
+    `.ctypes.data_as` costs microseconds per call, the C ABI takes the address itself)."""
+
+    def ptrs(self):
+        pt = self.__dict__.get("_ptrs")
+        if pt is None:
+            pt = self.__dict__["_ptrs"] = (self[0].ctypes.data, self[1].ctypes.data, self[2].ctypes.data)
+        return pt
+
+
+def _win_args(windows):
+    """(num_windows, address of l[], u[], coeff[], keep-alive) for the C ABI."""
+    if isinstance(windows, PackedWindows):
+        a, b, c = windows.ptrs()
+        return windows[3], a, b, c, windows
+    wl, wu, wc = pack_windows(windows)
+    return len(wl), wl.ctypes.data, wu.ctypes.data, wc.ctypes.data, (wl, wu, wc)
 
 
 def pack_windows(windows):
@@ -253,15 +276,25 @@ def _dt(t):
 
 
 def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()      # (argtypes are declared: ctypes converts the int itself)
 
 
 def _np(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+_raw_stream = None
+
+
 def _stream(device):
-    return ctypes.c_void_p(torch_mod().cuda.current_stream(device).cuda_stream)
+    """The current torch stream of `device` as the raw hipStream_t (an int).  torch._C._cuda_getCurrentRawStream is the
+    cheap way (what torch's own compiled code uses); torch.cuda.current_stream(...) builds a Stream object per call."""
+    global _raw_stream
+    if _raw_stream is None:
+        torch = torch_mod()
+        f = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        _raw_stream = f if f is not None else (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+    return _raw_stream(device.index if device.index is not None else torch_mod().cuda.current_device())
 
 
 def forward(mean, var, windows, lengths=None, algo=ALGO_AUTO, want_status=True):
@@ -275,8 +308,7 @@ def forward(mean, var, windows, lengths=None, algo=ALGO_AUTO, want_status=True):
     torch = torch_mod()
     assert mean.is_cuda and mean.dim() == 3 and mean.is_contiguous()
     B, T, D = mean.shape
-    nw = _nw(windows)
-    wl, wu, wc = pack_windows(windows)
+    nw, pl, pu, pc, _keep = _win_args(windows)
     if var is None:
         mode = VAR_UNIT
     elif var.dim() == 1:
@@ -291,7 +323,7 @@ def forward(mean, var, windows, lengths=None, algo=ALGO_AUTO, want_status=True):
     out = torch.empty((B, T, D // nw), dtype=mean.dtype, device=mean.device)
     status = torch.empty((B * (D // nw),), dtype=torch.int32, device=mean.device) if want_status else None
     rc = lib().mlpg_hip_forward(mean.device.index, _stream(mean.device), _dt(mean), algo, _p(mean), _p(var), mode,
-                                _p(lengths), B, T, D, nw, _np(wl), _np(wu), _np(wc), _p(out), _p(status))
+                                _p(lengths), B, T, D, nw, pl, pu, pc, _p(out), _p(status))
     _check(rc, "mlpg_hip_forward")
     return out, status
 
@@ -460,9 +492,8 @@ def backward(var, grad_out, windows, D, lengths=None, out_dtype=None, algo=ALGO_
     torch = torch_mod()
     assert grad_out.is_cuda and grad_out.dim() == 3 and grad_out.is_contiguous()
     B, T, sd = grad_out.shape
-    nw = _nw(windows)
+    nw, pl, pu, pc, _keep = _win_args(windows)
     assert sd * nw == D
-    wl, wu, wc = pack_windows(windows)
     if var is None:
         mode = VAR_UNIT
     elif var.dim() == 1:
@@ -476,7 +507,7 @@ def backward(var, grad_out, windows, D, lengths=None, out_dtype=None, algo=ALGO_
     grad = torch.empty((B, T, D), dtype=out_dtype, device=grad_out.device)
     status = torch.empty((B * sd,), dtype=torch.int32, device=grad_out.device) if want_status else None
     rc = lib().mlpg_hip_backward(grad_out.device.index, _stream(grad_out.device), _dt(grad_out), _dt(grad), algo,
-                                 _p(var), mode, _p(grad_out), _p(lengths), B, T, D, nw, _np(wl), _np(wu), _np(wc),
+                                 _p(var), mode, _p(grad_out), _p(lengths), B, T, D, nw, pl, pu, pc,
                                  _p(grad), _p(status))
     _check(rc, "mlpg_hip_backward")
     return grad, status
@@ -726,8 +757,8 @@ def _mse_workspace(device, B, T, D, nw, fir_form):
         if len(_MSE_NEED) > 4096:
             _MSE_NEED.clear()
         _MSE_NEED[nk] = need
-    stream = torch.cuda.current_stream(device)
-    key = (device.index, stream.cuda_stream)
+    stream = _stream(device)
+    key = (device.index, stream)
     ent = _MSE_WORKSPACE.get(key)
     capturing = torch.cuda.is_current_stream_capturing()
     if ent is None or ent[0].numel() < need:
@@ -749,10 +780,9 @@ def unit_mse_step(mean, target, windows, lengths=None, n_elems=None, want_y=Fals
     torch = torch_mod()
     assert mean.is_cuda and mean.dim() == 3 and mean.is_contiguous() and target.is_contiguous()
     B, T, D = mean.shape
-    nw = _nw(windows)
+    nw, pl, pu, pc, _keep = _win_args(windows)
     sd = D // nw
     assert target.shape == (B, T, sd) and target.dtype == mean.dtype and target.device == mean.device
-    wl, wu, wc = pack_windows(windows)
     if lengths is not None:
         assert lengths.dtype == torch.int32 and lengths.shape == (B,) and lengths.device == mean.device
     if n_elems is None:
@@ -763,8 +793,8 @@ def unit_mse_step(mean, target, windows, lengths=None, n_elems=None, want_y=Fals
     status = torch.empty((B * sd,), dtype=torch.int32, device=mean.device) if want_status else None
     # (the FIR form -- float32 batches without lengths of T >= 96 -- needs room for its dy buffer)
     ws, stream = _mse_workspace(mean.device, B, T, D, nw, mean.dtype == torch.float32 and lengths is None and T >= 96)
-    rc = lib().mlpg_hip_unit_mse_step(mean.device.index, ctypes.c_void_p(stream.cuda_stream), _dt(mean), _p(mean), _p(target), _p(lengths),
-                                      B, T, D, nw, _np(wl), _np(wu), _np(wc), float(n_elems), _p(y), _p(grad), _p(loss),
+    rc = lib().mlpg_hip_unit_mse_step(mean.device.index, stream, _dt(mean), _p(mean), _p(target), _p(lengths),
+                                      B, T, D, nw, pl, pu, pc, float(n_elems), _p(y), _p(grad), _p(loss),
                                       _p(status), _p(ws), ws.numel())
     _check(rc, "mlpg_hip_unit_mse_step")
     return loss, grad, y, status

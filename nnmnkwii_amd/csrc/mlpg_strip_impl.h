@@ -111,6 +111,9 @@ constexpr int kCtrlLine = 32;
                                // formed in float32, _mlpg.py:188) stay in registers from the assembly to the epilogue -- no second
                                // pass over the variances, no second division (round 5)
 #endif
+#ifndef MLPG_STRIP_BWD_BUFSTORE
+#define MLPG_STRIP_BWD_BUFSTORE 1  // backward epilogue (three windows): gradient rows by buffer stores (scalar offsets) instead of global stores
+#endif
 #ifndef MLPG_STRIP_BWD_KARG
 #define MLPG_STRIP_BWD_KARG 1  // backward, three windows: window coefficients by placed scalar loads from the argument segment (karg_f64x6)
 #endif
@@ -131,7 +134,9 @@ constexpr int kCtrlLine = 32;
                                 // written) while this item back-substitutes: its first ring then comes out of L2 (0: off)
 #endif
 #ifndef MLPG_STRIP_NT_STORES
-#define MLPG_STRIP_NT_STORES 0  // trajectory rows with the nontemporal hint (written once, never read by this kernel)
+#define MLPG_STRIP_NT_STORES 1  // trajectory and gradient rows with the nontemporal hint (written once, never read by this kernel); round 5 A/B
+                                // (profiles/r05_strip_stores_ab.txt): forward f64 +1.9 %, backward f32 +5.5 %.  (Round 3 measured the same gain and
+                                // its notes called it shipped, but the default stayed 0 until round 5.)
 #endif
 #ifndef MLPG_STRIP_SCHED_RELAX
 #define MLPG_STRIP_SCHED_RELAX 0
@@ -365,6 +370,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
   const unsigned long long u = (unsigned long long)base;
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
   return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+
+// row stores through a buffer descriptor (backward epilogue): scalar row/window offset + one lane offset, no 64-bit
+// address arithmetic per store
+__device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff, double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const u32x2 w = {(unsigned)u, (unsigned)(u >> 32)};
+  __builtin_amdgcn_raw_buffer_store_b64(w, rs, loff, soff, MLPG_STRIP_NT_STORES ? 2 : 0);
+}
+__device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, loff, soff, MLPG_STRIP_NT_STORES ? 2 : 0);
 }
 
 // Window coefficients straight from the kernel-argument segment, as scalar loads PLACED by the caller (backward
@@ -1429,6 +1445,9 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
 #pragma unroll
         for (int w = 0; w < 3; ++w) tg[w] = tau_of<TIN>(vglob[w * sd]);
       }
+      const __amdgpu_buffer_rsrc_t ors_e = make_rsrc(out_b);
+      const unsigned ooff_e = (unsigned)d * (unsigned)sizeof(TOUT);
+      (void)ors_e; (void)ooff_e;
       // the three coefficients per window (entries 0 .. 2 of wc[w]), fetched here (see karg_f64x6)
       double we[3][3];
       if (MLPG_STRIP_BWD_KARG) {
@@ -1444,9 +1463,15 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
         const int t = f0 + i;
         if (t < 0 || t >= Tmax) return;
         TOUT *orow = out_b + (size_t)t * ldo + d;
+        unsigned row_off = (unsigned)t * (unsigned)ldo * (unsigned)sizeof(TOUT);
+        if (MLPG_STRIP_BWD_BUFSTORE) asm volatile("" : "+s"(row_off));  // (not one of 17 loop invariants held in scalar registers)
         auto put = [&](const int w, const TOUT val) __attribute__((always_inline)) {
 #ifdef MLPG_STRIP_BWD_NOSTORE  // timing experiment only
           if (val == (TOUT)123.456) orow[(size_t)w * sd] = val;
+          return;
+#endif
+#if MLPG_STRIP_BWD_BUFSTORE
+          st_row(ors_e, row_off + (unsigned)w * (unsigned)sd * (unsigned)sizeof(TOUT), ooff_e, val);
           return;
 #endif
 #if MLPG_STRIP_NT_STORES

@@ -240,6 +240,19 @@ def mlpg(mean_frames, variance_frames, windows):
     ``(T, D)`` or global ``(D,)`` variances, raises ``AssertionError`` on a shape
     mismatch and ``numpy.linalg.LinAlgError`` ("k-th leading minor not positive
     definite") when a system is not positive definite.
+
+    Windows: what the reference's ``build_win_mats`` accepts (paramgen/_mlpg.py:13-50) within the library's compile-time
+    limits -- at most 8 windows, window extents ``l, u <= 4`` (half-bandwidth of ``P`` <= 8), at most 48 coefficients in
+    total (csrc/common.h: kMaxWindows, kMaxExtent, kMaxCoef); beyond those the call raises ``HipExtensionError`` (the
+    reference itself has no limit).  Which kernel a window set gets (``MLPG_HIP_ALGO_AUTO``; DESIGN.md "AUTO routing",
+    measured in profiles/r05_auto_routing.json):
+
+    * extents <= 1 (the usual static / delta / delta-delta set, also one or two windows): the fast kernels -- strip,
+      wave-per-system, constant-coefficient, FIR -- at 0.4-0.5 of the HBM roofline for wide streams;
+    * extents of 2 (the reference's 5-tap test windows, tests/test_paramgen.py:21-26), up to three windows: the chunked
+      kernel, which reads the inputs twice: 0.22 of the roofline;
+    * more than three windows with an extent of 2, or extents of 3-4: the natural-order kernel, one lane per system and
+      the factor through HBM: 0.04-0.07 of the roofline (correct, slow).
     """
     mean_frames = np.asarray(mean_frames)
     variance_frames = np.asarray(variance_frames)
