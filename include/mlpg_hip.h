@@ -74,8 +74,8 @@ extern "C" {
 int mlpg_hip_abi_version(void);
 const char *mlpg_hip_last_error(void);
 /* Test aid, not part of the reference's interface: launches per MLPG kernel family since the library was loaded --
- * 0 natural-order, 1 wave-per-system, 2 strip, 3 strip with several streams merged, 4 constant-coefficient, 5 fused, 6 chunked, 7 FIR
- * unit-variance step; -1 for any other `kind`.  (Tests use it to assert WHICH kernel a call took.) */
+ * 0 natural-order, 1 wave-per-system, 2 strip, 3 strip with several streams merged, 4 constant-coefficient, 5 fused, 6 chunked, 7 FIR,
+ * 8 constant-coefficient with several streams merged; -1 for any other `kind`.  (Tests use it to assert WHICH kernel a call took.) */
 long long mlpg_hip_launch_count(int kind);
 int mlpg_hip_device_count(void);
 /* Frees the per-device scratch caches. */

@@ -323,6 +323,9 @@ int stream_entry(int device, hipStream_t st, int dtype, int algo, const void *me
   p.ld_gout = 0;
   p.ld_out = ld_out;
   p.ld_status = ld_status;
+  // a piece of a stream (what a merged launch left over) goes to the kernels that take the window pitch separately, whatever
+  // kernel was asked for the call as a whole
+  if (p.pitch && (algo == MLPG_HIP_ALGO_CONST || algo == MLPG_HIP_ALGO_CHUNK || algo == MLPG_HIP_ALGO_FIR)) algo = MLPG_HIP_ALGO_AUTO;
   return dispatch_solve(st, dtype, dtype, algo, false, p, ws, device);
 }
 
@@ -463,7 +466,12 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
   Problem p_merged;
   bool have_merged = false;
   int piece_stream = -1, piece_first = 0;  // stream cut between the merged launch (dims < piece_first) and its own launch
-  if ((algo == MLPG_HIP_ALGO_AUTO || algo == MLPG_HIP_ALGO_STRIP) && var_mode == MLPG_HIP_VAR_FRAME) {
+  // Global (D,) and unit variances (round 5): the same packing, on the constant-coefficient kernel (one workgroup walks one
+  // (utterance, group of 64 lanes) sequence: 60 + 1 + 3 dims of a Merlin-style row in one group, the other 2 bap dims as a piece).
+  const bool merge_strip = (algo == MLPG_HIP_ALGO_AUTO || algo == MLPG_HIP_ALGO_STRIP) && var_mode == MLPG_HIP_VAR_FRAME;
+  const bool merge_const = (algo == MLPG_HIP_ALGO_AUTO || algo == MLPG_HIP_ALGO_CONST) &&
+                           (var_mode == MLPG_HIP_VAR_GLOBAL || var_mode == MLPG_HIP_VAR_UNIT);
+  if (merge_strip || merge_const) {
     int first = -1, cnt = 0, total = 0;
     int members[64];
     size_t coff_first = 0;
@@ -546,11 +554,17 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
       p.ld_gout = 0;
       p.ld_out = ld_out;
       p.ld_status = (int)sd_total;
-      // the decision the widest group would get alone (long utterances, or enough 64-frame strips)
-      Problem pw = p;
-      pw.sd = pos < 64 ? pos : 64;
-      pw.D = 3 * pw.sd;
-      ok = strip_supported(p, ws_merged) && (algo == MLPG_HIP_ALGO_STRIP || strip_preferred(pw, ws_merged, false, dtype));
+      if (merge_strip) {
+        // the decision the widest group would get alone (long utterances, or enough 64-frame strips)
+        Problem pw = p;
+        pw.sd = pos < 64 ? pos : 64;
+        pw.D = 3 * pw.sd;
+        ok = strip_supported(p, ws_merged) && (algo == MLPG_HIP_ALGO_STRIP || strip_preferred(pw, ws_merged, false, dtype));
+      } else {
+        // the constant-coefficient kernel's conditions (const_supported / const_preferred for groups of 64 lanes): a dynamic
+        // window of extent 1, and about a sequence per CU
+        ok = ws_merged.mw == 1 && rows_fit_buffer(p) && (algo == MLPG_HIP_ALGO_CONST || (long)B * ((pos + 63) / 64) >= 192);
+      }
     }
     have_merged = ok;
     if (!ok) {
@@ -615,7 +629,8 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
     }
   }
   if (have_merged) {
-    int rc = launch_strip_multi(main_st, dtype, p_merged, ws_merged, smap, device);
+    int rc = merge_strip ? launch_strip_multi(main_st, dtype, p_merged, ws_merged, smap, device)
+                         : launch_const_multi(main_st, dtype, p_merged, ws_merged, smap, device);
     if (rc == kStripMultiNotResident) {  // the grid cannot hold an utterance (nothing enqueued): one stream after the other
       rc = 0;
       for (int k = 0; k < num_streams && rc == 0; ++k)

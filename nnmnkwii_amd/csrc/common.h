@@ -65,7 +65,7 @@ inline bool rows_fit_buffer(const Problem &p) {
 
 void set_error(const char *fmt, ...);
 // launches per kernel family since the library was loaded (mlpg_hip_launch_count: a test aid)
-enum { kCountGeneric = 0, kCountWave, kCountStrip, kCountStripMulti, kCountConst, kCountFused, kCountChunk, kCountFir, kCountKinds };
+enum { kCountGeneric = 0, kCountWave, kCountStrip, kCountStripMulti, kCountConst, kCountFused, kCountChunk, kCountFir, kCountConstMulti, kCountKinds };
 void note_launch(int kind);
 // Grow-only scratch, cached per (device, stream, slot): slot 0 generic factor, 1 fastdtw pyramids,
 // 2 generic status, 3 strip records, 4 constant-coefficient kernel (factor table), 5 fastdtw from host costs (D rows, back-pointers), 6 chunked kernel (records, block factors, separator solutions, marks).  Returns nullptr (and sets the error) on failure.
@@ -99,6 +99,7 @@ bool const_unit_table_cached(int device, hipStream_t stream, unsigned long long 
 bool strip_xcd_lists_ok(hipStream_t st);
 bool const_preferred(const Problem &p, const WinSet &w);
 int launch_const(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
+int launch_const_multi(hipStream_t s, int dtype, const Problem &p, const WinSet &w, const StreamMap &sm, int device);
 bool chunk_supported(const Problem &p, const WinSet &w);
 bool chunk_preferred(const Problem &p, const WinSet &w, bool backward);
 int launch_chunk(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);

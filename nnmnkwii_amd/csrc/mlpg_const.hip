@@ -13,6 +13,8 @@ int launch_const_fwd_f64(hipStream_t st, int out_dtype, const Problem &p, const 
 int launch_const_fwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, int device, int shape);
 int launch_const_bwd_f64(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, int device, int shape);
 int launch_const_bwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, int device, int shape);
+int launch_const_multi_f64(hipStream_t st, const Problem &p, const WinSet &ws, int device, const StreamMap &sm);
+int launch_const_multi_f32(hipStream_t st, const Problem &p, const WinSet &ws, int device, const StreamMap &sm);
 
 bool const_scratch_fresh(int device, hipStream_t stream, unsigned long long gen) {
   static std::mutex mu;
@@ -84,6 +86,14 @@ int launch_const(hipStream_t st, int dtype, int out_dtype, bool backward, const 
                                  : launch_const_fwd_f64(st, out_dtype, p, ws, device, shape);
   return dtype == MLPG_HIP_F32 ? launch_const_bwd_f32(st, out_dtype, p, ws, device, shape)
                                : launch_const_bwd_f64(st, out_dtype, p, ws, device, shape);
+}
+
+
+// Several streams of one batch in one launch (mlpg_hip_forward_streams with global (D,) or unit variances): the lanes run over
+// the static dims of all of them, full groups of 64 (the caller packs the streams).  p.sd = the merged dims, p.mean / p.var /
+// p.out = the parent arrays (column 0), three windows of extent <= 1.
+int launch_const_multi(hipStream_t st, int dtype, const Problem &p, const WinSet &ws, const StreamMap &sm, int device) {
+  return dtype == MLPG_HIP_F32 ? launch_const_multi_f32(st, p, ws, device, sm) : launch_const_multi_f64(st, p, ws, device, sm);
 }
 
 }  // namespace mlpg

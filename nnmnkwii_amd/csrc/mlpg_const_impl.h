@@ -68,7 +68,18 @@ struct Args {
   // on the host so that the kernel holds them in scalar registers (a product of two scalar doubles formed in the kernel
   // is a vector instruction whose result stays in vector registers for the whole sequence loop)
   double wc[kMaxWindows][9];
+  StreamMap sm;        // MULTI kernels only: the streams whose static dims sit side by side on the lanes
 };
+
+// MULTI kernels: the stream a merged static-dim index belongs to (at most 4 streams, begin[] ascending, unused entries =
+// INT_MAX) and the dim's columns there (as strip::lane_stream)
+struct LaneStream { int sd, din, dstat, dout; };
+__device__ __forceinline__ LaneStream lane_stream(const StreamMap &sm, int d) {
+  const int s_ = (d >= sm.begin[1]) + (d >= sm.begin[2]) + (d >= sm.begin[3]);
+  auto pick = [&](const int (&v)[4]) { return s_ == 0 ? v[0] : s_ == 1 ? v[1] : s_ == 2 ? v[2] : v[3]; };
+  const int dl = d - pick(sm.begin);
+  return {pick(sm.sd), dl + pick(sm.in_col), dl + pick(sm.stat_col), dl + pick(sm.out_col)};
+}
 
 struct V2 { double x, y; };
 struct M2 { double a, b, c, d; };  // [a b; c d]
@@ -165,10 +176,11 @@ __device__ __forceinline__ FacRow ldl_row(double a, double c, double e, const Fa
 }
 __device__ __forceinline__ FacState advance(const FacState &s, const FacRow &r) { return {r.d, r.dinv, s.d1, s.dinv1, r.l1}; }
 
+// (d: the dim's window-0 column, sd: its window pitch -- the stream's own for a merged launch)
 template <typename TIN, int VM, int NW>
-__device__ __forceinline__ void lane_taus(const Problem &p, int d, double (&tau)[NW]) {
+__device__ __forceinline__ void lane_taus(const Problem &p, int d, int sd, double (&tau)[NW]) {
 #pragma unroll
-  for (int w = 0; w < NW; ++w) tau[w] = VM == MLPG_HIP_VAR_GLOBAL ? tau_of<TIN>(((const TIN *)p.var)[w * p.sd + d]) : 1.0;
+  for (int w = 0; w < NW; ++w) tau[w] = VM == MLPG_HIP_VAR_GLOBAL ? tau_of<TIN>(((const TIN *)p.var)[w * sd + d]) : 1.0;
 }
 
 // ---- setup: the T = infinity factor of every dim, until steady ---------------------------------------------------
@@ -178,14 +190,20 @@ __device__ __forceinline__ void lane_taus(const Problem &p, int d, double (&tau)
 // transient ends inside the first super-step: stream_kernel then takes the one-step lag (each chunk decides from its own
 // matrices whether it has to wait at all).
 enum { hA = 0, hB = 4, hL1 = 8, hL2 = 9, hDinv = 10, hTau = 11 };
-template <typename TIN, int VM, int NW>
+template <typename TIN, int VM, int NW, bool MULTI = false>
 __global__ __launch_bounds__(64) void setup_kernel(Problem p, Args a, int M, int W, int fresh) {
   const int lane = threadIdx.x, dg = blockIdx.x;
   const int d0 = dg * a.dgw;
-  const int nd = p.sd - d0 < a.dgw ? p.sd - d0 : a.dgw;
+  const int sd_all = MULTI ? a.sm.total : p.sd;
+  const int nd = sd_all - d0 < a.dgw ? sd_all - d0 : a.dgw;
   const int d = d0 + (lane < nd ? lane : nd - 1);
   double tau[NW];
-  lane_taus<TIN, VM, NW>(p, d, tau);
+  if (MULTI) {
+    const LaneStream ls = lane_stream(a.sm, d);
+    lane_taus<TIN, VM, NW>(p, ls.din, ls.sd, tau);
+  } else {
+    lane_taus<TIN, VM, NW>(p, d, p.sd, tau);
+  }
   // The table is a function of the precisions, the window coefficients and the shape only: a launch that finds them
   // unchanged (the same global variances applied to batch after batch) leaves the table as it is.  `fresh`: the host
   // knows the scratch holds nothing yet.
@@ -330,18 +348,21 @@ __device__ __forceinline__ double live_top(int w, int t) { return (t < 0 || (w !
 // Chunk 0 may start above row 0 (weights 0 above frame 0 and for the dynamic windows on it); the last frame of the
 // utterance's last chunk (= T-1) carries no dynamic precision.
 constexpr int kPipe = 3;  // rows of coefficients in flight
-template <typename TIN, bool BWD, int NW, int RINGA>
+// MULTI (several streams side by side on the lanes): the window pitch is the LANE's (its stream's static dim), so the
+// window offset rides in the lane offset (wlane = pitch in bytes) instead of the scalar one (win_bytes = 0 then)
+template <typename TIN, bool BWD, int NW, int RINGA, bool MULTI = false>
 __device__ __forceinline__ void ring_issue(TIN (&ring)[RINGA][BWD ? 1 : NW], int slot, int k, __amdgpu_buffer_rsrc_t rs,
-                                           unsigned loff, unsigned ld_bytes, unsigned win_bytes, int a0) {
+                                           unsigned loff, unsigned ld_bytes, unsigned win_bytes, int a0, unsigned wlane = 0u) {
   int t = a0 + k;
   t = t < 0 ? 0 : t;  // frames above the utterance's start weigh 0 (chunk 0); never read outside the utterance
 #pragma unroll
-  for (int w = 0; w < (BWD ? 1 : NW); ++w) ring[slot][w] = ld_row<TIN>(rs, (unsigned)t * ld_bytes + (unsigned)w * win_bytes, loff);
+  for (int w = 0; w < (BWD ? 1 : NW); ++w)
+    ring[slot][w] = ld_row<TIN>(rs, (unsigned)t * ld_bytes + (unsigned)w * win_bytes, MULTI ? loff + (unsigned)w * wlane : loff);
 }
-template <typename TIN, bool BWD, int NW, int M, int RING>
+template <typename TIN, bool BWD, int NW, int M, int RING, bool MULTI = false>
 __device__ __forceinline__ void pass1a(TIN (&ring)[RING][BWD ? 1 : NW], __amdgpu_buffer_rsrc_t rs, unsigned loff,
                                        unsigned ld_bytes, unsigned win_bytes, int a0, bool last, const double (&tau)[NW],
-                                       const double (*wc)[9], double (&z)[M], double &up, double &dn) {
+                                       const double (*wc)[9], double (&z)[M], double &up, double &dn, unsigned wlane = 0u) {
   // One instruction stream for every chunk (four specialised copies behind wave-uniform branches made the register
   // allocator spill at the joins): the weights of chunk 0's dead frames are wave-uniform 0/1 factors, three scalar
   // multiplies per frame that the other chunks carry along (the pass is bound by its loads).
@@ -352,7 +373,7 @@ __device__ __forceinline__ void pass1a(TIN (&ring)[RING][BWD ? 1 : NW], __amdgpu
     if (BWD) {
       double b = (double)ring[slot][0];
       if (a0 + k < 0) b = 0.0;
-      if (k + RING < M) ring_issue<TIN, BWD, NW, RING>(ring, slot, k + RING, rs, loff, ld_bytes, win_bytes, a0);
+      if (k + RING < M) ring_issue<TIN, BWD, NW, RING, MULTI>(ring, slot, k + RING, rs, loff, ld_bytes, win_bytes, a0, wlane);
       z[k] = b;
     } else {
       double nx = 0.0, cu = 0.0, pv = 0.0;
@@ -365,7 +386,7 @@ __device__ __forceinline__ void pass1a(TIN (&ring)[RING][BWD ? 1 : NW], __amdgpu
         cu += wc[w][1] * v;
         pv += wc[w][0] * v;
       }
-      if (k + RING < M) ring_issue<TIN, BWD, NW, RING>(ring, slot, k + RING, rs, loff, ld_bytes, win_bytes, a0);
+      if (k + RING < M) ring_issue<TIN, BWD, NW, RING, MULTI>(ring, slot, k + RING, rs, loff, ld_bytes, win_bytes, a0, wlane);
       if (k == 0) up = pv; else z[k - 1] += pv;
       if (k == 0) z[k] = cu; else z[k] += cu;
       if (k == M - 1) dn = nx; else z[k + 1] = nx;
@@ -505,8 +526,9 @@ struct Lds {
 #endif
 constexpr int kRing = MLPG_CONST_RING;  // frames of loads in flight per wavefront
 
-template <typename TIN, typename TOUT, bool BWD, int VM, int NW, int M, int W, int WPS, int SLOTS>
+template <typename TIN, typename TOUT, bool BWD, int VM, int NW, int M, int W, int WPS, int SLOTS, bool MULTI = false>
 __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet ws, Args a) {
+  static_assert(!(MULTI && BWD), "merged streams: forward only");
   __shared__ Lds<W, M, SLOTS> lds;
   constexpr int kSlots = SLOTS;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -551,25 +573,34 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
     const int NC = (T + M - 1) / M;        // chunks of this utterance, aligned to its end
     const int K = (NC + W - 1) / W;        // super-steps
     const int d0 = dg * a.dgw;
-    const int nd = p.sd - d0 < a.dgw ? p.sd - d0 : a.dgw;
+    const int sd_all = MULTI ? a.sm.total : p.sd;  // MULTI: the lanes run over the static dims of all streams
+    const int nd = sd_all - d0 < a.dgw ? sd_all - d0 : a.dgw;
     const bool lane_ok = lane < nd;
-    const int d = d0 + (lane_ok ? lane : nd - 1);  // idle lanes shadow the group's last dim (never stored)
+    const int dm = d0 + (lane_ok ? lane : nd - 1);  // idle lanes shadow the group's last dim (never stored)
+    // d: the dim's output column; din: its window-0 input column; dstat: its status column; sd_l: its window pitch
+    int d = dm, din = dm, dstat = dm, sd_l = p.sd;
+    if (MULTI) {
+      const LaneStream ls = lane_stream(a.sm, dm);
+      d = ls.dout; din = ls.din; dstat = ls.dstat; sd_l = ls.sd;
+    }
+    const int dbase = MULTI ? 0 : d0;  // MULTI: the descriptors start at column 0 of the parent arrays
     const unsigned ldo_bytes = (unsigned)p.ld_out * (unsigned)sizeof(TOUT);
     const unsigned out_win = (unsigned)p.sd * (unsigned)sizeof(TOUT);
-    const __amdgpu_buffer_rsrc_t ors = make_rsrc((TOUT *)p.out + (size_t)b * Tmax * p.ld_out + d0);
-    const unsigned ooff = (unsigned)(d - d0) * (unsigned)sizeof(TOUT);
-    const unsigned loff = (unsigned)(d - d0) * (unsigned)sizeof(TIN);
+    const __amdgpu_buffer_rsrc_t ors = make_rsrc((TOUT *)p.out + (size_t)b * Tmax * p.ld_out + dbase);
+    const unsigned ooff = (unsigned)(d - dbase) * (unsigned)sizeof(TOUT);
+    const unsigned loff = (unsigned)(din - dbase) * (unsigned)sizeof(TIN);
     const __amdgpu_buffer_rsrc_t irs =
-        make_rsrc(BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * p.ld_gout + d0 : (const TIN *)p.mean + (size_t)b * Tmax * p.ld_in + d0);
+        make_rsrc(BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * p.ld_gout + dbase : (const TIN *)p.mean + (size_t)b * Tmax * p.ld_in + dbase);
     const unsigned ld_bytes = (unsigned)(BWD ? p.ld_gout : p.ld_in) * (unsigned)sizeof(TIN);
-    const unsigned win_bytes = (unsigned)p.sd * (unsigned)sizeof(TIN);
+    const unsigned win_bytes = MULTI ? 0u : (unsigned)p.sd * (unsigned)sizeof(TIN);
+    const unsigned wlane = MULTI ? (unsigned)sd_l * (unsigned)sizeof(TIN) : 0u;
 
     // this wavefront's first chunk: its frames are requested before anything else
     TIN ring[kRing][NL];
     if (wv < NC) {
       const int a0 = T - (NC - wv) * M;
 #pragma unroll
-      for (int f = 0; f < kRing; ++f) ring_issue<TIN, BWD, NW, kRing>(ring, f, f, irs, loff, ld_bytes, win_bytes, a0);
+      for (int f = 0; f < kRing; ++f) ring_issue<TIN, BWD, NW, kRing, MULTI>(ring, f, f, irs, loff, ld_bytes, win_bytes, a0, wlane);
     }
     // the table's head
     const int i_s_v = a.tabi[dg * 128], ok_v = a.tabi[dg * 128 + 1];
@@ -590,7 +621,7 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
       }
     }
 #ifndef MLPG_CONST_TIMING
-    if (wv == 0 && lane_ok && p.status) p.status[(size_t)b * p.ld_status + d] = 0;
+    if (wv == 0 && lane_ok && p.status) p.status[(size_t)b * p.ld_status + dstat] = 0;
 #endif
     const int i_s = __builtin_amdgcn_readfirstlane(i_s_v);
     const bool lag_ok = __builtin_amdgcn_readfirstlane(ok_v) != 0;
@@ -689,19 +720,19 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
         const bool edge_dn = !BWD && !dead && !last && wv == W - 1;
         if (edge_dn) {
 #pragma unroll
-          for (int w = 0; w < NL; ++w) edge[w] = ld_row<TIN>(irs, (unsigned)(a0 + M) * ld_bytes + (unsigned)w * win_bytes, loff);
+          for (int w = 0; w < NL; ++w) edge[w] = ld_row<TIN>(irs, (unsigned)(a0 + M) * ld_bytes + (unsigned)w * win_bytes, MULTI ? loff + (unsigned)w * wlane : loff);
         }
         double up = 0.0, dn = 0.0;
         if (dead) {
 #pragma unroll
           for (int i = 0; i < M; ++i) z[i] = 0.0;
         } else {
-          pass1a<TIN, BWD, NW, M, kRing>(ring, irs, loff, ld_bytes, win_bytes, a0, last, tau, a.wc, z, up, dn);
+          pass1a<TIN, BWD, NW, M, kRing, MULTI>(ring, irs, loff, ld_bytes, win_bytes, a0, last, tau, a.wc, z, up, dn, wlane);
         }
         // the next super-step's first frames: they travel while this one is worked on
         if (j + W < NC) {
 #pragma unroll
-          for (int f = 0; f < kRing; ++f) ring_issue<TIN, BWD, NW, kRing>(ring, f, f, irs, loff, ld_bytes, win_bytes, a0 + S);
+          for (int f = 0; f < kRing; ++f) ring_issue<TIN, BWD, NW, kRing, MULTI>(ring, f, f, irs, loff, ld_bytes, win_bytes, a0 + S, wlane);
         }
         if (!BWD) {
           lds.halo[wv][0][lane] = up;
@@ -819,7 +850,7 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
       if (wv < NC) {
         const int a0 = T - (NC - wv) * M;
 #pragma unroll
-        for (int f = 0; f < kRing; ++f) ring_issue<TIN, BWD, NW, kRing>(ring, f, f, irs, loff, ld_bytes, win_bytes, a0);
+        for (int f = 0; f < kRing; ++f) ring_issue<TIN, BWD, NW, kRing, MULTI>(ring, f, f, irs, loff, ld_bytes, win_bytes, a0, wlane);
       }
       if (tid < 64) {
         lds.carry[0][0][tid] = 0.0;
@@ -827,7 +858,7 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
         lds.carry[0][2][tid] = 0.0;
       }
       __syncthreads();
-      const __amdgpu_buffer_rsrc_t prs = make_rsrc((TOUT *)p.out + (size_t)b * Tmax * p.ld_out + d0);
+      const __amdgpu_buffer_rsrc_t prs = make_rsrc((TOUT *)p.out + (size_t)b * Tmax * p.ld_out + dbase);
       for (int k = 0; k < K; ++k) {
         const int j = k * W + wv;
         const bool dead = j >= NC;
@@ -838,18 +869,18 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
         const bool edge_dn = !BWD && !dead && !last && wv == W - 1;
         if (edge_dn) {
 #pragma unroll
-          for (int w = 0; w < NL; ++w) edge[w] = ld_row<TIN>(irs, (unsigned)(a0 + M) * ld_bytes + (unsigned)w * win_bytes, loff);
+          for (int w = 0; w < NL; ++w) edge[w] = ld_row<TIN>(irs, (unsigned)(a0 + M) * ld_bytes + (unsigned)w * win_bytes, MULTI ? loff + (unsigned)w * wlane : loff);
         }
         double up = 0.0, dn = 0.0;
         if (dead) {
 #pragma unroll
           for (int i = 0; i < M; ++i) z[i] = 0.0;
         } else {
-          pass1a<TIN, BWD, NW, M, kRing>(ring, irs, loff, ld_bytes, win_bytes, a0, last, tau, a.wc, z, up, dn);
+          pass1a<TIN, BWD, NW, M, kRing, MULTI>(ring, irs, loff, ld_bytes, win_bytes, a0, last, tau, a.wc, z, up, dn, wlane);
         }
         if (j + W < NC) {
 #pragma unroll
-          for (int f = 0; f < kRing; ++f) ring_issue<TIN, BWD, NW, kRing>(ring, f, f, irs, loff, ld_bytes, win_bytes, a0 + S);
+          for (int f = 0; f < kRing; ++f) ring_issue<TIN, BWD, NW, kRing, MULTI>(ring, f, f, irs, loff, ld_bytes, win_bytes, a0 + S, wlane);
         }
         if (!BWD) {
           lds.halo[wv][0][lane] = up;
@@ -1004,10 +1035,23 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
       __syncthreads();
       const unsigned long long all = (unsigned long long)(unsigned)lds.bad[0] | ((unsigned long long)(unsigned)lds.bad[1] << 32);
       if (all != 0ull && wv == 0 && lane_ok && ((all >> lane) & 1ull)) {
-        const SysView<TIN, BWD> view = make_view<TIN, BWD>(p, ws, b, d, T);
-        int status = first_bad_pivot<2, TIN, BWD>(view, ws);
+        int status;
+        if (MULTI) {
+          // the dim's own stream as a problem of its own: column slices of the parent arrays (make_view addresses column
+          // w * sd + dloc of q.mean / q.var: the bases are shifted so that dloc = 0 is this dim)
+          Problem q = p;
+          q.sd = sd_l;
+          q.D = NW * sd_l;
+          q.mean = (const TIN *)p.mean + din;
+          q.var = p.var ? (const void *)((const TIN *)p.var + din) : nullptr;
+          const SysView<TIN, BWD> view = make_view<TIN, BWD>(q, ws, b, 0, T);
+          status = first_bad_pivot<2, TIN, BWD>(view, ws);
+        } else {
+          const SysView<TIN, BWD> view = make_view<TIN, BWD>(p, ws, b, d, T);
+          status = first_bad_pivot<2, TIN, BWD>(view, ws);
+        }
         if (status == 0) status = -2;
-        if (p.status) p.status[(size_t)b * p.ld_status + d] = status;
+        if (p.status) p.status[(size_t)b * p.ld_status + dstat] = status;
         TOUT *out_b = (TOUT *)p.out + (size_t)b * Tmax * p.ld_out;
         for (int t = 0; t < T; ++t) {
           if (!BWD) out_b[(size_t)t * p.ld_out + d] = (TOUT)0;
@@ -1062,12 +1106,14 @@ struct Plan {
   int M, W, ndg, dgw, nsg, tab_rows;
   size_t key_off, tab_off, tabi_off, total;
 };
-inline Plan make_plan(const Problem &p, int M, int W) {
+// sd_total > 0: a merged launch (several streams side by side on the lanes): full groups of 64 lanes
+inline Plan make_plan(const Problem &p, int M, int W, int sd_total = 0) {
   Plan q;
   q.M = M;
   q.W = W;
-  q.ndg = (p.sd + 63) / 64;
-  q.dgw = (p.sd + q.ndg - 1) / q.ndg;
+  const int sd = sd_total > 0 ? sd_total : p.sd;
+  q.ndg = (sd + 63) / 64;
+  q.dgw = sd_total > 0 ? 64 : (sd + q.ndg - 1) / q.ndg;
   q.nsg = p.B * q.ndg;
   q.tab_rows = p.Tmax < 4 ? 4 : p.Tmax;
   q.key_off = 0;
@@ -1077,10 +1123,12 @@ inline Plan make_plan(const Problem &p, int M, int W) {
   return q;
 }
 
-template <typename TIN, typename TOUT, bool BWD, int VM, int NW, int M, int W, int WPS, int SLOTS>
+template <typename TIN, typename TOUT, bool BWD, int VM, int NW, int M, int W, int WPS, int SLOTS, bool MULTI = false>
 int launch_cfg(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, const Plan &q, bool fresh, int device,
-               unsigned long long gen) {
+               unsigned long long gen, const StreamMap *smap = nullptr) {
   Args a;
+  memset(&a.sm, 0, sizeof(a.sm));
+  if (MULTI) a.sm = *smap;
   a.key = (double *)((char *)scratch_base + q.key_off);
   a.tab = (double *)((char *)scratch_base + q.tab_off);
   a.tabi = (int *)((char *)scratch_base + q.tabi_off);
@@ -1096,13 +1144,13 @@ int launch_cfg(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch
     const double v[9] = {cm, c0, cp, cp * cp, c0 * c0, cm * cm, cp * c0, c0 * cm, cp * cm};
     for (int k = 0; k < 9; ++k) a.wc[w][k] = v[k];
   }
-  auto kern = stream_kernel<TIN, TOUT, BWD, VM, NW, M, W, WPS, SLOTS>;
+  auto kern = stream_kernel<TIN, TOUT, BWD, VM, NW, M, W, WPS, SLOTS, MULTI>;
   int resident = 0;
   if (int rc = resident_grid((const void *)kern, W * 64, &resident)) return rc;
   // Unit variances: the table depends on the windows and the shape only, which the HOST can compare -- the launch of
   // setup_kernel (2.7 us when it only compares its key) is skipped when this (device, stream) ran the same thing last.
   bool skip = false;
-  if (VM == MLPG_HIP_VAR_UNIT) {
+  if (VM == MLPG_HIP_VAR_UNIT && !MULTI) {
     double key[2 + 3 * kMaxWindows] = {};
     key[0] = (double)((((((long long)a.tab_rows * 1024 + a.ndg) * 128 + a.dgw) * 64 + M) * 32 + W) * 8 + NW);
     key[1] = (double)sizeof(TIN);
@@ -1112,10 +1160,10 @@ int launch_cfg(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch
   } else {
     (void)const_unit_table_cached(device, st, gen, true, nullptr, 0);  // this launch rewrites the stream's table: forget the unit entry
   }
-  if (!skip) hipLaunchKernelGGL((setup_kernel<TIN, VM, NW>), dim3((unsigned)q.ndg), dim3(64), 0, st, p, a, M, W, fresh ? 1 : 0);
+  if (!skip) hipLaunchKernelGGL((setup_kernel<TIN, VM, NW, MULTI>), dim3((unsigned)q.ndg), dim3(64), 0, st, p, a, M, W, fresh ? 1 : 0);
   MLPG_HIP_CHECK(hipGetLastError());
   const int grid = q.nsg < resident ? q.nsg : resident;
-  note_launch(kCountConst);
+  note_launch(MULTI ? kCountConstMulti : kCountConst);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W * 64), 0, st, p, ws, a);
   MLPG_HIP_CHECK(hipGetLastError());
   return 0;
@@ -1139,6 +1187,15 @@ int launch_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_b
   using N3 = std::integral_constant<int, 3>;
   if (p.var_mode == MLPG_HIP_VAR_GLOBAL) return ws.nw == 3 ? go(G{}, N3{}) : go(G{}, N2{});
   return ws.nw == 3 ? go(U{}, N3{}) : go(U{}, N2{});
+}
+
+// several streams of one batch side by side on the lanes (forward, global or unit variances, three windows)
+template <typename TIN>
+int launch_multi_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, const Plan &q, bool fresh, int device,
+                   unsigned long long gen, const StreamMap &smap) {
+  if (p.var_mode == MLPG_HIP_VAR_GLOBAL)
+    return launch_cfg<TIN, TIN, false, MLPG_HIP_VAR_GLOBAL, 3, 16, kConstW, 2, kConstW, true>(st, p, ws, scratch_base, q, fresh, device, gen, &smap);
+  return launch_cfg<TIN, TIN, false, MLPG_HIP_VAR_UNIT, 3, 16, kConstW, 2, kConstW, true>(st, p, ws, scratch_base, q, fresh, device, gen, &smap);
 }
 
 }  // namespace cst

@@ -248,3 +248,75 @@ def test_merged_stream_launch_against_the_reference_itself_config5_utterance():
             y = ref_mlpg(np.ascontiguousarray(m[b, :, in_col:in_col + 3 * sd]), np.ascontiguousarray(v[b, :, in_col:in_col + 3 * sd]), STD3)
             assert np.abs(out[b, :, o0:o0 + sd] - y).max() <= 1e-9 * np.abs(y).max(), (in_col, b)
         o0 += sd
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("vmode", ["global", "unit"])
+def test_merged_stream_launch_global_and_unit_variances_against_the_oracle(dt, vmode):
+    """Round 5: with global (D,) or unit variances the streams of a Merlin-style row (mgc 60 | lf0 1 | bap 5; the parent
+    row also holds a pass-through vuv column) share ONE constant-coefficient launch (cst::stream_kernel<..., MULTI>: 64 lanes
+    = 60 + 1 + the first 3 bap dims; the other 2 bap dims run as a piece on the wave-per-system kernel).  Against the CPU
+    oracle per stream, ragged lengths, AUTO (the batch has a sequence per CU) and ALGO_CONST forced on a small batch;
+    mlpg_hip_launch_count(8) shows that the merged instantiation ran."""
+    import torch
+    from nnmnkwii_amd import _hip
+    from oracle import mlpg as O
+    rng = np.random.RandomState(41)
+    D = 180 + 3 + 1 + 15
+    streams = [(0, 60, STD3), (180, 1, STD3), (183, 1, None), (184, 5, STD3)]
+    tol = 1e-9 if dt == np.float64 else 5e-6
+    for B, T, algo in ((200, 300, _hip.ALGO_AUTO), (6, 531, _hip.ALGO_CONST)):
+        m = rng.randn(B, T, D).astype(dt)
+        vg = (rng.rand(D) + 0.1).astype(dt)
+        lengths = rng.randint(1, T + 1, B).astype(np.int32)
+        lengths[:4] = (T, 1, 2, 129)
+        for b in range(B):
+            m[b, lengths[b]:] = 0
+        md, Ld = torch.from_numpy(m).cuda(), torch.from_numpy(lengths).cuda()
+        vd = torch.from_numpy(vg).cuda() if vmode == "global" else None
+        n0 = _hip.lib().mlpg_hip_launch_count(8)
+        out, st = _hip.forward_streams(md, vd, streams, Ld, algo=algo)
+        torch.cuda.synchronize()
+        assert _hip.lib().mlpg_hip_launch_count(8) == n0 + 1, "the streams were not merged into one constant-coefficient launch"
+        assert int(st.abs().max()) == 0
+        out = out.cpu().numpy()
+        sel = [0, 1, 2, 3, B // 2, B - 1]
+        o0 = 0
+        for in_col, sd, win in streams:
+            got = out[sel][:, :, o0:o0 + sd]
+            if win is None:
+                assert np.array_equal(got, m[sel][:, :, in_col:in_col + sd])
+            else:
+                var = np.ascontiguousarray(vg[in_col:in_col + 3 * sd]) if vmode == "global" else np.ones(3 * sd, dtype=dt)
+                ref, _, rc = O.mlpg_batch(np.ascontiguousarray(m[sel][:, :, in_col:in_col + 3 * sd]), var, STD3, lengths[sel])
+                assert rc == 0
+                scale = np.abs(ref).max()
+                assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() <= tol * scale, (B, algo, in_col, vmode)
+                for i, b in enumerate(sel):
+                    assert not got[i, lengths[b]:].any()
+            o0 += sd
+
+
+def test_merged_stream_launch_global_variances_reports_a_failing_pivot_like_the_reference():
+    """A negative global variance in ONE stream of the merged launch: that stream's systems get the reference's verdict
+    (k-th leading minor, zero column), the other streams' trajectories are untouched."""
+    import torch
+    from nnmnkwii_amd import _hip
+    from oracle import mlpg as O
+    rng = np.random.RandomState(43)
+    B, T, D = 200, 200, 198
+    m = rng.randn(B, T, D)
+    vg = rng.rand(D) + 0.1
+    vg[180] = -0.5                      # lf0's static variance
+    streams = [(0, 60, STD3), (180, 1, STD3), (183, 5, STD3)]
+    n0 = _hip.lib().mlpg_hip_launch_count(8)
+    out, st = _hip.forward_streams(torch.from_numpy(m).cuda(), torch.from_numpy(vg).cuda(), streams)
+    torch.cuda.synchronize()
+    assert _hip.lib().mlpg_hip_launch_count(8) == n0 + 1
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    ref, stat, rc = O.mlpg_batch(np.ascontiguousarray(m[:2, :, 180:183]), np.ascontiguousarray(vg[180:183]), STD3, None)
+    assert int(stat.ravel()[0]) > 0
+    assert (st[:, 60] == int(stat.ravel()[0])).all() and not out[:, :, 60].any()
+    assert not st[:, :60].any() and not st[:, 61:].any()
+    ref, _, rc = O.mlpg_batch(np.ascontiguousarray(m[:2, :, :180]), np.ascontiguousarray(vg[:180]), STD3, None)
+    assert rc == 0 and np.abs(out[:2, :, :60] - ref).max() <= 1e-9 * np.abs(ref).max()

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-KINDS = ["generic", "wave", "strip", "strip_multi", "const", "fused", "chunk", "fir"]   # csrc/common.h kCount*
+KINDS = ["generic", "wave", "strip", "strip_multi", "const", "fused", "chunk", "fir", "const_multi"]   # csrc/common.h kCount*
 ALGOS = {"generic": 1, "wave": 2, "strip": 3, "const": 5, "chunk": 6, "fir": 7}          # include/mlpg_hip.h MLPG_HIP_ALGO_*
 
 # (name, B, T, sd, dtype, variance mode, window set, direction)

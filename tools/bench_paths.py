@@ -498,7 +498,26 @@ def _run(only, quick, device_index):
         ms = gpu_time(lambda: _hip.forward_streams(m, v, streams, want_status=False), steps=5)
         emit(path="c5-forward_streams-one-call", batch=B, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=tot_by,
              GBps=tot_by / ms / 1e6)
-        del m, v
+        del v
+        # the same call with GLOBAL (D,) variances -- what a Merlin-style pipeline passes (util/files.py:90-115: one variance
+        # vector per stream for the whole corpus): 32 B per (frame, dim); the streams merged on the constant-coefficient kernel
+        vg5 = torch.rand(198, dtype=torch.float64, device=dev, generator=gen) + 0.1
+        by_g = 32.0 * 66 * B * T
+        ms = gpu_time(lambda: _hip.forward_streams(m, vg5, streams, want_status=False), steps=5)
+        n0 = [int(_hip.lib().mlpg_hip_launch_count(k)) for k in range(9)]
+        _hip.forward_streams(m, vg5, streams, want_status=False)
+        n1 = [int(_hip.lib().mlpg_hip_launch_count(k)) for k in range(9)]
+        emit(path="c5g-forward_streams-one-call-global-variances", batch=B, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by_g,
+             GBps=by_g / ms / 1e6, launches={k: b - a for k, (a, b) in enumerate(zip(n0, n1)) if b != a},
+             note="launches: kernel family -> launches of one call (8 = merged constant-coefficient, 1 = wave-per-system for the 2 dims left over)")
+        ms_sep = 0.0
+        for in_col, sd_, _w in streams:       # the three streams as three calls on dense tensors, for comparison
+            md = m[:, :, in_col:in_col + 3 * sd_].contiguous()
+            vd = vg5[in_col:in_col + 3 * sd_].contiguous()
+            ms_sep += gpu_time(lambda: _hip.forward(md, vd, WINDOWS, want_status=False), steps=5)
+            del md
+        emit(path="c5g-three-calls-global-variances", batch=B, ms=ms_sep, frames_per_s=B * T / ms_sep * 1e3, alg_bytes=by_g, GBps=by_g / ms_sep / 1e6)
+        del m
 
 
 if __name__ == "__main__":
