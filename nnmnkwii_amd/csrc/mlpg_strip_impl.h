@@ -117,6 +117,10 @@ constexpr int kCtrlLine = 32;
 #ifndef MLPG_STRIP_BWD_KARG
 #define MLPG_STRIP_BWD_KARG 1  // backward, three windows: window coefficients by placed scalar loads from the argument segment (karg_f64x6)
 #endif
+#ifndef MLPG_STRIP_FWD_KARG
+#define MLPG_STRIP_FWD_KARG 1  // forward, three windows: the same for all nine coefficients per window (interleaved A/B, profiles/r05_strip_ab2.txt:
+                               // float64 0.2421 / 0.2387 -> 0.2415 / 0.2352 ms, float32 0.1830 / 0.1774 -> 0.1793 / 0.1762: 146 -> 119 spilled SGPRs)
+#endif
 #ifndef MLPG_STRIP_BWD_KEEP0
 #define MLPG_STRIP_BWD_KEEP0 1  // ... wavefront 0 too (it runs levels 2 and 3 meanwhile and has no 51 registers to spare: it reads
                                 // its chunk's variances again)
@@ -406,6 +410,19 @@ __device__ __forceinline__ void karg_f64x6(double (&d)[6]) {
                : "s"(kp), "n"(OFF), "n"(OFF + 32));
   d[0] = mk_f64(a[0], a[1]); d[1] = mk_f64(a[2], a[3]); d[2] = mk_f64(a[4], a[5]); d[3] = mk_f64(a[6], a[7]);
   d[4] = mk_f64(b[0], b[1]); d[5] = mk_f64(b[2], b[3]);
+}
+typedef __attribute__((ext_vector_type(16))) unsigned u32x16;
+template <unsigned OFF>
+__device__ __forceinline__ void karg_f64x9(double (&d)[9]) {
+  const unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  u32x16 a;
+  u32x2 b;
+  asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b)
+               : "s"(kp), "n"(OFF), "n"(OFF + 64));
+#pragma unroll
+  for (int q = 0; q < 8; ++q) d[q] = mk_f64(a[2 * q], a[2 * q + 1]);
+  d[8] = mk_f64(b[0], b[1]);
 }
 template <unsigned OFF>
 __device__ __forceinline__ void karg_f64x3(double (&d)[3]) {
@@ -1249,6 +1266,12 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
 #pragma unroll
           for (int q = 0; q < 6; ++q) wcl[w][3 + q] = c6[w][q];
         }
+        wcs = wcl;
+      }
+      if (!BWD && MLPG_STRIP_FWD_KARG && !MULTI) {
+        karg_f64x9<kKargWc + 0 * 72>(wcl[0]);
+        karg_f64x9<kKargWc + 1 * 72>(wcl[1]);
+        karg_f64x9<kKargWc + 2 * 72>(wcl[2]);
         wcs = wcl;
       }
       if (interior) bad = assemble_eliminate<TIN, BWD, VM, false, 3, MULTI, kKeepTau>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, wcs, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec, tk);
