@@ -410,7 +410,7 @@ def _run(only, quick, device_index):
         for n in range(ncpu):
             OD.fastdtw(X[n, :int(lenx[n])], Y[n, :int(leny[n])], 1)
         cpu_s = (time.perf_counter() - t0) / ncpu
-        ms_full = None if share_only else gpu_time(lambda: DTWAligner().transform((X, Y)), steps=3, warmup=1)
+        ms_full = None if share_only else gpu_time(lambda: DTWAligner().transform((X, Y)), steps=8, warmup=3)
         # DP cells over all pyramid levels (mean of 8 pairs): the kernel is latency-bound, cells/s is its work rate
         cells_per_pair = float(np.mean([fastdtw_window_cells(X[n, :int(lenx[n])], Y[n, :int(leny[n])], 1) for n in range(8)]))
         if not args.quick and not share_only:
