@@ -133,17 +133,10 @@ constexpr int kCtrlLine = 32;
                                 // level 1 is done (into the registers the ring has left), so that they travel while the strip waits for
                                 // its neighbours; the other 17 - n frames are requested in front of the first store as before (round 5)
 #endif
-#ifndef MLPG_STRIP_PREFETCH
-#define MLPG_STRIP_PREFETCH 0  // frames of the NEXT item's chunk touched (LDS-DMA loads into a dummy LDS line: no register is
-                                // written) while this item back-substitutes: its first ring then comes out of L2 (0: off)
-#endif
 #ifndef MLPG_STRIP_NT_STORES
 #define MLPG_STRIP_NT_STORES 1  // trajectory and gradient rows with the nontemporal hint (written once, never read by this kernel); round 5 A/B
                                 // (profiles/r05_strip_stores_ab.txt): forward f64 +1.9 %, backward f32 +5.5 %.  (Round 3 measured the same gain and
                                 // its notes called it shipped, but the default stayed 0 until round 5.)
-#endif
-#ifndef MLPG_STRIP_SCHED_RELAX
-#define MLPG_STRIP_SCHED_RELAX 0
 #endif
 #ifndef MLPG_STRIP_RING_F64
 #define MLPG_STRIP_RING_F64 6
@@ -151,15 +144,7 @@ constexpr int kCtrlLine = 32;
 #ifndef MLPG_STRIP_ROUTE1_TOL
 #define MLPG_STRIP_ROUTE1_TOL 0.0  // own transfer factor below which a 3-strip window is tried first (0: never)
 #endif
-#ifndef MLPG_STRIP_STREAM
-#define MLPG_STRIP_STREAM 1  // 1: streamed level 1, every wavefront loads its own 18 frames (shipped); 2: the halo handed over
-                             // through LDS, 66 instead of 72 frames per strip (round 3: parity green, 2-3 % SLOWER -- the kernel is
-                             // bound by its latency chain, not by bytes; kept as a switch); 0: window-major assembly (A/B)
-#endif
-#ifndef MLPG_STRIP_PHASES
-#define MLPG_STRIP_PHASES 1
-#endif
-constexpr int kMaxLists = 8 * MLPG_STRIP_PHASES;
+constexpr int kMaxLists = 8;
 constexpr int kLocal = 2;          // level 3 first looks at the records of strips r-2 .. r+2 only
                                    // (wider windows -- 4, 8, 16 strips per side -- when the strip's own transfer factor calls for them)
 constexpr double kRouteTol = 1e-11; // a strip whose own transfer factor 2 max|E^-1 V| exceeds this (= kDampTol^(1/2)) does not
@@ -247,7 +232,7 @@ constexpr size_t kLdsStage = (size_t)kStage * kRec * 64 * 8;     // level-3 stag
 constexpr size_t kLdsPark = (size_t)kPark * 64 * 8;
 constexpr size_t kLdsFac = (size_t)(kW - 1) * kFac * 64 * 8;
 constexpr size_t kLdsU = (size_t)(kW + 1) * 2 * 64 * 8;
-constexpr size_t kLdsMisc = 64 + kW * 256;  // control words + a throw-away line per wavefront (MLPG_STRIP_PREFETCH)
+constexpr size_t kLdsMisc = 64 + kW * 256;  // control words (+ slack)
 constexpr size_t kLdsBytes = kLdsStage + kLdsPark + kLdsFac + kLdsU + kLdsMisc;
 static_assert(kW * kRec <= kStage * kRec, "level-1 records must fit the staging area");
 static_assert(kLdsBytes <= 160 * 1024 / MLPG_STRIP_WGS, "MLPG_STRIP_WGS workgroups per CU must fit the 160 KB of LDS");
@@ -339,35 +324,28 @@ static_assert(kHB * kNB == kM + 2, "batches must tile the 18 frames");
 // per-load 64-bit address arithmetic and no address registers (global_load with 64-bit VGPR addresses costs two VALU
 // instructions and a register pair per load, which is what drove this kernel into scratch).
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-#ifndef MLPG_STRIP_LOAD_AUX
-#define MLPG_STRIP_LOAD_AUX 0   // cache policy of the row loads (experiment: 2 = nt)
-#endif
 template <typename TIN>
 __device__ __forceinline__ TIN ld_row(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff);
 template <>
 __device__ __forceinline__ double ld_row<double>(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff) {
-  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, loff, soff, MLPG_STRIP_LOAD_AUX);
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, loff, soff, 0);
   return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
 }
 template <>
 __device__ __forceinline__ float ld_row<float>(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, loff, soff, MLPG_STRIP_LOAD_AUX));
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, loff, soff, 0));
 }
-// the backward's grad_out rows (read once; MLPG_STRIP_GOUT_AUX = 2: nt, so that they do not displace the variance rows the
-// epilogue reads a second time)
-#ifndef MLPG_STRIP_GOUT_AUX
-#define MLPG_STRIP_GOUT_AUX 0
-#endif
+// the backward's grad_out rows (round 3 measured the `nt` cache policy for them: 2 % slower)
 template <typename TIN>
 __device__ __forceinline__ TIN ld_row_g(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff);
 template <>
 __device__ __forceinline__ double ld_row_g<double>(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff) {
-  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, loff, soff, MLPG_STRIP_GOUT_AUX);
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, loff, soff, 0);
   return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
 }
 template <>
 __device__ __forceinline__ float ld_row_g<float>(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, loff, soff, MLPG_STRIP_GOUT_AUX));
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, loff, soff, 0));
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
   // the base must be wave-uniform PROVABLY (a lane-tainted descriptor is wrapped in a waterfall loop per load)
@@ -438,15 +416,6 @@ __device__ __forceinline__ void karg_f64x3(double (&d)[3]) {
 constexpr unsigned kKargWs = (unsigned)((sizeof(Problem) + alignof(WinSet) - 1) / alignof(WinSet) * alignof(WinSet));
 constexpr unsigned kKargArgs = (unsigned)((kKargWs + sizeof(WinSet) + alignof(Args) - 1) / alignof(Args) * alignof(Args));
 constexpr unsigned kKargWc = kKargArgs + (unsigned)__builtin_offsetof(Args, wc);
-
-// A load whose result nobody wants (MLPG_STRIP_PREFETCH): it brings the row's lines into L2.  An LDS-DMA load into a
-// throw-away LDS line, so that no register is written (a register destination would have to stay reserved until the
-// data lands -- as inline assembly with a dead destination it silently overwrote whatever the allocator put there
-// next; as a builtin load it costs the registers this kernel does not have).  One dword per lane at this lane's
-// 8-byte (4-byte for float32) stride touches every line of the row.
-__device__ __forceinline__ void touch_row(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned loff, void *lds_dummy) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_dummy, 4, (int)loff, (int)soff, 0, 0);
-}
 
 // EDGE: a dead frame of the window (outside [lo, hi)) is loaded from the nearest live frame instead -- a finite
 // variance -- and enters with weight 0 (accumulate()), so that padding values never meet the reciprocal.
@@ -692,10 +661,10 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
   constexpr int kRing = RingDepth<TIN>::value;
   TIN rv[kRing][NW], rm[kRing][NW];
   auto load_frame = [&](TIN (&v)[NW], TIN (&m)[NW], const int i) __attribute__((always_inline)) {
-    // BWD: the frame's row offset as an opaque scalar.  Left transparent, the 18 multiples i * ldi_bytes (and their EDGE
-    // variants) are loop invariants of the persistent item loop: hoisted, they occupy scalar registers through the whole
-    // kernel, and the backward instances -- which carry the epilogue's scalars as well -- then re-read the window
-    // coefficients from spilled lanes (v_readlane) in front of every use in the stream below.
+    // BWD: the frame's row offset as an opaque scalar, so that the 18 multiples i * ldi_bytes (and their EDGE variants) are
+    // not hoisted out of the persistent item loop as invariants that occupy scalar registers through the whole kernel.
+    // (Part of round 5's hunt for the backward instances' scalar spills; what removed the v_readlane reloads in the stream
+    // were the placed coefficient loads -- karg_f64x6 -- this alone did not.)
     unsigned frame_off = (unsigned)(f0 + i) * ldi_bytes;
     if (BWD && !EDGE) asm volatile("" : "+s"(frame_off));
 #pragma unroll
@@ -710,15 +679,8 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
       // lane offset; otherwise it is wave-uniform and rides in the scalar offset
       const unsigned soff = MULTI ? frame_off : frame_off + (unsigned)w * win_bytes;
       const unsigned voff = MULTI ? loff + (unsigned)w * win_bytes : loff;
-#ifdef MLPG_STRIP_FAKE_LOADS  // timing experiment only: no memory traffic, opaque per-lane values instead
-      (void)soff;
-      (void)voff;
-      if (VM == MLPG_HIP_VAR_FRAME) { TIN x = (TIN)1.5; asm volatile("" : "+v"(x)); v[w] = x; }
-      if (!BWD) { TIN x = (TIN)0.25; asm volatile("" : "+v"(x)); m[w] = x; }
-#else
       if (VM == MLPG_HIP_VAR_FRAME) v[w] = ld_row<TIN>(vrs, soff, voff);
       if (!BWD) m[w] = ld_row<TIN>(mrs, soff, voff);
-#endif
     }
   };
   auto accumulate_frame = [&](const TIN (&v)[NW], const TIN (&m)[NW], const int i) __attribute__((always_inline)) {
@@ -827,10 +789,9 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
   }
   __builtin_amdgcn_sched_barrier(0);
   // step S handles frame I = S - 1 in ring slot S % 6: accumulate, refill with frame I + 6, eliminate row I - 1
-  // MLPG_STRIP_SCHED_RELAX (A/B switch): bit 0 drops the barrier after the accumulation, bit 1 the one after the
-  // refill, bit 2 the one after the elimination step (one wavefront per SIMD wants the scheduler to interleave the
-  // elimination's dependent chain with the next frame's accumulation; two per SIMD did not care)
-#define STRIP_SB(bit) do { if (!((MLPG_STRIP_SCHED_RELAX) & (bit))) __builtin_amdgcn_sched_barrier(0); } while (0)
+  // (the three barriers pin accumulation / refill / elimination in this order; relaxing any of them -- round 3 -- changed nothing
+  // with two wavefronts per SIMD)
+#define STRIP_SB(bit) __builtin_amdgcn_sched_barrier(0)
 #define STRIP_STEP(S)                                                                   \
   if ((S) < kM + 2) {                                                                   \
   accumulate_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1);                            \
@@ -859,216 +820,6 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
   rec[rL22] = -(l2p * vb1);
   return bad;
 }
-
-// The same stream with the HALO handed over inside the workgroup (round 3): a wavefront loads the frames f0-1 .. f0+M-2
-// of its chunk; what the frames f0+M-1 and f0+M add to its last two rows comes from the next wavefront of the strip,
-// which forms those five sums from its own first two frames (step 1 of its stream) and leaves them in LDS; level 2
-// (wavefront 0, behind the barrier that follows level 1 anyway) adds them to the separator entries of the records.  Only the strip's last wavefront
-// (`last`) loads its two right-hand frames itself; the others repeat their own last frame there (a cache hit) with
-// weight 0, so that the stream stays the same straight-line code for everybody.  66 instead of 72 frames per strip.
-template <typename TIN, bool BWD, int VM, bool EDGE, int NW>
-__device__ __forceinline__ bool assemble_eliminate_halo(const int last, double *lds_yb, const int slot_out, const int lane,
-                                                        __amdgpu_buffer_rsrc_t mrs, __amdgpu_buffer_rsrc_t vrs,
-                                                   __amdgpu_buffer_rsrc_t grs, const TIN *__restrict__ vglob,
-                                                   unsigned loff, long ldi, long ldg, int sd, int f0, int T, int mw,
-                                                   const double (*wc)[9], const double one, double (&Pd)[kM], double (&P1)[kM],
-                                                   double (&P2)[kM], double (&rhs)[kM], double &ca, double &cb,
-                                                   double &cc, double (&rec)[kRec]) {
-  // No zero-fill: every accumulator is ASSIGNED by the first contribution that reaches it (window 0 of the frame
-  // noted below), so that a row costs no register before its first frame arrives.
-  const unsigned ldi_bytes = (unsigned)ldi * (unsigned)sizeof(TIN), win_bytes = (unsigned)sd * (unsigned)sizeof(TIN);
-  // live frames of a window: [0, T) for the static window, [mw, T - mw) for the dynamic ones (none if mw == 0)
-  int lo[NW], hi[NW], cl[NW], ch[NW];
-  WinCoef k[NW];
-#pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    lo[w] = w ? mw : 0;
-    hi[w] = w ? (mw != 0 && T - mw > mw ? T - mw : mw) : T;
-    cl[w] = lo[w] < T ? lo[w] : T - 1;            // a window without live frames still loads (frame cl) and weighs 0
-    ch[w] = hi[w] > cl[w] ? hi[w] : cl[w] + 1;
-    k[w] = win_coef<TIN, VM>(wc, w, vglob, sd);
-    // unit variances: the precision 1.0 as an opaque per-lane run-time value.  As a literal (or any wave-uniform value)
-    // the whole matrix becomes uniform arithmetic that the compiler hoists above the stream and spills (544-880 B/lane).
-    if (VM == MLPG_HIP_VAR_UNIT) {
-      double t1 = one;
-      asm volatile("" : "+v"(t1));  // a per-lane value as far as the compiler can tell
-      k[w].tau_glob = t1;
-    }
-  }
-  constexpr int kRing = RingDepth<TIN>::value;
-  TIN rv[kRing][NW], rm[kRing][NW];
-  auto load_frame = [&](TIN (&v)[NW], TIN (&m)[NW], const int i) __attribute__((always_inline)) {
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      int t = f0 + i;
-      if (i >= kM - 1) t = last ? t : f0 + kM - 2;
-      if (EDGE) t = t < cl[w] ? cl[w] : (t >= ch[w] ? ch[w] - 1 : t);
-      const unsigned soff = (unsigned)t * ldi_bytes + (unsigned)w * win_bytes;
-#ifdef MLPG_STRIP_FAKE_LOADS  // timing experiment only: no memory traffic, opaque per-lane values instead
-      (void)soff;
-      if (VM == MLPG_HIP_VAR_FRAME) { TIN x = (TIN)1.5; asm volatile("" : "+v"(x)); v[w] = x; }
-      if (!BWD) { TIN x = (TIN)0.25; asm volatile("" : "+v"(x)); m[w] = x; }
-#else
-      if (VM == MLPG_HIP_VAR_FRAME) v[w] = ld_row<TIN>(vrs, soff, loff);
-      if (!BWD) m[w] = ld_row<TIN>(mrs, soff, loff);
-#endif
-    }
-  };
-  const double wR = last ? 1.0 : 0.0;  // weight of the two right-hand frames
-  double y[5];
-  auto accumulate_frame = [&](const TIN (&v)[NW], const TIN (&m)[NW], const int i) __attribute__((always_inline)) {
-    const int t = f0 + i;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      double tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[w]) : k[w].tau_glob;
-      if (EDGE) tau *= (t >= lo[w] && t < hi[w]) ? 1.0 : 0.0;  // wave-uniform weight
-      if (i >= kM - 1) tau *= wR;
-      double tm = 0.0;
-      if (!BWD) tm = tau * (double)m[w];
-      const bool first = w == 0;  // first contribution to: Pd, rhs of row t+1; P1 of row t; P2 of row t-1
-      if (i >= 0 && i < kM) {  // row t
-        Pd[i] += k[w].c00 * tau;
-        P1[i] = first ? k[w].cp0 * tau : P1[i] + k[w].cp0 * tau;
-        if (!BWD) rhs[i] += k[w].c0 * tm;
-      }
-      if (i + 1 >= 0 && i + 1 < kM) {  // row t+1
-        Pd[i + 1] = first ? k[w].cpp * tau : Pd[i + 1] + k[w].cpp * tau;
-        if (!BWD) rhs[i + 1] = first ? k[w].cp * tm : rhs[i + 1] + k[w].cp * tm;
-      }
-      if (i - 1 >= 0 && i - 1 < kM) {  // row t-1
-        Pd[i - 1] += k[w].cmm * tau;
-        P1[i - 1] += k[w].c0m * tau;
-        P2[i - 1] = first ? k[w].cpm * tau : P2[i - 1] + k[w].cpm * tau;
-        if (!BWD) rhs[i - 1] += k[w].cm * tm;
-      }
-      // coupling of the chunk's first two rows to the previous chunk's separator:
-      // ca = P[f0, f0-2], cb = P[f0, f0-1], cc = P[f0+1, f0-1]
-      if (i == -1) {
-        ca = first ? k[w].cpm * tau : ca + k[w].cpm * tau;
-        cb = first ? k[w].cp0 * tau : cb + k[w].cp0 * tau;
-        // what this frame adds to the PREVIOUS chunk's rows M-2 (t-1) and M-1 (t)
-        y[0] = first ? k[w].cmm * tau : y[0] + k[w].cmm * tau;
-        y[1] = first ? k[w].c0m * tau : y[1] + k[w].c0m * tau;
-        y[3] = first ? k[w].c00 * tau : y[3] + k[w].c00 * tau;
-        if (!BWD) {
-          y[2] = first ? k[w].cm * tm : y[2] + k[w].cm * tm;
-          y[4] = first ? k[w].c0 * tm : y[4] + k[w].c0 * tm;
-        }
-      }
-      if (i == 0) {
-        cb += k[w].c0m * tau;
-        cc = first ? k[w].cpm * tau : cc + k[w].cpm * tau;
-        y[3] += k[w].cmm * tau;
-        if (!BWD) y[4] += k[w].cm * tm;
-      }
-    }
-  };
-  // matrix edges (EDGE): rows >= T are identity rows, entries that would leave the T x T matrix vanish.  Wave-uniform
-  // 0/1 factors instead of branches (x * 1 and x * 1 + 0 are exact; dead frames enter with weight 0, so nothing
-  // that is multiplied by 0 here can be Inf or NaN unless the input is): straight-line code for the allocator.
-  auto fix_row = [&](const int i) __attribute__((always_inline)) {
-    const int f = f0 + i;
-    const double live = f < T ? 1.0 : 0.0, live1 = f + 1 < T ? 1.0 : 0.0, live2 = f + 2 < T ? 1.0 : 0.0;
-    Pd[i] = Pd[i] * live + (1.0 - live);
-    P1[i] *= live1;
-    P2[i] *= live2;
-    rhs[i] *= live;
-  };
-  // elimination state (see `eliminate`)
-  bool bad = false;
-  double t00 = 0.0, t01 = 0.0, t11 = 0.0, h0 = 0.0, h1 = 0.0;
-  double g1 = 0.0, g2 = 0.0, va1 = 0.0, va2 = 0.0, vb1 = 0.0, vb2 = 0.0;
-  double l1p = 0.0, l2p = 0.0, l2pp = 0.0;
-  auto elim_row = [&](const int i) __attribute__((always_inline)) {
-    if (EDGE) {
-      fix_row(i);
-      if (i == 0) {
-        const double keep = (f0 == 0 || f0 >= T) ? 0.0 : 1.0, keepc = f0 + 1 >= T ? 0.0 : 1.0;
-        ca *= keep;
-        cb *= keep;
-        cc *= keep * keepc;
-      }
-    }
-    const double dd = Pd[i];
-    bad |= !(dd > 0.0);
-    const double dinv = fast_rcp(dd);
-    const double e1 = P1[i], e2 = P2[i];
-    const double l1 = e1 * dinv, l2 = e2 * dinv;
-    Pd[i + 1] -= l1 * e1;
-    P1[i + 1] -= l2 * e1;
-    Pd[i + 2] -= l2 * e2;
-    const double gi = rhs[i] - l1p * g1 - l2pp * g2;
-    const double ba = (i == 0) ? ca : 0.0;
-    const double bb = (i == 0) ? cb : ((i == 1) ? cc : 0.0);
-    const double va = ba - l1p * va1 - l2pp * va2;
-    const double vb = bb - l1p * vb1 - l2pp * vb2;
-    const double wa = va * dinv, wb = vb * dinv;
-    t00 += wa * va;
-    t01 += wa * vb;
-    t11 += wb * vb;
-    h0 += wa * gi;
-    h1 += wb * gi;
-    Pd[i] = dinv;
-    P1[i] = l1;
-    P2[i] = l2;
-    rhs[i] = gi;
-    g2 = g1; g1 = gi;
-    va2 = va1; va1 = va;
-    vb2 = vb1; vb1 = vb;
-    l2pp = l2p; l2p = l2; l1p = l1;
-  };
-
-  // prologue: the first kRing frames (f0-1 ..) in flight
-#pragma unroll
-  for (int sl = 0; sl < kRing; ++sl) load_frame(rv[sl], rm[sl], sl - 1);
-  static_assert(kRing >= 2 && kRing <= kM + 2, "ring depth");
-  if (BWD) {
-#pragma unroll
-    for (int i = 0; i < kM; ++i) {
-      int t = f0 + i;
-      if (EDGE) t = t >= T ? T - 1 : t;
-      rhs[i] = (double)ld_row_g<TIN>(grs, (unsigned)t * (unsigned)ldg * (unsigned)sizeof(TIN), loff);  // rows >= T are reset by fix_row
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // step S handles frame I = S - 1 in ring slot S % 6: accumulate, refill with frame I + 6, eliminate row I - 1
-  // MLPG_STRIP_SCHED_RELAX (A/B switch): bit 0 drops the barrier after the accumulation, bit 1 the one after the
-  // refill, bit 2 the one after the elimination step (one wavefront per SIMD wants the scheduler to interleave the
-  // elimination's dependent chain with the next frame's accumulation; two per SIMD did not care)
-#define STRIP_SB(bit) do { if (!((MLPG_STRIP_SCHED_RELAX) & (bit))) __builtin_amdgcn_sched_barrier(0); } while (0)
-#define STRIP_STEP(S)                                                                   \
-  if ((S) < kM + 2) {                                                                   \
-  accumulate_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1);                            \
-  STRIP_SB(1);                                                                          \
-  if ((S) + kRing < kM + 2) { load_frame(rv[(S) % kRing], rm[(S) % kRing], (S)-1 + kRing); } \
-  STRIP_SB(2);                                                                          \
-  if ((S) == 1) {                                                                       \
-    _Pragma("unroll")                                                                   \
-    for (int q = 0; q < 5; ++q) lds_yb[(slot_out * 5 + q) * 64 + lane] = (BWD && (q == 2 || q == 4)) ? 0.0 : y[q]; \
-  }                                                                                     \
-  if ((S)-2 >= 0 && (S)-2 < kN) { elim_row((S)-2); }                                    \
-  STRIP_SB(4);                                                                          \
-  }
-  STRIP_STEP(0) STRIP_STEP(1) STRIP_STEP(2) STRIP_STEP(3) STRIP_STEP(4) STRIP_STEP(5)
-  STRIP_STEP(6) STRIP_STEP(7) STRIP_STEP(8) STRIP_STEP(9) STRIP_STEP(10) STRIP_STEP(11)
-  STRIP_STEP(12) STRIP_STEP(13) STRIP_STEP(14) STRIP_STEP(15) STRIP_STEP(16) STRIP_STEP(17)
-#undef STRIP_STEP
-#undef STRIP_SB
-  if (EDGE) {
-    fix_row(kN);
-    fix_row(kN + 1);
-  }
-  rec[rT00] = t00; rec[rT01] = t01; rec[rT11] = t11; rec[rH0] = h0; rec[rH1] = h1;
-  rec[rD11] = Pd[kN]; rec[rD12] = P1[kN]; rec[rD22] = Pd[kN + 1];
-  rec[rF1] = rhs[kN] - (l1p * g1 + l2pp * g2);
-  rec[rF2] = rhs[kN + 1] - l2p * g1;
-  rec[rL11] = -(l1p * va1 + l2pp * va2);
-  rec[rL12] = -(l1p * vb1 + l2pp * vb2);
-  rec[rL21] = -(l2p * va1);
-  rec[rL22] = -(l2p * vb1);
-  return bad;
-}
-
 
 // ---- level 1: back-substitution; on return x[0..kM) is the chunk's solution -------------------
 __device__ __forceinline__ void backsub(const double (&Pd)[kM], const double (&P1)[kM], const double (&P2)[kM],
@@ -1130,9 +881,6 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   // traffic is agent scope), only for speed.
   const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;  // hwreg(HW_REG_XCC_ID, 0, 4)
   const int R = a.R;
-  const int phase = (MLPG_STRIP_PHASES > 1 && a.nlists > 1 && blockIdx.x >= gridDim.x / 2) ? 1 : 0;
-  int cur_lst = 0, cur_lim = 0;   // the work list this workgroup is drawing from (MLPG_STRIP_PREFETCH draws inside the body)
-  int *cur_ticket = nullptr;
   auto body = [&](const int g, const int r) __attribute__((always_inline)) {
   const int b = g / a.ndg, dg = g - b * a.ndg;
   const int Tmax = p.Tmax;
@@ -1235,22 +983,9 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
 #pragma unroll
     for (int sl = 0; sl < kEarly0; ++sl) ldf(tv[sl], sl - 1);
   };
-  if (MLPG_STRIP_STREAM == 2 && NW3 && MLPG_STRIP_ABLATE < 2) {
-    // three windows: the streamed level 1 with the halo handed over through LDS.  Every chunk of an active strip runs
-    // it, also one behind the utterance's end (all weights 0, identity rows): its predecessor expects its hand-over.
-    // Slots in the tail of the staging area (free until level 3): slot w = what wavefront w consumes; wavefront 0
-    // produces into slot kW-1, which nobody reads (the last wavefront takes zeros instead).
-    double *lds_yb = lds_stage + (size_t)kW * kRec * 64;
-    const int slot_out = wv > 0 ? wv - 1 : kW - 1;
-    const int lastw = wv == kW - 1;
-    const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < T - mw;
-    if (interior) bad = assemble_eliminate_halo<TIN, BWD, VM, false, 3>(lastw, lds_yb, slot_out, lane, mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
-    else bad = assemble_eliminate_halo<TIN, BWD, VM, true, 3>(lastw, lds_yb, slot_out, lane, mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, a.wc, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec);
-    STRIP_TICK(1);
-  } else
   if (f0 < T) {
     const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < T - mw;
-    if (MLPG_STRIP_STREAM == 1 && NW3 && MLPG_STRIP_ABLATE < 2) {
+    if (NW3 && MLPG_STRIP_ABLATE < 2) {
       // the usual three windows: assembly and elimination streamed in frame order
       double wcl[3][9];
       const double (*wcs)[9] = a.wc;
@@ -1341,44 +1076,6 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   const V2 uo = {lds_u[((wv + 1) * 2) * 64 + lane], lds_u[((wv + 1) * 2 + 1) * 64 + lane]};
   const double sx = lds_u[(kW * 2) * 64 + lane];
   const bool sys_bad = !(sx == sx) || !(uo.x == uo.x) || !(ul.x == ul.x);  // NaN: some pivot of this system failed
-  const int ntk = MLPG_STRIP_PREFETCH ? __builtin_amdgcn_readfirstlane(lds_misc[5]) : 0;
-  asm volatile("" ::: "memory");
-  if (MLPG_STRIP_PREFETCH) {
-    // the next item of this workgroup is known: touch the first frames of this wavefront's chunk of it, so that they
-    // travel from HBM while this item back-substitutes and stores
-    // (issued AFTER this item's last LDS reads: the compiler orders every LDS access behind outstanding LDS-DMA loads)
-    if (ntk < cur_lim) {
-      int g2, r2;
-      ticket_item<MULTI>(a, ntk, cur_lst, g2, r2);
-      const int b2 = g2 / a.ndg, dg2 = g2 - b2 * a.ndg;
-      int T2 = p.lengths ? p.lengths[b2] : Tmax;
-      T2 = T2 < 0 ? 0 : (T2 > Tmax ? Tmax : T2);
-      const int fn = (r2 * kW + wv) * kM;
-      if (r2 < R && fn < T2) {
-        const int dn0 = dg2 * a.dgw;
-        const int nd2 = sd - dn0 < a.dgw ? sd - dn0 : a.dgw;
-        const unsigned loff2 = (unsigned)(lane < nd2 ? lane : nd2 - 1) * (unsigned)sizeof(TIN);
-        const __amdgpu_buffer_rsrc_t mr = make_rsrc(BWD ? (const TIN *)p.out : (const TIN *)p.mean + (size_t)b2 * Tmax * ldi + dn0);
-        const __amdgpu_buffer_rsrc_t vr =
-            make_rsrc(VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)b2 * Tmax * ldi + dn0 : (const TIN *)p.out);
-        const unsigned lb = (unsigned)ldi * (unsigned)sizeof(TIN), wb = (unsigned)sd * (unsigned)sizeof(TIN);
-        void *dummy = (void *)(lds_misc + 16 + wv * 64);
-#pragma unroll
-        for (int q = 0; q < (MLPG_STRIP_PREFETCH > 100 ? 0 : MLPG_STRIP_PREFETCH); ++q) {
-          int t = fn - 1 + q;
-          t = t < 0 ? 0 : (t >= T2 ? T2 - 1 : t);
-#pragma unroll
-          for (int w = 0; w < 3; ++w) {
-            if (w < nw) {
-              const unsigned so = (unsigned)t * lb + (unsigned)w * wb;
-              if (VM == MLPG_HIP_VAR_FRAME) touch_row(vr, so, loff2, dummy);
-              if (!BWD) touch_row(mr, so, loff2, dummy);
-            }
-          }
-        }
-      }
-    }
-  }
   if (MLPG_STRIP_ABLATE < 2) backsub(Pd, P1, P2, rhs, ca, cb, cc, ul, uo);
   STRIP_TICK(12);
 
@@ -1489,10 +1186,6 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
         unsigned row_off = (unsigned)t * (unsigned)ldo * (unsigned)sizeof(TOUT);
         if (MLPG_STRIP_BWD_BUFSTORE) asm volatile("" : "+s"(row_off));  // (not one of 17 loop invariants held in scalar registers)
         auto put = [&](const int w, const TOUT val) __attribute__((always_inline)) {
-#ifdef MLPG_STRIP_BWD_NOSTORE  // timing experiment only
-          if (val == (TOUT)123.456) orow[(size_t)w * sd] = val;
-          return;
-#endif
 #if MLPG_STRIP_BWD_BUFSTORE
           st_row(ors_e, row_off + (unsigned)w * (unsigned)sd * (unsigned)sizeof(TOUT), ooff_e, val);
           return;
@@ -1572,7 +1265,7 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   if (wv == 0 && lane == 0 && p.status && (g * R + r) * 4 + 3 < p.B * p.ld_status) {
     int *tp = p.status + (g * R + r) * 4;
     tp[0] = (int)(tr0 & 0x3FFFFFFF); tp[1] = (int)(tra - tr0) | ((int)(tr1 - tr0) << 16); tp[2] = (int)(tr2 - tr0);
-    tp[3] = (int)((long long)__builtin_amdgcn_s_memrealtime() - tr0) | (xcd << 24) | (phase << 28);
+    tp[3] = (int)((long long)__builtin_amdgcn_s_memrealtime() - tr0) | (xcd << 24);
   }
 #endif
   };  // tail
@@ -1586,21 +1279,7 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
     }
     S2 E_s = {1.0, 0.0, 1.0};
     V2 g_s = {0.0, 0.0};
-    // level-1 records; with the handed-over halo (MLPG_STRIP_STREAM == 2) the separator entries D11, D12, D22, F1, F2
-    // of chunks 0 .. kW-2 still lack what the next chunk's first two frames add to them: slot j of the hand-over area
-    // (rows behind the utterance's end are identity rows: their sums vanish)
-    const bool halo = MLPG_STRIP_STREAM == 2 && NW3 && MLPG_STRIP_ABLATE < 2;
-    const double *lds_yr = lds_stage + (size_t)kW * kRec * 64 + lane;
-    auto R_ = [&](int j, int k) __attribute__((always_inline)) {
-      double v = lds_rec[(j * kRec + k) * 64 + lane];
-      if (halo && j < kW - 1 && (k == rD11 || k == rD12 || k == rD22 || k == rF1 || k == rF2)) {
-        const int q = k == rD11 ? 0 : k == rD12 ? 1 : k == rF1 ? 2 : k == rD22 ? 3 : 4;
-        const int fj = (r * kW + j) * kM;  // first frame of chunk j
-        const double live = (q == 0 || q == 2) ? (fj + kN < T ? 1.0 : 0.0) : (fj + kN + 1 < T ? 1.0 : 0.0);
-        if (!(BWD && (q == 2 || q == 4))) v += live * lds_yr[(j * 5 + q) * 64];
-      }
-      return v;
-    };
+    auto R_ = [&](int j, int k) __attribute__((always_inline)) { return lds_rec[(j * kRec + k) * 64 + lane]; };  // level-1 records
     S2 E = {R_(0, rD11), R_(0, rD12), R_(0, rD22)};
     V2 gg = {R_(0, rF1), R_(0, rF2)};
     M2 V = {R_(0, rL11), R_(0, rL12), R_(0, rL21), R_(0, rL22)};
@@ -1878,14 +1557,6 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
       if (bad3) sig.x = __builtin_nan("");
     }
 
-    if (MLPG_STRIP_PREFETCH && lane == 0) {
-      // Nothing this item still needs comes from another workgroup: the next ticket may be drawn (not earlier -- a
-      // ticket held unpublished while this strip waits for its utterance could be the very strip it waits for).
-      int tkn = cur_lim;
-      if (__hip_atomic_load(cur_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cur_lim) tkn = atomicAdd(cur_ticket, 1);
-      lds_misc[5] = tkn;
-      lds_misc[6] = 1;
-    }
     // wavefront 0's share of the early variance rows: only now has it registers to receive them (levels 2 and 3 are done);
     // they travel during the two back-substitutions
     if (kEarly0 > 0) early_issue0();
@@ -1978,37 +1649,21 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   if (!kSplitTail) tail(std::false_type{}, std::integral_constant<int, kEarly>{});
   };  // body
 
-#ifndef MLPG_STRIP_STAGGER
-#define MLPG_STRIP_STAGGER 0  // x 8128 cycles (measured: no gain; kept for experiments)
-#endif
-  // The two workgroups of a CU start together and would load, wait and solve in lockstep (the memory pipe idle
-  // half of the time).  Blocks b and b + 256 of a launch usually share a CU: the second one starts half a period
-  // late, and the offset persists because the periods are equal.  (A wrong guess about placement costs nothing.)
-  if (MLPG_STRIP_STAGGER && (MLPG_STRIP_PHASES > 1 ? phase : (int)(blockIdx.x & 256)))
-    for (int q = 0; q < MLPG_STRIP_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
-
+  // (Starting the second workgroup of each CU half an item late was measured in round 2 -- no gain: two workgroups per CU that draw
+  // tickets desynchronise by themselves -- and removed in round 5.)
   for (int k = 0; k < a.nlists; ++k) {
-    const int lst = (xcd + phase * 8 + k) % a.nlists;
+    const int lst = (xcd + k) % a.nlists;
     // items of this list.  MULTI: the lists are dealt by UTTERANCE (all its dim groups in one list, a full group and
     // the narrow last one alternating) -- by system group, the full groups of 66 = 64 + 2 dims would all land in
     // the even lists and the XCDs behind the odd ones would idle
     const int lim = MULTI ? ((a.nsg / a.ndg - lst + a.nlists - 1) / a.nlists) * a.ndg * R
                           : ((a.nsg * a.nb - lst + a.nlists - 1) / a.nlists) * a.bs;
     int *ticket = a.ctrl + (1 + lst) * kCtrlLine;
-    cur_lst = lst;
-    cur_lim = lim;
-    cur_ticket = ticket;
     for (;;) {
       if (tid == 0) {
         int tk = lim;  // a plain look first: an exhausted list costs no read-modify-write
-        if (MLPG_STRIP_PREFETCH && lds_misc[6]) {
-          tk = lds_misc[5];  // drawn inside the previous item (from this same list)
-        } else if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lim) {
-          tk = atomicAdd(ticket, 1);
-        }
+        if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lim) tk = atomicAdd(ticket, 1);
         lds_misc[0] = tk;
-        lds_misc[5] = lim;
-        lds_misc[6] = 0;
       }
       __syncthreads();
       const int tk = __builtin_amdgcn_readfirstlane(lds_misc[0]);
