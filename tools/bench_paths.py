@@ -516,7 +516,12 @@ def _run(only, quick, device_index):
             vd = vg5[in_col:in_col + 3 * sd_].contiguous()
             ms_sep += gpu_time(lambda: _hip.forward(md, vd, WINDOWS, want_status=False), steps=5)
             del md
-        emit(path="c5g-three-calls-global-variances", batch=B, ms=ms_sep, frames_per_s=B * T / ms_sep * 1e3, alg_bytes=by_g, GBps=by_g / ms_sep / 1e6)
+        emit(path="c5g-three-calls-global-variances", batch=B, ms=ms_sep, frames_per_s=B * T / ms_sep * 1e3, alg_bytes=by_g, GBps=by_g / ms_sep / 1e6,
+             note="dense copies of the three streams' columns, one mlpg_hip_forward each")
+        # ... and as three calls IN PLACE (one stream per forward_streams call: nothing to merge) -- what the one-call form competes with
+        ms_inplace = sum(gpu_time(lambda: _hip.forward_streams(m, vg5, [st_]), steps=5) for st_ in streams)
+        emit(path="c5g-three-calls-in-place-global-variances", batch=B, ms=ms_inplace, frames_per_s=B * T / ms_inplace * 1e3, alg_bytes=by_g,
+             GBps=by_g / ms_inplace / 1e6)
         del m
 
 
