@@ -352,3 +352,40 @@ def test_host_cost_route_equals_the_in_kernel_route_for_the_euclidean_distance()
         assert pl[n] == ql[n]
         assert np.array_equal(pi[n, :pl[n]], qi[n, :pl[n]]) and np.array_equal(pj[n, :pl[n]], qj[n, :pl[n]])
         assert abs(cost[n] - qcost[n]) <= 1e-12 * cost[n]
+
+
+def test_kernel_against_textbook_dtw_and_its_own_path_cost():
+    """Independent of the fastdtw restatement (the package is absent: parity unpinned): with a radius that covers the
+    whole matrix the kernel's distance must be the optimum of the textbook DTW recurrence; at radius 1 on config-4 sized
+    pairs the reported distance must be the local costs accumulated along the reported path, never below the optimum."""
+    rng = np.random.RandomState(91)
+
+    def textbook(x, y):
+        d = np.sqrt(((x[:, None, :] - y[None, :, :]) ** 2).sum(-1))
+        D = np.full((len(x) + 1, len(y) + 1), np.inf)
+        D[0, 0] = 0.0
+        for i in range(1, len(x) + 1):
+            for j in range(1, len(y) + 1):
+                D[i, j] = d[i - 1, j - 1] + min(D[i - 1, j], D[i, j - 1], D[i - 1, j - 1])
+        return float(D[-1, -1]), d
+
+    small = [(_tracks(rng, tx, 4), _tracks(rng, ty, 4)) for tx, ty in ((30, 41), (64, 50), (17, 17), (70, 23))]
+    pi, pj, pl, cost = _run_pairs(small, radius=80)
+    for n, (x, y) in enumerate(small):
+        opt, d = textbook(x, y)
+        assert abs(cost[n] - opt) <= 1e-12 * opt, (n, cost[n], opt)
+        k = int(pl[n])
+        assert abs(float(d[pi[n, :k], pj[n, :k]].sum()) - opt) <= 1e-12 * opt
+    big = [(_tracks(rng, int(rng.randint(700, 901)), 25), _tracks(rng, int(rng.randint(700, 901)), 25)) for _ in range(6)]
+    pi, pj, pl, cost = _run_pairs(big, radius=1)
+    for n, (x, y) in enumerate(big):
+        k = int(pl[n])
+        i, j = pi[n, :k], pj[n, :k]
+        assert (i[0], j[0]) == (0, 0) and (i[-1], j[-1]) == (len(x) - 1, len(y) - 1)
+        si, sj = np.diff(i), np.diff(j)
+        assert ((si >= 0) & (si <= 1) & (sj >= 0) & (sj <= 1) & (si + sj >= 1)).all()
+        acc = float(np.sqrt(((x[i] - y[j]) ** 2).sum(-1)).sum())
+        assert abs(acc - cost[n]) <= 1e-11 * acc, (n, acc, cost[n])
+    opt, _ = textbook(big[0][0][:200], big[0][1][:180])
+    _, _, _, c1 = _run_pairs([(big[0][0][:200], big[0][1][:180])], radius=1)
+    assert c1[0] >= opt * (1 - 1e-12)

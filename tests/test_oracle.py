@@ -231,3 +231,41 @@ def test_dtw_oracle_matches_64_reference_pairs_with_numpy_norm():
         k = int(g["plen"][n])
         assert len(path) == k and np.array_equal(path, g["paths"][n, :k].astype(np.int32)), n
         assert abs(d - g["dist"][n]) <= 1e-12 * g["dist"][n]
+
+
+def _textbook_dtw_cost(x, y):
+    """Dynamic time warping from its definition (Sakoe & Chiba 1978: D[i,j] = d(i,j) + min(D[i-1,j], D[i,j-1], D[i-1,j-1]),
+    Euclidean local cost, full matrix) -- written here, independent of oracle/dtw.py and of fastdtw's source."""
+    tx, ty = len(x), len(y)
+    d = np.sqrt(((x[:, None, :] - y[None, :, :]) ** 2).sum(-1))
+    D = np.full((tx + 1, ty + 1), np.inf)
+    D[0, 0] = 0.0
+    for i in range(1, tx + 1):
+        for j in range(1, ty + 1):
+            D[i, j] = d[i - 1, j - 1] + min(D[i - 1, j], D[i, j - 1], D[i - 1, j - 1])
+    return float(D[tx, ty]), d
+
+
+def test_fastdtw_restatement_against_textbook_dtw():
+    """What can be pinned without the fastdtw package: (1) with a radius that covers the whole matrix fastdtw IS exact DTW --
+    its distance must equal the textbook recurrence's optimum; (2) for any radius its path is a valid warping path whose
+    accumulated local cost is the distance it reports, and that distance is never below the optimum."""
+    rng = np.random.RandomState(77)
+    for (tx, ty, D) in [(9, 13, 2), (40, 31, 5), (64, 64, 3), (25, 70, 4)]:
+        x = np.cumsum(rng.randn(tx, D), 0) * 0.1
+        y = np.cumsum(rng.randn(ty, D), 0) * 0.1
+        opt, d = _textbook_dtw_cost(x, y)
+        for radius in (1, 2, 3, max(tx, ty)):
+            for tie in (0, 1):
+                dist, path = OD.fastdtw(x, y, radius, tie=tie)
+                path = np.asarray(path)
+                assert path[0].tolist() == [0, 0] and path[-1].tolist() == [tx - 1, ty - 1]
+                steps = np.diff(path, axis=0)
+                assert ((steps >= 0) & (steps <= 1)).all() and (steps.sum(1) >= 1).all()
+                acc = float(d[path[:, 0], path[:, 1]].sum())
+                assert abs(acc - dist) <= 1e-12 * max(1.0, abs(dist)), (tx, ty, radius, tie)
+                assert dist >= opt - 1e-12 * opt
+                if radius >= max(tx, ty):
+                    assert abs(dist - opt) <= 1e-12 * opt, (tx, ty, tie, dist, opt)
+        d1, p1 = OD.fastdtw_py(x, y, max(tx, ty))
+        assert abs(d1 - opt) <= 1e-12 * opt
