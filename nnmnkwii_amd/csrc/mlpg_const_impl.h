@@ -64,6 +64,8 @@ struct Args {
   int *tabi;           // [dim group][128]: [0] i_s, [1] lag ok, [64 + lane] first failing row + 1 of the T = infinity factor (0: none)
   double *key;         // [dim group][kMaxWindows + 2][64]: what the group's table was computed from (setup_kernel)
   int ndg, dgw, nsg, tab_rows;
+  int stagger;         // start offset of every other group of 8 workgroups, in units of 8128 cycles (0: none); set by the launcher
+                       // from the grid and the device's CU count (stream_kernel)
   // per window cm = W[t,t-1], c0 = W[t,t], cp = W[t,t+1] and the products cp cp, c0 c0, cm cm, cp c0, c0 cm, cp cm: computed
   // on the host so that the kernel holds them in scalar registers (a product of two scalar doubles formed in the kernel
   // is a vector instruction whose result stays in vector registers for the whole sequence loop)
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
   // workgroups in turn: every other workgroup of an XCD) starts 2 x 8128 cycles late, and since the periods are equal
   // the offset persists.  Measured (config 2 shape, global variances, float64): forward 0.143 -> 0.126 ms, backward
   // 0.140 -> 0.134; 512 x 2000 x 60: 0.460 -> 0.425.  A launch that does not fill the chip has nothing to gain (config 3
-  // shape: 0.039 -> 0.045 ms with the delay), so only full grids do it.
+  // shape: 0.039 -> 0.045 ms with the delay), so only grids of at least half the device's CUs do it (Args::stagger, set by the launcher).
 #ifndef MLPG_CONST_STAGGER
 #define MLPG_CONST_STAGGER 2
 #endif
@@ -561,9 +563,10 @@ __global__ __launch_bounds__(W * 64, WPS) void stream_kernel(Problem p, WinSet w
 #ifndef MLPG_CONST_STAGGER_MASK
 #define MLPG_CONST_STAGGER_MASK 1
 #endif
-  if (gridDim.x >= 128)
-    for (int q = 0; q < MLPG_CONST_STAGGER * (int)((blockIdx.x >> MLPG_CONST_STAGGER_SHIFT) & MLPG_CONST_STAGGER_MASK); ++q)
-      __builtin_amdgcn_s_sleep(127);
+  // (a.stagger: MLPG_CONST_STAGGER for a grid of at least half the device's CUs, 0 below -- the launcher decides from the
+  // device it launches on, not from a constant tuned on one part)
+  for (int q = 0; q < a.stagger * (int)((blockIdx.x >> MLPG_CONST_STAGGER_SHIFT) & MLPG_CONST_STAGGER_MASK); ++q)
+    __builtin_amdgcn_s_sleep(127);
   for (int q = blockIdx.x; q < a.nsg; q += gridDim.x) {
     const int b = q / a.ndg, dg = q - b * a.ndg;
     const int Tmax = p.Tmax;
@@ -1163,6 +1166,9 @@ int launch_cfg(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch
   if (!skip) hipLaunchKernelGGL((setup_kernel<TIN, VM, NW, MULTI>), dim3((unsigned)q.ndg), dim3(64), 0, st, p, a, M, W, fresh ? 1 : 0);
   MLPG_HIP_CHECK(hipGetLastError());
   const int grid = q.nsg < resident ? q.nsg : resident;
+  // the start offset pays once the workgroups of an XCD run in lockstep, i.e. from about one workgroup per two CUs on (measured on
+  // 256 CUs: 64 workgroups lose 15 %, 256 gain 12 %; profiles/r04_notes.md section 2); `resident` is CUs x workgroups per CU (1 here)
+  a.stagger = 2 * grid >= resident ? MLPG_CONST_STAGGER : 0;
   note_launch(MULTI ? kCountConstMulti : kCountConst);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W * 64), 0, st, p, ws, a);
   MLPG_HIP_CHECK(hipGetLastError());
