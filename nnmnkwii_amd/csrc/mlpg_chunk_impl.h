@@ -555,19 +555,19 @@ __global__ __launch_bounds__(64) void reduce_elim_kernel(const Problem p, const 
   };
 #pragma unroll
   for (int j = 0; j < kPF2; ++j) load(pb[j], k0 + j * dk);
-  for (int k = k0; k != k1; k += dk) {
+  // One step: block k sits in ring slot `slot` (a compile-time index: the k loop is unrolled by kPF2; until round 5 the slots
+  // were rotated with register moves).  Measured neutral (72.9 vs 67 us for 256 x 50 blocks): the pass is bound by READING the
+  // records -- 270 MB at the config-2 shape, 4 TB/s from 512 wavefronts with three blocks each in flight -- not by latency.
+  auto step = [&](auto slot_c, const int k) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
     double D[NS], r[Q], E[Q * Q];
 #pragma unroll
-    for (int i = 0; i < NS; ++i) D[i] = pb[0][i] + pb[0][NS + Q + i];
+    for (int i = 0; i < NS; ++i) D[i] = pb[slot][i] + pb[slot][NS + Q + i];
 #pragma unroll
-    for (int i = 0; i < Q; ++i) r[i] = pb[0][NS + i] + pb[0][2 * NS + Q + i];
+    for (int i = 0; i < Q; ++i) r[i] = pb[slot][NS + i] + pb[slot][2 * NS + Q + i];
 #pragma unroll
-    for (int i = 0; i < Q * Q; ++i) E[i] = pb[0][2 * NS + 2 * Q + i];
-#pragma unroll
-    for (int j = 0; j + 1 < kPF2; ++j)
-#pragma unroll
-      for (int i = 0; i < kBlk; ++i) pb[j][i] = pb[j + 1][i];
-    load(pb[kPF2 - 1], k + kPF2 * dk);
+    for (int i = 0; i < Q * Q; ++i) E[i] = pb[slot][2 * NS + 2 * Q + i];
+    load(pb[slot], k + kPF2 * dk);
     if (k != k0) {
       if (h) B::template couple<false>(D, r, E, Lp, dpi, rp);
       else B::template couple<true>(D, r, E, Lp, dpi, rp);
@@ -589,6 +589,15 @@ __global__ __launch_bounds__(64) void reduce_elim_kernel(const Problem p, const 
       dpi[i] = di[i];
       rp[i] = r[i];
     }
+  };
+  static_assert(kPF2 == 3, "the k loop below is unrolled by three");
+  for (int k = k0;;) {
+    if (k == k1) break;
+    step(std::integral_constant<int, 0>{}, k); k += dk;
+    if (k == k1) break;
+    step(std::integral_constant<int, 1>{}, k); k += dk;
+    if (k == k1) break;
+    step(std::integral_constant<int, 2>{}, k); k += dk;
   }
   if (bad) a.bad[(size_t)g * 64 + lane] = 1;
 }
@@ -656,19 +665,13 @@ __global__ __launch_bounds__(64) void reduce_subst_kernel(const Problem p, const
     };
 #pragma unroll
     for (int j = 0; j < kPF2; ++j) load_up(j, m + 1 + j);
-    for (int k = m + 1; k < Kb; ++k) {
+    auto step_up = [&](auto slot_c, const int k) __attribute__((always_inline)) {   // (static ring slots: see reduce_elim_kernel)
+      constexpr int slot = decltype(slot_c)::value;
       double Lf[NS], di[Q], v[Q], E[Q * Q];
-      B::unpack_fac(pF[0], Lf, di, v);
+      B::unpack_fac(pF[slot], Lf, di, v);
 #pragma unroll
-      for (int i = 0; i < Q * Q; ++i) E[i] = pE[0][i];
-#pragma unroll
-      for (int j = 0; j + 1 < kPF2; ++j) {
-#pragma unroll
-        for (int i = 0; i < G::kFac; ++i) pF[j][i] = pF[j + 1][i];
-#pragma unroll
-        for (int i = 0; i < Q * Q; ++i) pE[j][i] = pE[j + 1][i];
-      }
-      load_up(kPF2 - 1, k + kPF2);
+      for (int i = 0; i < Q * Q; ++i) E[i] = pE[slot][i];
+      load_up(slot, k + kPF2);
 #pragma unroll
       for (int q = 0; q < Q; ++q)
 #pragma unroll
@@ -679,6 +682,15 @@ __global__ __launch_bounds__(64) void reduce_subst_kernel(const Problem p, const
         xm[i] = v[i];
         xs[((size_t)k * Q + i) * 64] = v[i];
       }
+    };
+    static_assert(kPF2 == 3, "the k loop below is unrolled by three");
+    for (int k = m + 1;;) {
+      if (k >= Kb) break;
+      step_up(std::integral_constant<int, 0>{}, k); ++k;
+      if (k >= Kb) break;
+      step_up(std::integral_constant<int, 1>{}, k); ++k;
+      if (k >= Kb) break;
+      step_up(std::integral_constant<int, 2>{}, k); ++k;
     }
   } else {
     // downwards from the middle: x_k = D'_k^-1 (r'_k - E_{k+1}^T x_{k+1}), k = m-1 .. 0
@@ -695,19 +707,13 @@ __global__ __launch_bounds__(64) void reduce_subst_kernel(const Problem p, const
     };
 #pragma unroll
     for (int j = 0; j < kPF2; ++j) load_dn(j, m - 1 - j);
-    for (int k = m - 1; k >= 0; --k) {
+    auto step_dn = [&](auto slot_c, const int k) __attribute__((always_inline)) {
+      constexpr int slot = decltype(slot_c)::value;
       double Lf[NS], di[Q], v[Q], E[Q * Q];
-      B::unpack_fac(pF[0], Lf, di, v);
+      B::unpack_fac(pF[slot], Lf, di, v);
 #pragma unroll
-      for (int i = 0; i < Q * Q; ++i) E[i] = pE[0][i];
-#pragma unroll
-      for (int j = 0; j + 1 < kPF2; ++j) {
-#pragma unroll
-        for (int i = 0; i < G::kFac; ++i) pF[j][i] = pF[j + 1][i];
-#pragma unroll
-        for (int i = 0; i < Q * Q; ++i) pE[j][i] = pE[j + 1][i];
-      }
-      load_dn(kPF2 - 1, k - kPF2);
+      for (int i = 0; i < Q * Q; ++i) E[i] = pE[slot][i];
+      load_dn(slot, k - kPF2);
 #pragma unroll
       for (int q = 0; q < Q; ++q)
 #pragma unroll
@@ -718,6 +724,15 @@ __global__ __launch_bounds__(64) void reduce_subst_kernel(const Problem p, const
         xm[i] = v[i];
         xs[((size_t)k * Q + i) * 64] = v[i];
       }
+    };
+    static_assert(kPF2 == 3, "the k loop below is unrolled by three");
+    for (int k = m - 1;;) {
+      if (k < 0) break;
+      step_dn(std::integral_constant<int, 0>{}, k); --k;
+      if (k < 0) break;
+      step_dn(std::integral_constant<int, 1>{}, k); --k;
+      if (k < 0) break;
+      step_dn(std::integral_constant<int, 2>{}, k); --k;
     }
   }
   if (bad) a.bad[(size_t)g * 64 + lane] = 1;
