@@ -111,6 +111,10 @@ constexpr int kCtrlLine = 32;
                                // formed in float32, _mlpg.py:188) stay in registers from the assembly to the epilogue -- no second
                                // pass over the variances, no second division (round 5)
 #endif
+#ifndef MLPG_STRIP_FWD_BUFSTORE
+#define MLPG_STRIP_FWD_BUFSTORE 1  // forward: trajectory rows by buffer stores (three interleaved rounds, profiles/r05_strip_ab3.txt: float64
+                                   // 0.2323 / 0.2320 / 0.2376 -> 0.2281 / 0.2300 / 0.2330 ms; float32 within the noise)
+#endif
 #ifndef MLPG_STRIP_BWD_BUFSTORE
 #define MLPG_STRIP_BWD_BUFSTORE 1  // backward epilogue (three windows): gradient rows by buffer stores (scalar offsets) instead of global stores
 #endif
@@ -1102,6 +1106,17 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   if (!lane_ok) return;
 #endif
   if (!BWD) {
+#if MLPG_STRIP_FWD_BUFSTORE
+    // trajectory rows by buffer stores: the utterance's descriptor, the row offset in a scalar register, the dim's offset in one
+    // vector register (16 stores per chunk; interleaved A/B in round 5: see the switch)
+    const __amdgpu_buffer_rsrc_t ors_f = make_rsrc(out_b);
+    const unsigned ooff_f = (unsigned)d * (unsigned)sizeof(TOUT), ldo_b = (unsigned)ldo * (unsigned)sizeof(TOUT);
+#pragma unroll
+    for (int i = 0; i < kM; ++i) {
+      const int t = f0 + i;
+      if (t < Tmax) st_row(ors_f, (unsigned)t * ldo_b, ooff_f, (t < T && !zero_out) ? (TOUT)rhs[i] : (TOUT)0);
+    }
+#else
 #pragma unroll
     for (int i = 0; i < kM; ++i) {
       const int t = f0 + i;
@@ -1111,6 +1126,7 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
       if (t < Tmax) out_b[(size_t)t * ldo + d] = (t < T && !zero_out) ? (TOUT)rhs[i] : (TOUT)0;
 #endif
     }
+#endif
   } else {
     // grad[t, w*sd+d] = tau_w[t] * (cm x[t-1] + c0 x[t] + cp x[t+1])  (paramgen/_mlpg.py:202-281).  The row whose
     // right neighbour lives in the next chunk is written by that chunk: this wavefront writes rows f0-1 .. f0+14,
