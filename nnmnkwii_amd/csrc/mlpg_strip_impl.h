@@ -79,6 +79,9 @@ constexpr int kW = MLPG_STRIP_W;  // chunks (wavefronts) per strip (workgroup)
 constexpr int kM = MLPG_STRIP_M;  // frames per chunk
 constexpr int kN = kM - 2;   // interior frames of a chunk; frames kN, kN+1 are its separator
 constexpr int kRec = 14;     // doubles per lane in a level-1 / level-2 record
+#ifndef MLPG_STRIP_DAMP1_TOL
+#define MLPG_STRIP_DAMP1_TOL 0x1p-66  // acceptance bound of the 3-strip window (route 1), see kDamp1Tol
+#endif
 #ifndef MLPG_STRIP_STAGE
 #define MLPG_STRIP_STAGE (MLPG_STRIP_W > 6 ? 8 : 6)
 #endif
@@ -146,7 +149,7 @@ constexpr int kCtrlLine = 32;
 #define MLPG_STRIP_RING_F64 6
 #endif
 #ifndef MLPG_STRIP_ROUTE1_TOL
-#define MLPG_STRIP_ROUTE1_TOL 0.0  // own transfer factor below which a 3-strip window is tried first (0: never)
+#define MLPG_STRIP_ROUTE1_TOL 0x1p-66  // own transfer factor below which the 3-strip window is tried first (0: never), see kDamp1Tol
 #endif
 constexpr int kMaxLists = 8;
 constexpr int kLocal = 2;          // level 3 first looks at the records of strips r-2 .. r+2 only
@@ -154,6 +157,14 @@ constexpr int kLocal = 2;          // level 3 first looks at the records of stri
 constexpr double kRouteTol = 1e-11; // a strip whose own transfer factor 2 max|E^-1 V| exceeds this (= kDampTol^(1/2)) does not
                                     // try the 5-strip window (see the route)
 constexpr double kDampTol = 1e-22; // ... and accepts that if the window's edges are damped below this at rows r-1, r
+// The 3-strip window r-1 .. r+1 (round 5).  Separators 64 frames apart are coupled by 1e-24 .. 1e-21 for variances of one order of
+// magnitude, so the rigorous bound of ONE strip per side lands around 1e-22 -- on either side of kDampTol (tools/strip_model.py on
+// the bench data: median 1.0e-22, maximum 1.1e-21, while the windowed result equalled the exact solve to the last bit in every
+// strip).  Its acceptance bound is therefore 2^-66 = 1.4e-20: what the window leaves out moves the separator values by at most
+// 2^-13 of the spacing of doubles there.  A strip tries it when its own transfer factor is below that; a rejected attempt is followed
+// by the 5-strip window, then by the whole utterance (the ladder in the kernel).  Measured: config 2 forward 0.233 -> 0.216-0.225 ms
+// (profiles/r05_notes.md section 11): the strip waits for two neighbours instead of four and sweeps three records instead of five.
+constexpr double kDamp1Tol = MLPG_STRIP_DAMP1_TOL;
 // the records strip r of Ract reads first: rows lo .. hiE; the last one only as the clamped edge (T, h, V) if `edge`
 struct Window { int lo, hiE, edge; };
 __device__ __forceinline__ Window local_window(int r, int Ract, int k) {
@@ -1537,34 +1548,61 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
         }
         damp = dt > db ? dt : db;
       };
-      const Window w = local_window(r, Ract, route ? route : kLocal);
-      const bool full_range = w.lo == 0 && !w.edge;
       if (route == 0) {
         sweep(0, Ract - 1, 0);
       } else {
-      sweep(w.lo, w.hiE, w.edge);
-      // accept the windowed result only if every system of the strip is damped far below the rounding level and
-      // met no failing pivot (those are re-examined on the whole utterance, so that the verdict never depends on
-      // the window)
-      const bool lane_fine = !lane_ok || full_range || (damp < kDampTol && sig.x == sig.x);
-      const int accept = timed_out || __ballot(!lane_fine) == 0ull;
-      if (lane == 0) lds_misc[2] = accept;
-      if (!accept && lane == 0) {
-        // the whole utterance is needed: wait for all of its strips
+        // The ladder (round 5): the window the strip routed itself to; if its bound is not small enough, a rejected 3-strip
+        // window is followed by the 5-strip one (its records from HBM this time), any other by the whole utterance.  Every
+        // decision depends on the strip's and its neighbours' DATA only, never on timing.
+        int cur = route;
         int *cnt = a.ctrl + (1 + kMaxLists + g) * kCtrlLine;
-        int spins = 0, ok = 1;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < Ract) {
-          __builtin_amdgcn_s_sleep(32);
-          if (++spins > kSpinLimit) { ok = 0; break; }
+        int *flags = a.ctrl + (1 + kMaxLists + a.nsg) * kCtrlLine + (size_t)g * flag_pitch(R);
+        for (;;) {
+          const Window w = local_window(r, Ract, cur);
+          const bool full_range = w.lo == 0 && !w.edge;
+          sweep(w.lo, w.hiE, w.edge);
+          // accept the windowed result only if every system of the strip is damped far below the rounding level and
+          // met no failing pivot (those are re-examined on the whole utterance, so that the verdict never depends on
+          // the window)
+          const double tolw = cur == 1 ? kDamp1Tol : kDampTol;
+          const bool lane_fine = !lane_ok || full_range || (damp < tolw && sig.x == sig.x);
+          const int accept = timed_out || __ballot(!lane_fine) == 0ull;
+          // 0: done; 1: the 5-strip window next (after a 3-strip one that does not already reach that far); 2: the whole utterance
+          const int next = accept ? 0 : ((cur == 1 && kLocal > 1) ? 1 : 2);
+          int ok = 1;
+          if (next == 1) {
+            // the two strips the wider window adds may not have arrived yet (lane l polls the flag of strip wlo + l)
+            const Window w2 = local_window(r, Ract, kLocal);
+            int spins = 0;
+            for (;;) {
+              int f = 1;
+              if (lane <= w2.hiE - w2.lo) f = __hip_atomic_load(flags + w2.lo + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (__ballot(f == 0) == 0ull) break;
+              __builtin_amdgcn_s_sleep(MLPG_STRIP_POLL_SLEEP);
+              if (++spins > kSpinLimit) { ok = 0; break; }
+            }
+          } else if (next == 2) {
+            // the whole utterance is needed: wait for all of its strips
+            int spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < Ract) {
+              __builtin_amdgcn_s_sleep(32);
+              if (++spins > kSpinLimit) { ok = 0; break; }
+            }
+          }
+          if (lane == 0) {
+            if (!ok) atomicAdd(a.ctrl, 1);
+            if (next) lds_misc[1] = ok;
+            lds_misc[2] = next;
+          }
+          __syncthreads();  // (S2b) the stagers learn the decision
+          if (next == 0) break;
+          timed_out = !ok;
+          if (next == 2) {
+            sweep(0, Ract - 1, 0);
+            break;
+          }
+          cur = kLocal;
         }
-        if (!ok) atomicAdd(a.ctrl, 1);
-        lds_misc[1] = ok;
-      }
-      __syncthreads();  // (S2b) the stagers learn the decision
-      if (!accept) {
-        timed_out = !__builtin_amdgcn_readfirstlane(lds_misc[1]);
-        sweep(0, Ract - 1, 0);
-      }
       }
     } else {
       bool bad3 = false;
@@ -1645,18 +1683,25 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
         }
       };
       const int route = __builtin_amdgcn_readfirstlane(lds_misc[3]);  // wavefront 0's choice (see there)
-      const Window w = local_window(r, Ract, route ? route : kLocal);
       if (route == 0) {
         skip_own = false;
         stage(0, Ract - 1);
       } else {
         skip_own = route <= kLocal && 2 * route + 1 <= kStage;  // only the narrow (single-batch) windows have this strip's own record in LDS already
-        stage(w.lo, w.hiE);
-        __syncthreads();  // (S2b) wavefront 0's decision: is the window enough?
-        if (!__builtin_amdgcn_readfirstlane(lds_misc[2])) {
+        int cur = route;
+        for (;;) {  // wavefront 0's ladder, mirrored
+          const Window w = local_window(r, Ract, cur);
+          stage(w.lo, w.hiE);
+          __syncthreads();  // (S2b) wavefront 0's decision: is the window enough?
+          const int next = __builtin_amdgcn_readfirstlane(lds_misc[2]);
+          if (next == 0) break;
           timed_out = !__builtin_amdgcn_readfirstlane(lds_misc[1]);
-          skip_own = false;  // the full sweep stages every row from HBM (several batches reuse the slots)
-          stage(0, Ract - 1);
+          skip_own = false;  // from here on every row is staged from HBM
+          if (next == 2) {
+            stage(0, Ract - 1);
+            break;
+          }
+          cur = kLocal;
         }
       }
     }

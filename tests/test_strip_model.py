@@ -107,3 +107,30 @@ def test_model_wider_windows_for_tighter_dynamic_variances():
     assert max(d for d, _ in s2) > 1e-22 and max(d for d, _ in s4) < 1e-22
     assert max(e for _, e in s4) < 1e-13
     assert rel_err(y4, O.mlpg(m, v, W3)) < 1e-10
+
+
+def test_three_strip_window_and_the_ladder():
+    W3 = WINDOW_SETS["std3"]
+    """Round 5: the 3-strip level-3 window.  On the bench's data (variances of one order of magnitude) its rigorous bound sits
+    around 1e-22 -- on either side of the 5-strip window's acceptance bound -- while its result equals the exact solve; with
+    the kernel's bound of 2^-66 every strip accepts it.  With dynamic variances 10 x tighter it is rejected and the ladder
+    goes on to the 5-strip window (or to the exact solve): the trajectory matches the oracle either way."""
+    rng = np.random.RandomState(5)
+    T, sd = 700, 7
+    m = rng.randn(T, 3 * sd)
+    v = rng.rand(T, 3 * sd) + 0.1
+    ref = O.mlpg(m, v, W3)
+    stats = []
+    y, bad = S.mlpg_strip(m, v, W3, local_k=(1, 2), local_tol=(2.0 ** -66, 1e-22), stats=stats)
+    assert not bad.any() and np.abs(y - ref).max() <= 1e-12 * np.abs(ref).max()
+    d1 = [d for d, e, k in stats if k == 1]
+    assert len(d1) == len(stats) and max(d1) < 2.0 ** -66          # every strip took the 3-strip window ...
+    assert 1e-25 < np.median(d1) < 1e-20                            # ... whose bound is nowhere near 1e-47 (the 5-strip one's)
+    assert max(e for d, e, k in stats) <= 1e-15                     # and the separator values are the exact solve's
+    v2 = v.copy()
+    v2[:, sd:] *= 0.1                                               # dynamic features 10 x tighter: slower decay
+    ref2 = O.mlpg(m, v2, W3)
+    stats = []
+    y2, bad = S.mlpg_strip(m, v2, W3, local_k=(1, 2), local_tol=(2.0 ** -66, 1e-22), stats=stats)
+    assert not bad.any() and np.abs(y2 - ref2).max() <= 1e-12 * np.abs(ref2).max()
+    assert any(k == 2 for d, e, k in stats)                         # the ladder was used

@@ -418,11 +418,18 @@ def mlpg_strip(mean_frames, variance_frames, windows, W=4, T=None, two_sided=Tru
             s, sr, bad2, _ = utterance_solve_two_sided(recs, r)
             bad = bad | bad2
             if local_k:
-                lo_, hi_, edge_ = local_window(r, R, local_k)
-                s2, sr2, _, damp = utterance_solve_two_sided(recs, r, lo_, hi_, edge_)
-                stats.append((float(damp.max()), float(max(np.abs(np.stack(sr2) - np.stack(sr)).max(), np.abs(np.stack(s2) - np.stack(s)).max()))))
-                if damp.max() < local_tol:
-                    s, sr = s2, sr2
+                # the kernel's ladder (round 5): local_k / local_tol may be sequences -- the windows tried in turn, each with its
+                # own acceptance bound (kernel: 1 strip per side at 2^-66, then 2 at 1e-22); none accepted = the exact solve
+                ks = local_k if isinstance(local_k, (tuple, list)) else (local_k,)
+                tols = local_tol if isinstance(local_tol, (tuple, list)) else (local_tol,) * len(ks)
+                for k_, tol_ in zip(ks, tols):
+                    lo_, hi_, edge_ = local_window(r, R, k_)
+                    s2, sr2, _, damp = utterance_solve_two_sided(recs, r, lo_, hi_, edge_)
+                    rec_ = (float(damp.max()), float(max(np.abs(np.stack(sr2) - np.stack(sr)).max(), np.abs(np.stack(s2) - np.stack(s)).max())))
+                    stats.append(rec_ + (k_,) if len(ks) > 1 else rec_)
+                    if damp.max() < tol_:
+                        s, sr = s2, sr2
+                        break
         else:
             sr = sig[r]
         us = strip_backsub(facs[r], s, sr)
