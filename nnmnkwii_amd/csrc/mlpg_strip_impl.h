@@ -136,9 +136,11 @@ constexpr int kCtrlLine = 32;
 #define MLPG_STRIP_BWD_EARLY0 0  // MLPG_STRIP_BWD_EARLY for wavefront 0 (requested behind its publish)
 #endif
 #ifndef MLPG_STRIP_BWD_EARLY
-#define MLPG_STRIP_BWD_EARLY 8  // backward, float64 inputs: the variance rows of the epilogue's first n frames are requested as soon as
+#define MLPG_STRIP_BWD_EARLY 4  // backward, float64 in and out: the variance rows of the epilogue's first n frames are requested as soon as
                                 // level 1 is done (into the registers the ring has left), so that they travel while the strip waits for
-                                // its neighbours; the other 17 - n frames are requested in front of the first store as before (round 5)
+                                // its neighbours; the other 17 - n frames are requested in front of the first store as before (round 5).
+                                // Worth half a percent (0 / 8 / 10 rows: 0.2671 / 0.2652 / 0.2646 ms); 4 is what fits without a spill
+                                // beside the level-3 ladder's state (8: 15 spilled registers)
 #endif
 #ifndef MLPG_STRIP_NT_STORES
 #define MLPG_STRIP_NT_STORES 1  // trajectory and gradient rows with the nontemporal hint (written once, never read by this kernel); round 5 A/B
@@ -704,7 +706,7 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
     for (int w = 0; w < NW; ++w) {
       double tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[w]) : k[w].tau_glob;
       if (EDGE) tau *= (t >= lo[w] && t < hi[w]) ? 1.0 : 0.0;  // wave-uniform weight
-      if (KEEP && i < kM) tk[i + 1][w] = (float)tau;  // exact: a float32 reciprocal, or 0
+      if (KEEP && i < kM) tk[i + 1][w] = (float)tau;  // float32 inputs: exact (a float32 reciprocal, or 0); float64 inputs: rounded
       double tm = 0.0;
       if (!BWD) tm = tau * (double)m[w];
       const bool first = w == 0;  // first contribution to: Pd, rhs of row t+1; P1 of row t; P2 of row t-1
@@ -966,13 +968,15 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   double rec[kRec];
   bool bad = false;
   // Backward epilogue inputs (frame-major form, three windows): the precisions of the frames f0-1 .. f0+kM-1.
-  //   float32 inputs (kKeepTau): kept from the assembly in tk[][] -- float32 values, 51 registers;
-  //   float64 inputs: the variance rows are read a second time; those of the first kEarly frames are requested right
+  //   float32 inputs, or a float32 gradient (kKeepTau): kept from the assembly in tk[][] -- float32 values, 51 registers;
+  //   float64 inputs with a float64 gradient: the variance rows are read a second time; those of the first kEarly frames are requested right
   //   after level 1 (early_issue(): the ring's registers are free then), so that they travel while the strip waits
   //   for its neighbours, the rest in front of the epilogue's first store.
-  constexpr bool kKeepTau = NW3 && BWD && VM == MLPG_HIP_VAR_FRAME && sizeof(TIN) == 4 && MLPG_STRIP_BWD_KEEP && !MULTI;
+  // (float64 inputs with a float32 gradient -- what the reference's mlpg_grad returns, _mlpg.py:248 -- keep the precisions rounded
+  // to float32 too: the product is rounded to float32 anyway, so this costs at most one more rounding of 2^-24)
+  constexpr bool kKeepTau = NW3 && BWD && VM == MLPG_HIP_VAR_FRAME && (sizeof(TIN) == 4 || sizeof(TOUT) == 4) && MLPG_STRIP_BWD_KEEP && !MULTI;
   constexpr int kEpi = kM + 1;
-  constexpr int kEarly = (NW3 && BWD && VM == MLPG_HIP_VAR_FRAME && sizeof(TIN) == 8 && MLPG_STRIP_BWD_FRAME_MAJOR) ? MLPG_STRIP_BWD_EARLY : 0;
+  constexpr int kEarly = (NW3 && BWD && VM == MLPG_HIP_VAR_FRAME && sizeof(TIN) == 8 && !kKeepTau && MLPG_STRIP_BWD_FRAME_MAJOR) ? MLPG_STRIP_BWD_EARLY : 0;
   // the tail is instantiated per role only where the roles differ in what they keep (otherwise once, behind the roles:
   // two copies of the epilogue cost scalar registers that the streamed level 1 then spills)
   constexpr bool kSplitTail = kKeepTau && !MLPG_STRIP_BWD_KEEP0;

@@ -50,3 +50,10 @@ for dt in (torch.float64, torch.float32):
         grr, _ = _hip.backward(v[:8], g[:8], W3, 3 * sd, out_dtype=dt, algo=1)
         err = float((gr - grr).abs().max() / grr.abs().max())
         print("%-28s %s backward %.4f ms (min %.4f)  frac %.3f  dev vs natural-order %.2e  status %d" % (tag, str(dt)[6:], b, bmin, by / b / 1e6 / 8000, err, int(st.abs().sum())), flush=True)
+        if dt == torch.float64:
+            # float64 in, float32 gradient out: what the reference's mlpg_grad returns (_mlpg.py:248)
+            b32, b32min = timeit(lambda: _hip.backward(v, g, W3, 3 * sd, out_dtype=torch.float32, algo=3, want_status=False))
+            gr, _ = _hip.backward(v[:8], g[:8], W3, 3 * sd, out_dtype=torch.float32, algo=3)
+            err = float((gr.double() - grr).abs().max() / grr.abs().max())
+            by32 = (8 * 4 + 4 * 3) * sd * B * T
+            print("%-28s float64 -> float32 backward %.4f ms (min %.4f)  frac %.3f  dev vs natural-order (float64) %.2e" % (tag, b32, b32min, by32 / b32 / 1e6 / 8000, err), flush=True)
