@@ -459,3 +459,48 @@ def test_retired_pipe_algo_selects_the_strip_kernel():
     assert _hip.lib().mlpg_hip_launch_count(2) == n0 + 1
     b, _ = _hip.forward(m, v, STD3, algo=_hip.ALGO_STRIP)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_strip_ladder_rungs_with_variance_regimes_changing_along_the_utterance(dt):
+    """Round 5: level 3 tries the 3-strip window r-1 .. r+1 first (a strip routes itself there when its own transfer factor
+    is below 2^-66), then the 5-strip one, then the whole utterance.  Here the variance regime changes every few strips
+    along the utterance -- ordinary (one order of magnitude), dynamic features 10 x / 100 x tighter, 100 x / 1000 x tighter
+    -- so that strips with tiny transfer factors sit next to slowly decaying ones: their 3-strip attempt is rejected by the
+    bound and the ladder is climbed.  Every utterance against the oracle and the natural-order kernel; ragged lengths;
+    repeated launches bitwise equal (the rung a strip ends on depends on the data only)."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(2025)
+    B, T, sd = 6, 1536, 60
+    m = rng.randn(B, T, 3 * sd).astype(dt)
+    v = (rng.rand(B, T, 3 * sd) + 0.1)
+    scale_d = np.ones((B, T, 1))
+    for b in range(B):
+        for s0 in range(0, T, 128):                       # two strips per regime
+            reg = rng.randint(3) if b else (s0 // 128) % 3
+            f1, f2 = ((1.0, 1.0), (0.1, 0.01), (0.01, 0.001))[reg]
+            v[b, s0:s0 + 128, sd:2 * sd] *= f1
+            v[b, s0:s0 + 128, 2 * sd:] *= f2
+    v = v.astype(dt)
+    lengths = np.array([T, T - 1, 1000, 65, 700, T], dtype=np.int32)
+    for b in range(B):
+        m[b, lengths[b]:] = 0
+    ref, _, rc = O.mlpg_batch(m, v, STD3, lengths)
+    assert rc == 0
+    mg, vg, L = torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(lengths).cuda()
+    out, status = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_STRIP)
+    out2, _ = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_STRIP)
+    gen, _ = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_GENERIC)
+    assert int(status.abs().max().item()) == 0 and torch.equal(out, out2)
+    out, gen = out.cpu().numpy().astype(np.float64), gen.cpu().numpy().astype(np.float64)
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    tol = 1e-9 if dt == np.float64 else 5e-6
+    e_ref = (np.abs(out - ref) / scale).max()
+    e_gen = (np.abs(gen - ref) / scale).max()
+    assert e_ref <= max(tol, 10 * e_gen), (e_ref, e_gen)
+    go = torch.from_numpy(rng.randn(B, T, sd).astype(dt)).cuda()
+    gs, _ = _hip.backward(vg, go, STD3, 3 * sd, L, out_dtype=torch.float64, algo=_hip.ALGO_STRIP)
+    gg, _ = _hip.backward(vg, go, STD3, 3 * sd, L, out_dtype=torch.float64, algo=_hip.ALGO_GENERIC)
+    assert float((gs - gg).abs().max()) <= (1e-7 if dt == np.float64 else 1e-5) * float(gg.abs().max())
