@@ -226,10 +226,11 @@ void mlpg_hip_host_free(void *p);
  *          are copied through (frames >= lengths[b] zero-filled).
  *   status : int32 (B, sum_k static_dim), streams in table order; may be NULL.
  * The slices are consumed in place (no repacking).  Streams that share their
- * three windows (extents <= 1) and have per-frame variances are solved by ONE
- * launch (their static dims side by side on the lanes; a stream may be cut to
- * fill the last 64-lane group, its remaining dims then run as a launch of their
- * own); every other stream is one launch.  Launches other than the widest go
+ * three windows (extents <= 1) are solved by ONE launch -- per-frame variances:
+ * of the strip kernel; global (ld_in,) or unit variances (round 5): of the
+ * constant-coefficient kernel -- their static dims side by side on the lanes; a
+ * stream may be cut to fill the last 64-lane group, its remaining dims then run
+ * as a launch of their own; every other stream is one launch.  Launches other than the widest go
  * to internal streams forked from and joined back into `stream` with events
  * (no host synchronisation; capturable): when the call returns, everything is
  * ordered on `stream`.  Which kernel solves a dim depends on the grouping, the
