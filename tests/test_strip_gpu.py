@@ -1,3 +1,7 @@
+    """Failing pivots at the config-2 size: 4096 strips over 512 workgroups on all eight XCDs (whose L2s are not coherent with each
+    other), ~60 failures scattered over utterances, dims, windows and strips.  Status equal to the natural-order kernel's, failed
+    columns exactly zero (no strip's rows land on top of the zeros the verdict writes), the other columns untouched by it; twenty
+    launches in a row, a clean launch after each (it starts from the control words a launch with marks left behind)."""
 """GPU parity tests (-m gpu) of the strip MLPG kernel (algo = MLPG_HIP_ALGO_STRIP: lane per static dim,
 wavefront per 16-frame chunk, strips of one utterance solved across workgroups), through the C ABI,
 against the CPU oracle.  Same tolerances as tests/test_mlpg_gpu.py."""
@@ -504,3 +508,88 @@ def test_strip_ladder_rungs_with_variance_regimes_changing_along_the_utterance(d
     gs, _ = _hip.backward(vg, go, STD3, 3 * sd, L, out_dtype=torch.float64, algo=_hip.ALGO_STRIP)
     gg, _ = _hip.backward(vg, go, STD3, 3 * sd, L, out_dtype=torch.float64, algo=_hip.ALGO_GENERIC)
     assert float((gs - gg).abs().max()) <= (1e-7 if dt == np.float64 else 1e-5) * float(gg.abs().max())
+
+
+def _scatter_failures(rng, v, B, T, sd, lengths, n):
+    """n negative variances at random live places of a (B, T, 3 sd) tensor (torch, on the GPU)."""
+    import torch
+    bs = rng.randint(0, B, size=n)
+    ds = rng.randint(0, sd, size=n)
+    ws = rng.randint(0, 3, size=n)
+    ts = np.array([rng.randint(2 if w else 0, max(lengths[b] - (2 if w else 0), 3)) for b, w in zip(bs, ws)])
+    v[torch.from_numpy(bs).cuda(), torch.from_numpy(ts).cuda(), torch.from_numpy(ws * sd + ds).cuda()] = -1e-3
+    return bs, ds
+
+
+@pytest.mark.parametrize("direction", ["fwd", "bwd"])
+def test_strip_failures_settled_at_full_size(direction):
+    """Round 5: the launch's last workgroup -- not a second kernel -- turns the marks of failing pivots into the reference's status
+    and zero columns, and re-zeroes the control words.  At the config-2 size (4096 strips over 512 workgroups on all eight XCDs,
+    whose L2s are not coherent with each other) with ~60 failures scattered over utterances, dims, windows and strips: status
+    equal to the natural-order kernel's, failed columns exactly zero (no strip's rows land on top of the zeros), the other
+    columns untouched by it; twenty launches in a row, clean launches in between (the control words they start from were left by
+    a launch that had marks)."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(77)
+    B, T, sd = 256, 1000, 60
+    g = torch.Generator(device="cuda").manual_seed(5)
+    m = torch.randn(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=g)
+    v_ok = torch.rand(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=g) + 0.1
+    go = torch.randn(B, T, sd, dtype=torch.float64, device="cuda", generator=g)
+    lengths = np.full(B, T, dtype=np.int32)
+
+    def run(v, algo):
+        if direction == "fwd":
+            return _hip.forward(m, v, STD3, algo=algo)
+        o, st = _hip.backward(v, go, STD3, 3 * sd, out_dtype=torch.float64, algo=algo)
+        return o.view(B, T, 3, sd), st
+
+    clean, st0 = run(v_ok, _hip.ALGO_STRIP)
+    assert int(st0.abs().max()) == 0
+    n0 = _hip.lib().mlpg_hip_launch_count(2)
+    for it in range(20):
+        v = v_ok.clone()
+        bs, ds = _scatter_failures(rng, v, B, T, sd, lengths, 60)
+        out, st = run(v, _hip.ALGO_STRIP)
+        again, st_again = run(v_ok, _hip.ALGO_STRIP)            # starts from the control words the failing launch left
+        ref, st_ref = run(v, _hip.ALGO_GENERIC) if it < 2 else (None, None)
+        st = st.view(B, sd)
+        failed = torch.zeros(B, sd, dtype=torch.bool, device="cuda")
+        failed[torch.from_numpy(bs).cuda(), torch.from_numpy(ds).cuda()] = True
+        assert torch.equal(st != 0, failed), it
+        assert int(st_again.abs().max()) == 0 and torch.equal(again, clean), it
+        bad = failed[:, None, :] if direction == "fwd" else failed[:, None, None, :]
+        assert not bool((out != 0)[bad.expand_as(out)].any()), it
+        if ref is not None:
+            assert torch.equal(st, st_ref.view(B, sd))
+            good = ~bad.expand_as(out)
+            assert float((out - ref)[good].abs().max()) <= 1e-9 * float(ref[good].abs().max())
+    assert _hip.lib().mlpg_hip_launch_count(2) == n0 + 40
+
+
+def test_strip_failures_settled_over_many_groups():
+    """The same with many system groups (4500 short utterances, a control area over 1 MB): failures scattered over them, then a
+    clean launch."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(78)
+    B, T, sd = 4500, 100, 8
+    g = torch.Generator(device="cuda").manual_seed(6)
+    m = torch.randn(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=g)
+    v_ok = torch.rand(B, T, 3 * sd, dtype=torch.float64, device="cuda", generator=g) + 0.1
+    lengths = np.full(B, T, dtype=np.int32)
+    clean, st0 = _hip.forward(m, v_ok, STD3, algo=_hip.ALGO_STRIP)
+    assert int(st0.abs().max()) == 0
+    v = v_ok.clone()
+    bs, ds = _scatter_failures(rng, v, B, T, sd, lengths, 80)
+    out, st = _hip.forward(m, v, STD3, algo=_hip.ALGO_STRIP)
+    again, st_again = _hip.forward(m, v_ok, STD3, algo=_hip.ALGO_STRIP)
+    ref, st_ref = _hip.forward(m, v, STD3, algo=_hip.ALGO_GENERIC)
+    assert torch.equal(st, st_ref) and int((st != 0).sum()) == len(set(zip(bs.tolist(), ds.tolist())))
+    assert int(st_again.abs().max()) == 0 and torch.equal(again, clean)
+    bad = (st.view(B, sd) != 0)[:, None, :].expand_as(out)
+    assert not bool((out != 0)[bad].any())
+    assert float((out - ref)[~bad].abs().max()) <= 1e-9 * float(ref[~bad].abs().max())
