@@ -1,7 +1,3 @@
-    """Failing pivots at the config-2 size: 4096 strips over 512 workgroups on all eight XCDs (whose L2s are not coherent with each
-    other), ~60 failures scattered over utterances, dims, windows and strips.  Status equal to the natural-order kernel's, failed
-    columns exactly zero (no strip's rows land on top of the zeros the verdict writes), the other columns untouched by it; twenty
-    launches in a row, a clean launch after each (it starts from the control words a launch with marks left behind)."""
 """GPU parity tests (-m gpu) of the strip MLPG kernel (algo = MLPG_HIP_ALGO_STRIP: lane per static dim,
 wavefront per 16-frame chunk, strips of one utterance solved across workgroups), through the C ABI,
 against the CPU oracle.  Same tolerances as tests/test_mlpg_gpu.py."""
@@ -523,12 +519,10 @@ def _scatter_failures(rng, v, B, T, sd, lengths, n):
 
 @pytest.mark.parametrize("direction", ["fwd", "bwd"])
 def test_strip_failures_settled_at_full_size(direction):
-    """Round 5: the launch's last workgroup -- not a second kernel -- turns the marks of failing pivots into the reference's status
-    and zero columns, and re-zeroes the control words.  At the config-2 size (4096 strips over 512 workgroups on all eight XCDs,
-    whose L2s are not coherent with each other) with ~60 failures scattered over utterances, dims, windows and strips: status
-    equal to the natural-order kernel's, failed columns exactly zero (no strip's rows land on top of the zeros), the other
-    columns untouched by it; twenty launches in a row, clean launches in between (the control words they start from were left by
-    a launch that had marks)."""
+    """Failing pivots at the config-2 size: 4096 strips over 512 workgroups on all eight XCDs (whose L2s are not coherent with each
+    other), ~60 failures scattered over utterances, dims, windows and strips.  Status equal to the natural-order kernel's, failed
+    columns exactly zero (no strip's rows land on top of the zeros the verdict writes), the other columns untouched by it; twenty
+    launches in a row, a clean launch after each (it starts from the control words a launch with marks left behind)."""
     import torch
     from nnmnkwii_amd import _hip
     STD3 = WINDOW_SETS["std3"]
