@@ -57,7 +57,9 @@ extern "C" {
 #define MLPG_HIP_ALGO_AUTO 0    /* strip kernel for wide streams, wave-per-system for narrow, else generic */
 #define MLPG_HIP_ALGO_GENERIC 1 /* thread-per-system, factor in HBM scratch       */
 #define MLPG_HIP_ALGO_WAVE 2    /* wave-per-system, factor in registers           */
-#define MLPG_HIP_ALGO_STRIP 3   /* lane-per-static-dim, wavefront per 16-frame chunk, any T */
+#define MLPG_HIP_ALGO_STRIP 3   /* lane-per-static-dim, wavefront per 16-frame chunk, any T.  A stream of 1 .. 32 static dims in a batch
+                                   without lengths (forward, per-frame variances, three windows): the lanes of a wavefront run over
+                                   64 / dims consecutive utterances x the dims instead (the transposed form, round 5) */
 #define MLPG_HIP_ALGO_PIPE 4    /* retired in ABI 11 (the software-pipelined strip kernel of round 3, now under
                                    tools/experimental/pipe): selects the strip kernel */
 #define MLPG_HIP_ALGO_CONST 5   /* global (D,) / unit variances: the matrix of a static dim is the same for every
@@ -75,7 +77,8 @@ int mlpg_hip_abi_version(void);
 const char *mlpg_hip_last_error(void);
 /* Test aid, not part of the reference's interface: launches per MLPG kernel family since the library was loaded --
  * 0 natural-order, 1 wave-per-system, 2 strip, 3 strip with several streams merged, 4 constant-coefficient, 5 fused, 6 chunked, 7 FIR,
- * 8 constant-coefficient with several streams merged; -1 for any other `kind`.  (Tests use it to assert WHICH kernel a call took.) */
+ * 8 constant-coefficient with several streams merged, 9 strip in its transposed form (narrow streams: the lanes over several
+ * utterances); -1 for any other `kind`.  (Tests use it to assert WHICH kernel a call took.) */
 long long mlpg_hip_launch_count(int kind);
 int mlpg_hip_device_count(void);
 /* Frees the per-device scratch caches. */
@@ -230,7 +233,9 @@ void mlpg_hip_host_free(void *p);
  * of the strip kernel; global (ld_in,) or unit variances (round 5): of the
  * constant-coefficient kernel -- their static dims side by side on the lanes; a
  * stream may be cut to fill the last 64-lane group, its remaining dims then run
- * as a launch of their own; every other stream is one launch.  Launches other than the widest go
+ * as a launch of their own; every other stream is one launch.  Without `lengths`, a
+ * narrow stream (or such a remainder) with per-frame variances takes the strip kernel's
+ * transposed form (see MLPG_HIP_ALGO_STRIP) behind the merged launch on `stream`.  Launches other than the widest go
  * to internal streams forked from and joined back into `stream` with events
  * (no host synchronisation; capturable): when the call returns, everything is
  * ordered on `stream`.  Which kernel solves a dim depends on the grouping, the

@@ -215,6 +215,13 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     // retired (tools/experimental/pipe): the strip scheme it pipelined, or the kernel AUTO would take
     algo = strip_supported(p, ws) ? MLPG_HIP_ALGO_STRIP : MLPG_HIP_ALGO_AUTO;
   }
+  // a narrow stream (or the piece a merged launch left over) of a batch without lengths: the strip kernel with its lanes over
+  // several utterances; a launch the grid cannot hold falls through to the other kernels
+  if ((algo == MLPG_HIP_ALGO_AUTO && strip_tr_preferred(p, ws, backward, in_dtype, out_dtype)) ||
+      (algo == MLPG_HIP_ALGO_STRIP && p.pitch && p.pitch != p.sd && strip_tr_supported(p, ws, backward, in_dtype, out_dtype))) {
+    const int rc = launch_strip_tr(st, in_dtype, p, ws, device);
+    if (rc != kStripMultiNotResident) return rc;
+  }
   if (p.pitch && p.pitch != p.sd) {
     // a piece of a stream (window pitch != number of dims): the kernels that take the pitch separately
     if (backward) {
@@ -290,28 +297,24 @@ int solve_entry(int device, void *stream, int in_dtype, int out_dtype, int algo,
 
 // One stream of a multi-stream batch: a column slice [in_col, in_col + nw*sd) of the (B, Tmax, ld_in)
 // parameter matrices, trajectory written to columns [out_col, out_col + sd) of the (B, Tmax, ld_out) output.
-int stream_entry(int device, hipStream_t st, int dtype, int algo, const void *mean, const void *var, int var_mode,
-                 long ld_in, const int32_t *lengths, int B, int Tmax, const mlpg_hip_stream_t &sm, const int32_t *wl,
-                 const int32_t *wu, const double *wc, void *out, long ld_out, int32_t *status, int ld_status,
-                 int status_col, int d_first = 0, int d_count = -1) {
-  // [d_first, d_first + d_count): the stream's static dims this call solves (all of them by default)
+// [d_first, d_first + d_count): the stream's static dims the problem holds (all of them by default).
+int stream_problem(int dtype, const void *mean, const void *var, int var_mode, long ld_in, const int32_t *lengths, int B, int Tmax,
+                   const mlpg_hip_stream_t &sm, const int32_t *wl, const int32_t *wu, const double *wc, void *out, long ld_out,
+                   int32_t *status, int ld_status, int status_col, int d_first, int d_count, Problem *pp, WinSet *ws) {
   const size_t esz = dtype == MLPG_HIP_F32 ? 4 : 8;
   const int nw = sm.num_windows;
   const int sd = d_count < 0 ? sm.static_dim : d_count;
-  const char *mean_s = (const char *)mean + esz * (size_t)(sm.in_col + d_first);
-  char *out_s = (char *)out + esz * (size_t)(sm.out_col + d_first);
   status_col += d_first;
-  if (nw == 0) return launch_copy_cols(st, dtype, mean_s, ld_in, lengths, B, Tmax, sd, out_s, ld_out);
   size_t coff = 0;
   for (int w = 0; w < sm.win_first; ++w) coff += (size_t)(wl[w] + wu[w] + 1);
-  WinSet ws;
-  if (int rc = pack_windows(nw, wl + sm.win_first, wu + sm.win_first, wc + coff, &ws)) return rc;
-  Problem p;
-  p.mean = mean_s;
+  if (nw > 0)
+    if (int rc = pack_windows(nw, wl + sm.win_first, wu + sm.win_first, wc + coff, ws)) return rc;
+  Problem &p = *pp;
+  p.mean = (const char *)mean + esz * (size_t)(sm.in_col + d_first);
   p.var = var ? (const char *)var + esz * (size_t)(sm.in_col + d_first) : nullptr;
   p.grad_out = nullptr;
   p.lengths = lengths;
-  p.out = out_s;
+  p.out = (char *)out + esz * (size_t)(sm.out_col + d_first);
   p.status = status ? status + status_col : nullptr;
   p.var_mode = var_mode;
   p.B = B;
@@ -323,10 +326,39 @@ int stream_entry(int device, hipStream_t st, int dtype, int algo, const void *me
   p.ld_gout = 0;
   p.ld_out = ld_out;
   p.ld_status = ld_status;
+  return 0;
+}
+
+int stream_entry(int device, hipStream_t st, int dtype, int algo, const void *mean, const void *var, int var_mode,
+                 long ld_in, const int32_t *lengths, int B, int Tmax, const mlpg_hip_stream_t &sm, const int32_t *wl,
+                 const int32_t *wu, const double *wc, void *out, long ld_out, int32_t *status, int ld_status,
+                 int status_col, int d_first = 0, int d_count = -1) {
+  Problem p;
+  WinSet ws;
+  if (int rc = stream_problem(dtype, mean, var, var_mode, ld_in, lengths, B, Tmax, sm, wl, wu, wc, out, ld_out, status, ld_status,
+                              status_col, d_first, d_count, &p, &ws))
+    return rc;
+  if (sm.num_windows == 0) return launch_copy_cols(st, dtype, p.mean, ld_in, lengths, B, Tmax, p.sd, p.out, ld_out);
   // a piece of a stream (what a merged launch left over) goes to the kernels that take the window pitch separately, whatever
   // kernel was asked for the call as a whole
   if (p.pitch && (algo == MLPG_HIP_ALGO_CONST || algo == MLPG_HIP_ALGO_CHUNK || algo == MLPG_HIP_ALGO_FIR)) algo = MLPG_HIP_ALGO_AUTO;
   return dispatch_solve(st, dtype, dtype, algo, false, p, ws, device);
+}
+
+// Will stream_entry hand this stream (or piece) to the transposed strip form?  Such a launch is a persistent grid like the merged
+// launch's: mlpg_hip_forward_streams queues it on the caller's stream behind that one instead of beside it on a side stream (two
+// persistent grids that share the device each hold fewer workgroups than their work lists were dealt for).
+bool stream_takes_tr(int dtype, int algo, const void *mean, const void *var, int var_mode, long ld_in, const int32_t *lengths, int B,
+                     int Tmax, const mlpg_hip_stream_t &sm, const int32_t *wl, const int32_t *wu, const double *wc, void *out,
+                     long ld_out, int d_first = 0, int d_count = -1) {
+  if (sm.num_windows != 3) return false;
+  Problem p;
+  WinSet ws;
+  if (stream_problem(dtype, mean, var, var_mode, ld_in, lengths, B, Tmax, sm, wl, wu, wc, out, ld_out, nullptr, 1, 0, d_first, d_count, &p, &ws))
+    return false;
+  if (p.pitch && (algo == MLPG_HIP_ALGO_CONST || algo == MLPG_HIP_ALGO_CHUNK || algo == MLPG_HIP_ALGO_FIR)) algo = MLPG_HIP_ALGO_AUTO;
+  return algo == MLPG_HIP_ALGO_AUTO ? strip_tr_preferred(p, ws, false, dtype, dtype)
+                                    : algo == MLPG_HIP_ALGO_STRIP && strip_tr_supported(p, ws, false, dtype, dtype);
 }
 
 }  // namespace
@@ -586,8 +618,18 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
   int nside = 0;
   // The fork is recorded BEFORE anything of this call is queued on the caller's stream and the widest stream is
   // launched last: the narrow streams' kernels then only wait for what preceded the call, not for the wide kernel.
+  // streams (and the piece) that take the transposed strip form: on the caller's stream, behind the merged launch / in front of the
+  // widest stream (see stream_takes_tr)
+  bool tr_flag[64] = {};
+  for (int k = 0; k < num_streams; ++k) {
+    const mlpg_hip_stream_t &sm = streams_h[k];
+    if (sm.static_dim <= 0 || merged_flag[k]) continue;
+    const bool piece = k == piece_stream;
+    tr_flag[k] = stream_takes_tr(dtype, algo, mean, var, var_mode, (long)ld_in, lengths, B, Tmax, sm, win_l_h, win_u_h, win_coef_h, out,
+                                 (long)ld_out, piece ? piece_first : 0, piece ? sm.static_dim - piece_first : -1);
+  }
   int n_narrow = 0;
-  for (int k = 0; k < num_streams; ++k) n_narrow += streams_h[k].static_dim > 0 && k != widest && !merged_flag[k];
+  for (int k = 0; k < num_streams; ++k) n_narrow += streams_h[k].static_dim > 0 && k != widest && !merged_flag[k] && !tr_flag[k];
   if (side && n_narrow > 0) MLPG_HIP_CHECK(hipEventRecord(side->fork, main_st));
   auto join_side = [&]() -> int {  // also on the error paths: an unjoined side stream would break a graph capture
     for (int q = 0; q < nside; ++q) {
@@ -612,7 +654,7 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
     return 0;
   };
   for (int k = 0; k < num_streams; ++k) {
-    if (streams_h[k].static_dim <= 0 || k == widest || merged_flag[k]) continue;
+    if (streams_h[k].static_dim <= 0 || k == widest || merged_flag[k] || tr_flag[k]) continue;
     hipStream_t st = main_st;
     if (side && nside < SideStreams::kN) {
       st = side->st[nside];
@@ -646,6 +688,12 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
       return rc;
     }
   }
+  for (int k = 0; k < num_streams; ++k)
+    if (tr_flag[k] && k != widest)
+      if (int rc = run_stream(k, main_st)) {
+        (void)join_side();
+        return rc;
+      }
   if (widest >= 0)
     if (int rc = run_stream(widest, main_st)) {
       (void)join_side();

@@ -54,6 +54,12 @@ struct Problem {
 struct StreamMap {
   int n, total;
   int begin[4], in_col[4], sd[4], out_col[4], stat_col[4];
+  // Transposed form (tr_u > 0; strip kernel, round 5): ONE narrow stream whose lanes run over tr_u consecutive UTTERANCES x its
+  // tr_nd static dims (lane = u * tr_nd + d; total = tr_u * tr_nd <= 64), so that a stream of 1 .. 32 dims fills the 64 lanes
+  // it would otherwise leave idle.  A system group is then a block of tr_u utterances (tr_B utterances in all: the last block may
+  // be short); sd[0] is the window pitch, in_col[0] / out_col[0] / stat_col[0] the stream's columns, and tr_in / tr_out / tr_stat
+  // the element strides from one utterance to the next in the input, output and status arrays.  No lengths (one T for all lanes).
+  int tr_u, tr_nd, tr_B, tr_in, tr_out, tr_stat;
 };
 
 // The strip, constant-coefficient and chunked kernels address an utterance's rows through a buffer descriptor with 32-bit byte
@@ -65,7 +71,7 @@ inline bool rows_fit_buffer(const Problem &p) {
 
 void set_error(const char *fmt, ...);
 // launches per kernel family since the library was loaded (mlpg_hip_launch_count: a test aid)
-enum { kCountGeneric = 0, kCountWave, kCountStrip, kCountStripMulti, kCountConst, kCountFused, kCountChunk, kCountFir, kCountConstMulti, kCountKinds };
+enum { kCountGeneric = 0, kCountWave, kCountStrip, kCountStripMulti, kCountConst, kCountFused, kCountChunk, kCountFir, kCountConstMulti, kCountStripTr, kCountKinds };
 void note_launch(int kind);
 // Grow-only scratch, cached per (device, stream, slot): slot 0 generic factor, 1 fastdtw pyramids,
 // 2 generic status, 3 strip records, 4 constant-coefficient kernel (factor table), 5 fastdtw from host costs (D rows, back-pointers), 6 chunked kernel (records, block factors, separator solutions, marks).  Returns nullptr (and sets the error) on failure.
@@ -79,6 +85,9 @@ int launch_wave(hipStream_t s, int dtype, int out_dtype, bool backward, const Pr
                 int device);
 bool strip_supported(const Problem &p, const WinSet &w);
 bool strip_preferred(const Problem &p, const WinSet &w, bool backward, int in_dtype);
+bool strip_tr_supported(const Problem &p, const WinSet &w, bool backward, int in_dtype, int out_dtype);
+bool strip_tr_preferred(const Problem &p, const WinSet &w, bool backward, int in_dtype, int out_dtype);
+int launch_strip_tr(hipStream_t s, int dtype, const Problem &p, const WinSet &w, int device);
 int launch_strip(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
                  int device);
 // launch_strip_multi's "nothing was enqueued" result: fewer workgroups can be resident than an utterance has strips

@@ -3,6 +3,9 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <limits.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace mlpg {
@@ -13,6 +16,8 @@ int launch_strip_bwd_f64(hipStream_t st, int out_dtype, const Problem &p, const 
 int launch_strip_bwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl);
 int launch_strip_multi_f64(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl, const StreamMap &sm);
 int launch_strip_multi_f32(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl, const StreamMap &sm);
+int launch_strip_tr_f64(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch, int R, bool zero_ctrl, const StreamMap &sm);
+int launch_strip_tr_f32(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch, int R, bool zero_ctrl, const StreamMap &sm);
 
 namespace {
 #ifndef MLPG_STRIP_W
@@ -58,6 +63,34 @@ bool strip_preferred(const Problem &p, const WinSet &ws, bool backward, int in_d
   (void)backward;
   (void)in_dtype;
   return nitems >= 512;
+}
+
+// Transposed form (round 5): a NARROW stream -- 1 .. 32 static dims: lf0, bap, vuv of a Merlin-style row, or the piece a merged launch
+// left over -- leaves most of the strip kernel's 64 lanes idle, and the wave-per-system kernel that took such streams walks each
+// (utterance, dim) system with one wavefront (512 x 2000 frames of lf0: 0.08 ms for 57 MB).  Here the lanes of a group run over
+// 64 / sd consecutive UTTERANCES x the stream's dims (StreamMap::tr_u): same kernel, same records, only the lane's columns carry the
+// utterance's offset.  All lanes of a wavefront then share one T: batches without a lengths vector only; forward, per-frame
+// variances, three windows of extent <= 1 (what the MULTI instantiation is compiled for); every offset inside the 2 GB window of the
+// group's first utterance.
+bool strip_tr_supported(const Problem &p, const WinSet &ws, bool backward, int in_dtype, int out_dtype) {
+  if (backward || in_dtype != out_dtype || p.lengths || p.var_mode != MLPG_HIP_VAR_FRAME || ws.nw != 3) return false;
+  if (p.sd < 1 || p.sd > 32 || p.B < 2 || !strip_supported(p, ws)) return false;
+  const int u = 64 / p.sd;
+  const long ld = p.ld_in > p.ld_out ? p.ld_in : p.ld_out;
+  return (double)u * (double)p.Tmax * (double)ld * 8.0 < 2147483647.0;
+}
+// AUTO takes it where it beat the wave-per-system kernel (tools/dbg/narrow_time.py, profiles/r05_tr_narrow.txt): full lane groups,
+// and enough (group, strip) items that the persistent grid's fixed costs -- about 30 us: one launch, one round of items, the verdict
+// launch -- are paid back: 256 items in float64, 512 in float32 (the wave kernel moves half the bytes there); beyond 1024 frames
+// the wave kernel needs 32 frames per lane and 64 items suffice (512 x 2000 x 5 dims: 0.087 against 0.188 ms; 512 x 2000 x 1:
+// 0.059 against 0.074; 256 x 1000 x 25: 0.108 against 0.152; but 256 x 1000 x 1, 64 items: 0.030 against 0.020).
+bool strip_tr_preferred(const Problem &p, const WinSet &ws, bool backward, int in_dtype, int out_dtype) {
+  if (!strip_tr_supported(p, ws, backward, in_dtype, out_dtype)) return false;
+  const int u = 64 / p.sd;
+  const long items = (long)((p.B + u - 1) / u) * ((p.Tmax + kStripFrames - 1) / kStripFrames);
+  if (p.B < u) return false;
+  if (p.Tmax > 1024) return items >= 64;
+  return items >= (in_dtype == MLPG_HIP_F32 ? 512 : 256);
 }
 
 namespace {
@@ -136,8 +169,37 @@ bool strip_xcd_lists_ok(hipStream_t st) {
   return ok;
 }
 
+int launch_strip_tr(hipStream_t st, int dtype, const Problem &p, const WinSet &ws, int device) {
+  const int R = (p.Tmax + kStripFrames - 1) / kStripFrames;
+  StreamMap sm;
+  memset(&sm, 0, sizeof(sm));
+  for (int q = 0; q < 4; ++q) sm.begin[q] = INT_MAX;
+  sm.n = 1;
+  sm.begin[0] = 0;
+  sm.sd[0] = p.pitch ? p.pitch : p.sd;  // the window pitch (a piece of a stream: the whole stream's static dim)
+  sm.tr_nd = p.sd;
+  sm.tr_u = 64 / p.sd;
+  sm.total = sm.tr_u * sm.tr_nd;
+  sm.tr_B = p.B;
+  sm.tr_in = (int)((long)p.Tmax * p.ld_in);
+  sm.tr_out = (int)((long)p.Tmax * p.ld_out);
+  sm.tr_stat = p.ld_status;
+  const size_t nsg = (size_t)(p.B + sm.tr_u - 1) / sm.tr_u;
+  bool zero_ctrl = true;
+  void *sc = strip_scratch(st, device, nsg, R, &zero_ctrl);
+  if (!sc) return MLPG_HIP_ENOMEM;
+  const int rc = dtype == MLPG_HIP_F32 ? launch_strip_tr_f32(st, p, ws, sc, R, zero_ctrl, sm) : launch_strip_tr_f64(st, p, ws, sc, R, zero_ctrl, sm);
+  if (rc == kStripNotResident) strip_scratch_forget(st, device);
+  return rc;
+}
+
 int launch_strip(hipStream_t st, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &ws,
                  int device) {
+  // a narrow stream asked for by name: the transposed form where it applies (the plain form would run 64 / sd times the items)
+  if (strip_tr_supported(p, ws, backward, dtype, out_dtype)) {
+    const int rc = launch_strip_tr(st, dtype, p, ws, device);
+    if (rc != kStripNotResident) return rc;
+  }
   const int R = (p.Tmax + kStripFrames - 1) / kStripFrames;
   const int ndg = (p.sd + 63) / 64;
   const int dgw = (p.sd + ndg - 1) / ndg;

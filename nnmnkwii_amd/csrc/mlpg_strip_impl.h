@@ -238,6 +238,11 @@ __device__ __forceinline__ void ticket_item(const Args &a, int tk, int lst, int 
 // MULTI kernels: the stream a merged static-dim index belongs to (at most 4 streams, begin[] ascending, unused
 // entries = INT_MAX) and the dim's columns there
 struct LaneStream { int sd, din, dstat, dout; };
+// transposed form (StreamMap::tr_u): merged index d = u * tr_nd + dim of utterance b0 + u; the columns carry the utterance's offset
+__device__ __forceinline__ LaneStream lane_stream_tr(const StreamMap &sm, int d) {
+  const int u = d / sm.tr_nd, dl = d - u * sm.tr_nd;
+  return {sm.sd[0], u * sm.tr_in + sm.in_col[0] + dl, u * sm.tr_stat + sm.stat_col[0] + dl, u * sm.tr_out + sm.out_col[0] + dl};
+}
 __device__ __forceinline__ LaneStream lane_stream(const StreamMap &sm, int d) {
   const int s_ = (d >= sm.begin[1]) + (d >= sm.begin[2]) + (d >= sm.begin[3]);
   auto pick = [&](const int (&v)[4]) { return s_ == 0 ? v[0] : s_ == 1 ? v[1] : s_ == 2 ? v[2] : v[3]; };
@@ -872,8 +877,10 @@ __device__ __forceinline__ void backsub(const double (&Pd)[kM], const double (&P
 // assemble_eliminate and the backward epilogue the frame-major one, and nothing of the window-major forms for other window
 // counts is compiled into the kernel (round 5: those forms alone cost the backward instances ~280 spilled scalar
 // registers and 20 k instructions of code); NW3 = false serves one, two or more than three windows.
-template <typename TIN, typename TOUT, bool BWD, int VM, bool MULTI = false, bool NW3 = true>
+// TR (MULTI kernels): the lanes of a group run over several utterances of one narrow stream (StreamMap::tr_u).
+template <typename TIN, typename TOUT, bool BWD, int VM, bool MULTI = false, bool NW3 = true, bool TR = false>
 __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem p, WinSet ws, Args a) {
+  static_assert(!TR || MULTI, "the transposed form is a MULTI kernel");
   extern __shared__ __align__(16) unsigned char smem[];
   double *lds_rec = (double *)smem;                                  // [kW][kRec][64]   (level 1 -> 2)
   double *lds_stage = (double *)smem;                                // [kStage][kRec][64] (level 3), same bytes
@@ -899,22 +906,24 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;  // hwreg(HW_REG_XCC_ID, 0, 4)
   const int R = a.R;
   auto body = [&](const int g, const int r) __attribute__((always_inline)) {
-  const int b = g / a.ndg, dg = g - b * a.ndg;
+  // (TR: group g = the block of utterances b .. b + tr_u - 1, one dim group)
+  const int b = TR ? g * a.sm.tr_u : g / a.ndg, dg = TR ? 0 : g - b * a.ndg;
   const int Tmax = p.Tmax;
   const long ldi = p.ld_in, ldg = p.ld_gout, ldo = p.ld_out;
-  int T = p.lengths ? p.lengths[b] : Tmax;
+  int T = (p.lengths && !TR) ? p.lengths[b] : Tmax;
   T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
   const int Ract = (T + kW * kM - 1) / (kW * kM);  // strips of this utterance that hold live frames
   const bool xwg = MLPG_STRIP_ABLATE ? false : Ract > 1;  // the utterance spans several strips: level 3 runs
   const int d0 = dg * a.dgw;
   const int sd_all = MULTI ? a.sm.total : p.sd;  // MULTI: the lanes run over the static dims of all streams
-  const int nd = sd_all - d0 < a.dgw ? sd_all - d0 : a.dgw;
+  const int nd = TR ? (a.sm.tr_B - b < a.sm.tr_u ? a.sm.tr_B - b : a.sm.tr_u) * a.sm.tr_nd
+                    : (sd_all - d0 < a.dgw ? sd_all - d0 : a.dgw);
   const bool lane_ok = lane < nd;
   int d = d0 + (lane_ok ? lane : nd - 1);  // idle lanes shadow the group's last dim (never stored)
   // sd: the pitch between a dim's windows in a row; d: its output (and status) column; din: its window-0 input column
   int sd = p.sd, din = d, dstat = d;
   if (MULTI) {
-    const LaneStream ls = lane_stream(a.sm, d);
+    const LaneStream ls = TR ? lane_stream_tr(a.sm, d) : lane_stream(a.sm, d);
     sd = ls.sd;
     din = ls.din;
     dstat = ls.dstat;
@@ -1751,7 +1760,7 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
 // reference's verdict: status = natural-order first failing pivot (-2 if that scan finds none: the blocked
 // elimination broke down on a numerically singular system; -1 after a time-out) and an all-zero output column,
 // exactly what the other kernels deliver.  It also re-zeroes the control words for the next launch.
-template <typename TIN, typename TOUT, bool BWD, bool MULTI = false>
+template <typename TIN, typename TOUT, bool BWD, bool MULTI = false, bool TR = false>
 __global__ void __launch_bounds__(256) verdict_kernel(const Problem p, const WinSet ws, const Args a) {
   const int lane = threadIdx.x & 63;
   const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1766,19 +1775,20 @@ __global__ void __launch_bounds__(256) verdict_kernel(const Problem p, const Win
   if (g == 0)
     for (int i = lane; i < (1 + kMaxLists) * kCtrlLine; i += 64) a.ctrl[i] = 0;
   if (m == 0ull) return;
-  const int b = g / a.ndg, dg = g - b * a.ndg;
+  const int b = TR ? g * a.sm.tr_u : g / a.ndg, dg = TR ? 0 : g - b * a.ndg;
   const int d0 = dg * a.dgw;
   const int sd_all = MULTI ? a.sm.total : p.sd;
-  const int nd = sd_all - d0 < a.dgw ? sd_all - d0 : a.dgw;
+  const int nd = TR ? (a.sm.tr_B - b < a.sm.tr_u ? a.sm.tr_B - b : a.sm.tr_u) * a.sm.tr_nd
+                    : (sd_all - d0 < a.dgw ? sd_all - d0 : a.dgw);
   if (lane >= nd || !((m >> lane) & 1ull)) return;
   int d = d0 + lane, dstat = d;
   const int Tmax = p.Tmax;
-  int T = p.lengths ? p.lengths[b] : Tmax;
+  int T = (p.lengths && !TR) ? p.lengths[b] : Tmax;
   T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
   int status = -1;
   if (MULTI) {
     // the dim's own stream as a problem of its own: column slices of the parent arrays
-    const LaneStream ls = lane_stream(a.sm, d);
+    const LaneStream ls = TR ? lane_stream_tr(a.sm, d) : lane_stream(a.sm, d);
     Problem q = p;
     q.sd = ls.sd;
     q.D = ws.nw * ls.sd;
@@ -1839,13 +1849,13 @@ inline int resident_grid(const void *kern, int threads, size_t lds, int *out) {
   return 0;
 }
 
-template <typename TIN, typename TOUT, bool BWD, bool MULTI>
+template <typename TIN, typename TOUT, bool BWD, bool MULTI, bool TR = false>
 int launch_impl(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, int ndg, int dgw,
                 bool zero_ctrl, const StreamMap *smap) {
   Args a;
   memset(&a.sm, 0, sizeof(a.sm));
   if (MULTI) a.sm = *smap;
-  const int nsg = p.B * ndg;
+  const int nsg = TR ? (p.B + smap->tr_u - 1) / smap->tr_u : p.B * ndg;  // (TR: blocks of utterances, one dim group)
   a.ctrl = (int *)scratch_base;
   a.rec = (double *)((char *)scratch_base + ctrl_bytes(nsg, R));
   a.R = R;
@@ -1889,16 +1899,16 @@ int launch_impl(hipStream_t st, const Problem &p, const WinSet &ws, void *scratc
     if (nitems > resident && R > resident / 2) return kNotResident;
     if (zero_ctrl) MLPG_HIP_CHECK(hipMemsetAsync(a.ctrl, 0, ctrl_ints(nsg, R) * sizeof(int), st));
     const long grid = nitems < resident ? nitems : resident;
-    note_launch(MULTI ? kCountStripMulti : kCountStrip);
+    note_launch(TR ? kCountStripTr : MULTI ? kCountStripMulti : kCountStrip);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kW * 64), kLdsBytes, st, p, ws, a);
     MLPG_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL((verdict_kernel<TIN, TOUT, BWD, MULTI>), dim3((unsigned)((nsg + 3) / 4)), dim3(256), 0, st, p, ws, a);
+    hipLaunchKernelGGL((verdict_kernel<TIN, TOUT, BWD, MULTI, TR>), dim3((unsigned)((nsg + 3) / 4)), dim3(256), 0, st, p, ws, a);
     MLPG_HIP_CHECK(hipGetLastError());
     return 0;
   };
   if constexpr (MULTI) {
     // several streams side by side on the lanes: forward, per-frame variances, three windows (the caller checked)
-    return go(strip_kernel<TIN, TOUT, false, MLPG_HIP_VAR_FRAME, true, true>);
+    return go(strip_kernel<TIN, TOUT, false, MLPG_HIP_VAR_FRAME, true, true, TR>);
   } else {
     if (ws.nw == 3) {
       switch (p.var_mode) {
@@ -1924,6 +1934,10 @@ template <typename TIN, typename TOUT>
 int launch_multi_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, int ndg, int dgw,
                    bool zero_ctrl, const StreamMap &smap) {
   return launch_impl<TIN, TOUT, false, true>(st, p, ws, scratch_base, R, ndg, dgw, zero_ctrl, &smap);
+}
+template <typename TIN, typename TOUT>
+int launch_tr_t(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, bool zero_ctrl, const StreamMap &smap) {
+  return launch_impl<TIN, TOUT, false, true, true>(st, p, ws, scratch_base, R, 1, 64, zero_ctrl, &smap);
 }
 
 }  // namespace strip

@@ -4,4 +4,8 @@ namespace mlpg {
 int launch_strip_multi_f32(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl, const StreamMap &sm) {
   return strip::launch_multi_t<float, float>(st, p, ws, scratch, R, ndg, dgw, zero_ctrl, sm);
 }
+// ... and the transposed form: one narrow stream, the lanes over several utterances (StreamMap::tr_u)
+int launch_strip_tr_f32(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch, int R, bool zero_ctrl, const StreamMap &sm) {
+  return strip::launch_tr_t<float, float>(st, p, ws, scratch, R, zero_ctrl, sm);
+}
 }  // namespace mlpg

@@ -1,4 +1,4 @@
-"""MLPG_HIP_ALGO_AUTO's routing as a tested table: profiles/r05_auto_routing.json holds, for 25
+"""MLPG_HIP_ALGO_AUTO's routing as a tested table: profiles/r05_auto_routing.json holds, for 29
 representative launches, the kernel family AUTO picked on the MI355X (read off the library's launch counters by
 tools/auto_routing.py) and the time of every kernel that accepts the launch.  The GPU test re-derives the routes with the
 library as built; the CPU test checks that the recorded choice is the fastest recorded kernel, or within 6 % of it."""
@@ -23,9 +23,11 @@ def test_recorded_auto_choice_is_the_fastest_recorded_kernel_or_close():
     for r in rows:
         ms = r["ms"]
         kinds = r["auto"].split("+")
-        assert len(kinds) == 1 and kinds[0] in ms, r
+        # (the transposed strip form has no algorithm number of its own: MLPG_HIP_ALGO_STRIP takes it for narrow streams)
+        key = "strip" if kinds[0] == "strip_tr" else kinds[0]
+        assert len(kinds) == 1 and key in ms, r
         best = min(ms.values())
-        assert ms[kinds[0]] <= 1.06 * best + 0.002, (r["case"], r["direction"], r["auto"], ms)
+        assert ms[key] <= 1.06 * best + 0.002, (r["case"], r["direction"], r["auto"], ms)
 
 
 @pytest.mark.gpu

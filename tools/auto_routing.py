@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-KINDS = ["generic", "wave", "strip", "strip_multi", "const", "fused", "chunk", "fir", "const_multi"]   # csrc/common.h kCount*
+KINDS = ["generic", "wave", "strip", "strip_multi", "const", "fused", "chunk", "fir", "const_multi", "strip_tr"]   # csrc/common.h kCount*
 ALGOS = {"generic": 1, "wave": 2, "strip": 3, "const": 5, "chunk": 6, "fir": 7}          # include/mlpg_hip.h MLPG_HIP_ALGO_*
 
 # (name, B, T, sd, dtype, variance mode, window set, direction)
@@ -48,6 +48,10 @@ CASES = [
     ("5-tap windows f64", 256, 1000, 60, "f64", "frame", "wide3", "fwd"),
     ("5-tap windows f64", 256, 1000, 60, "f64", "frame", "wide3", "bwd"),
     ("config 1 (T=100, 2 dims) f64", 1, 100, 2, "f64", "frame", "std3", "fwd"),
+    ("lf0 of a config-2 batch f64", 256, 1000, 1, "f64", "frame", "std3", "fwd"),
+    ("bap (5 dims) of a config-2 batch f32", 256, 1000, 5, "f32", "frame", "std3", "fwd"),
+    ("16 dims f64", 256, 1000, 16, "f64", "frame", "std3", "fwd"),
+    ("lf0, short utterances f64", 512, 200, 1, "f64", "frame", "std3", "fwd"),
 ]
 
 
