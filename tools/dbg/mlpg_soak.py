@@ -20,15 +20,18 @@ STD3 = WINDOW_SETS["std3"]
 def soak(budget=40.0, seed=4711):
     rng = np.random.RandomState(seed)
     t0 = time.time()
-    n_streams = n_fused = 0
+    n_streams = n_fused = n_nolen = 0
+    tr0 = int(_hip.lib().mlpg_hip_launch_count(9))
     bad = None
     while time.time() - t0 < budget and bad is None:
         dt = [np.float64, np.float32][rng.randint(2)]
         tol = 1e-9 if dt == np.float64 else 3e-6
         if rng.rand() < 0.6:
             # ---- multi-stream ----
-            B = int(rng.randint(1, 9))
+            B = int(rng.randint(1, 9)) if rng.rand() < 0.6 else int(rng.randint(9, 140))   # (enough utterances for the transposed form's lane groups)
             T = int(rng.choice([40, 300, 700, 1100, 1500, 2100]))
+            if B > 40:
+                T = min(T, 1100)
             k = int(rng.randint(2, 6))
             sds = [int(rng.choice([1, 2, 3, 5, 7, 20, 40, 60, 64, 66])) for _ in range(k)]
             passthru = [rng.rand() < 0.2 for _ in range(k)]
@@ -42,9 +45,13 @@ def soak(budget=40.0, seed=4711):
             v = (rng.rand(B, T, D) + 0.1).astype(dt)
             lengths = rng.randint(1, T + 1, size=B).astype(np.int32)
             lengths[rng.randint(B)] = T
+            no_lengths = rng.rand() < 0.4     # batches without a lengths vector: narrow streams and pieces take the strip kernel's transposed form
+            if no_lengths:
+                lengths[:] = T
             for b in range(B):
                 m[b, lengths[b]:] = 0
-            md, vd, Ld = torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(lengths).cuda()
+            md, vd, Ld = torch.from_numpy(m).cuda(), torch.from_numpy(v).cuda(), (None if no_lengths else torch.from_numpy(lengths).cuda())
+            n_nolen += int(no_lengths)
             streams = [(cols[i], sds[i], None if passthru[i] else STD3) for i in range(k)]
             # variance mode: per frame (merged strip launch), global (D,) or unit (round 5: merged constant-coefficient launch)
             vmode = ["frame", "global", "unit"][rng.randint(3)]
@@ -91,9 +98,9 @@ def soak(budget=40.0, seed=4711):
             if not (e1 <= tol and e2 <= tol * max(1e-6, float(gr.abs().max())) + 1e-30 and abs(float(loss) - lr) <= 10 * tol * max(lr, 1e-30)):
                 bad = ("fused", dt.__name__, B, T, sd, lengths is not None, e1, e2, float(loss), lr)
             n_fused += 1
-    return n_streams, n_fused, bad
+    return n_streams, n_fused, bad, n_nolen, int(_hip.lib().mlpg_hip_launch_count(9)) - tr0
 
 
 if __name__ == "__main__":
-    r = soak(float(sys.argv[1]) if len(sys.argv) > 1 else 40.0)
-    print("multi-stream cases", r[0], "fused cases", r[1], "mismatch", r[2])
+    r = soak(float(sys.argv[1]) if len(sys.argv) > 1 else 40.0, int(sys.argv[2]) if len(sys.argv) > 2 else 4711)
+    print("multi-stream cases", r[0], "(%d without lengths; %d launches of the transposed strip form)" % (r[3], r[4]), "fused cases", r[1], "mismatch", r[2])

@@ -19,6 +19,7 @@ def main(seconds=60.0, seed=0):
     t0 = time.time()
     n = 0
     nneg = nfail = 0
+    tr0 = int(_hip.lib().mlpg_hip_launch_count(9))
     worst = 0.0
     while time.time() - t0 < seconds:
         B = int(rng.randint(1, 48))
@@ -35,6 +36,8 @@ def main(seconds=60.0, seed=0):
         v = None if mode == 2 else ((torch.rand(3 * sd, dtype=dt, device="cuda") + 0.1) * scale if mode == 1
                                    else (torch.rand(B, T, 3 * sd, dtype=dt, device="cuda") + 0.1) * scale)
         L = torch.from_numpy(rng.randint(0 if rng.rand() < 0.1 else 1, T + 1, size=B).astype(np.int32)).cuda()
+        if rng.rand() < 0.25:
+            L = None      # no lengths vector: forward launches of <= 32 dims with per-frame variances take the transposed form
         if mode == 0 and rng.rand() < 0.15:
             # failing pivots: a few negative variances anywhere (padding included: not a failure there); status and zero columns
             # against the natural-order kernel, the other systems as usual
@@ -76,7 +79,8 @@ def main(seconds=60.0, seed=0):
         worst = max(worst, err if tight >= 0.3 and dt == torch.float64 else 0.0)
         n += 1
     print("soak: %d launches pairs in %.0f s (%d of them with negative variances: %d failing systems, status and zero columns equal to the "
-          "natural-order kernel's), no other status, worst f64 deviation (ordinary variances) %.2e" % (n, time.time() - t0, nneg, nfail, worst))
+          "natural-order kernel's; %d launches of the transposed form), no other status, worst f64 deviation (ordinary variances) %.2e"
+          % (n, time.time() - t0, nneg, nfail, int(_hip.lib().mlpg_hip_launch_count(9)) - tr0, worst))
 
 
 if __name__ == "__main__":
