@@ -237,17 +237,18 @@ __device__ __forceinline__ void ticket_item(const Args &a, int tk, int lst, int 
 
 // MULTI kernels: the stream a merged static-dim index belongs to (at most 4 streams, begin[] ascending, unused
 // entries = INT_MAX) and the dim's columns there
-struct LaneStream { int sd, din, dstat, dout; };
+struct LaneStream { int sd, din, dstat, dout, dvar; };  // dvar: the dim's window-0 column in a global (D,) variance vector
 // transposed form (StreamMap::tr_u): merged index d = u * tr_nd + dim of utterance b0 + u; the columns carry the utterance's offset
 __device__ __forceinline__ LaneStream lane_stream_tr(const StreamMap &sm, int d) {
   const int u = d / sm.tr_nd, dl = d - u * sm.tr_nd;
-  return {sm.sd[0], u * sm.tr_in + sm.in_col[0] + dl, u * sm.tr_stat + sm.stat_col[0] + dl, u * sm.tr_out + sm.out_col[0] + dl};
+  return {sm.sd[0], u * sm.tr_in + sm.in_col[0] + dl, u * sm.tr_stat + sm.stat_col[0] + dl, u * sm.tr_out + sm.out_col[0] + dl,
+          sm.in_col[0] + dl};
 }
 __device__ __forceinline__ LaneStream lane_stream(const StreamMap &sm, int d) {
   const int s_ = (d >= sm.begin[1]) + (d >= sm.begin[2]) + (d >= sm.begin[3]);
   auto pick = [&](const int (&v)[4]) { return s_ == 0 ? v[0] : s_ == 1 ? v[1] : s_ == 2 ? v[2] : v[3]; };
   const int dl = d - pick(sm.begin);
-  return {pick(sm.sd), dl + pick(sm.in_col), dl + pick(sm.stat_col), dl + pick(sm.out_col)};
+  return {pick(sm.sd), dl + pick(sm.in_col), dl + pick(sm.stat_col), dl + pick(sm.out_col), dl + pick(sm.in_col)};
 }
 
 constexpr size_t kLdsStage = (size_t)kStage * kRec * 64 * 8;     // level-3 staging; its head doubles as the level-1 records
@@ -921,12 +922,13 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   const bool lane_ok = lane < nd;
   int d = d0 + (lane_ok ? lane : nd - 1);  // idle lanes shadow the group's last dim (never stored)
   // sd: the pitch between a dim's windows in a row; d: its output (and status) column; din: its window-0 input column
-  int sd = p.sd, din = d, dstat = d;
+  int sd = p.sd, din = d, dstat = d, dvar = d;
   if (MULTI) {
     const LaneStream ls = TR ? lane_stream_tr(a.sm, d) : lane_stream(a.sm, d);
     sd = ls.sd;
     din = ls.din;
     dstat = ls.dstat;
+    dvar = ls.dvar;
     d = ls.dout;
   }
   const int f0 = (r * kW + wv) * kM;
@@ -960,7 +962,7 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   const __amdgpu_buffer_rsrc_t mrs = make_rsrc(BWD ? (const TIN *)p.out : (const TIN *)p.mean + (size_t)b * Tmax * ldi + dbase);
   const __amdgpu_buffer_rsrc_t vrs =
       make_rsrc(VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)b * Tmax * ldi + dbase : (const TIN *)p.out);
-  const TIN *vglob = VM == MLPG_HIP_VAR_GLOBAL ? (const TIN *)p.var + d : nullptr;
+  const TIN *vglob = VM == MLPG_HIP_VAR_GLOBAL ? (const TIN *)p.var + dvar : nullptr;
   const __amdgpu_buffer_rsrc_t grs = make_rsrc(BWD ? (const TIN *)p.grad_out + (size_t)b * Tmax * ldg + d0 : (const TIN *)p.out);
   const TIN *vcol = VM == MLPG_HIP_VAR_FRAME ? (const TIN *)p.var + (size_t)b * Tmax * ldi + d : nullptr;  // backward epilogue
   (void)vcol;
@@ -1794,7 +1796,8 @@ __global__ void __launch_bounds__(256) verdict_kernel(const Problem p, const Win
     q.D = ws.nw * ls.sd;
     // make_view addresses column (w * sd + dloc) of q.mean: shift the bases so that dloc = 0 is this dim
     q.mean = (const TIN *)p.mean + ls.din;
-    q.var = p.var ? (const void *)((const TIN *)p.var + ls.din) : nullptr;
+    // (a global (D,) variance vector has no utterance offset)
+    q.var = p.var ? (const void *)((const TIN *)p.var + (p.var_mode == MLPG_HIP_VAR_GLOBAL ? ls.dvar : ls.din)) : nullptr;
     if (!timed_out) {
       const SysView<TIN, BWD> view = make_view<TIN, BWD>(q, ws, b, 0, T);
       status = first_bad_pivot<2, TIN, BWD>(view, ws);
@@ -1908,6 +1911,10 @@ int launch_impl(hipStream_t st, const Problem &p, const WinSet &ws, void *scratc
   };
   if constexpr (MULTI) {
     // several streams side by side on the lanes: forward, per-frame variances, three windows (the caller checked)
+    if constexpr (TR) {  // the transposed form also with global (D,) and unit variances
+      if (p.var_mode == MLPG_HIP_VAR_GLOBAL) return go(strip_kernel<TIN, TOUT, false, MLPG_HIP_VAR_GLOBAL, true, true, true>);
+      if (p.var_mode == MLPG_HIP_VAR_UNIT) return go(strip_kernel<TIN, TOUT, false, MLPG_HIP_VAR_UNIT, true, true, true>);
+    }
     return go(strip_kernel<TIN, TOUT, false, MLPG_HIP_VAR_FRAME, true, true, TR>);
   } else {
     if (ws.nw == 3) {

@@ -1,6 +1,6 @@
 """GPU parity tests (-m gpu) of the strip kernel's TRANSPOSED form (round 5): a narrow stream -- 1 .. 32 static dims -- whose lanes run
-over 64 / sd consecutive utterances x its dims (csrc/common.h StreamMap::tr_u; batches without a lengths vector, forward, per-frame
-variances, three windows of extent <= 1).  Through the C ABI against the CPU oracle; MLPG_HIP_ALGO_STRIP takes the form wherever it
+over 64 / sd consecutive utterances x its dims (csrc/common.h StreamMap::tr_u; batches without a lengths vector, forward, three
+windows of extent <= 1; per-frame, global (D,) or unit variances).  Through the C ABI against the CPU oracle; MLPG_HIP_ALGO_STRIP takes the form wherever it
 applies, MLPG_HIP_ALGO_AUTO where it is preferred (launch counter kind 9)."""
 import numpy as np
 import pytest
@@ -46,6 +46,49 @@ def test_transposed_form_against_the_oracle(B, T, sd, dt):
     out3, _ = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_STRIP)
     assert _count() == n0 + 2
     assert float((out3.double().cpu() - torch.from_numpy(out)).abs().max()) <= (1e-9 if dt == np.float64 else 5e-6) * float(np.abs(ref).max())
+
+
+@pytest.mark.parametrize("B,T,sd", [(70, 700, 1), (33, 300, 5), (64, 1100, 2), (10, 130, 25), (3, 1, 7), (130, 65, 3)])
+@pytest.mark.parametrize("vm", ["global", "unit"])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_transposed_form_with_global_and_unit_variances(B, T, sd, vm, dt):
+    """The same lane map with a global (D,) variance vector (no utterance offset in ITS columns) and with unit variances."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(B * 1000 + T + sd + 7)
+    m = rng.randn(B, T, 3 * sd).astype(dt)
+    v = (rng.rand(3 * sd) + 0.1).astype(dt) if vm == "global" else np.ones(3 * sd, dtype=dt)
+    ref, _, rc = O.mlpg_batch(m, v, STD3)
+    assert rc == 0
+    mg = torch.from_numpy(m).cuda()
+    vg = torch.from_numpy(v).cuda() if vm == "global" else None
+    n0 = _count()
+    out, st = _hip.forward(mg, vg, STD3, algo=_hip.ALGO_STRIP)
+    assert _count() == n0 + 1 and int(st.abs().max()) == 0
+    out = out.cpu().numpy().astype(np.float64)
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    scale[scale == 0] = 1.0
+    assert (np.abs(out - ref) / scale).max() <= (1e-9 if dt == np.float64 else 5e-6)
+
+
+def test_transposed_form_negative_global_variance_gives_the_reference_verdict():
+    """A negative entry of the global variance vector fails that dim in EVERY utterance: status per (utterance, dim) = the
+    natural-order kernel's, zero columns, the other dims untouched."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(4)
+    B, T, sd = 45, 400, 5
+    m = torch.from_numpy(rng.randn(B, T, 3 * sd)).cuda()
+    v = torch.from_numpy(rng.rand(3 * sd) + 0.1).cuda()
+    v[3] = -1e-3
+    out, st = _hip.forward(m, v, STD3, algo=_hip.ALGO_STRIP)
+    ref, st_ref = _hip.forward(m, v, STD3, algo=_hip.ALGO_GENERIC)
+    assert torch.equal(st, st_ref) and int((st.view(B, sd)[:, 3] != 0).sum()) == B and int((st != 0).sum()) == B
+    assert not bool(out[:, :, 3].any())
+    keep = [0, 1, 2, 4]
+    assert float((out[:, :, keep] - ref[:, :, keep]).abs().max()) <= 1e-9 * float(ref.abs().max())
 
 
 def test_transposed_form_on_a_column_slice_of_a_wide_batch():
