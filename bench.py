@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true", help="skip the live PMC pass (two rocprofv3 child runs, ~40 s)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object (the other BASELINE configs and kernel variants, timed after the metric)")
+    ap.add_argument("--precondition", type=int, default=200,
+                    help="steps of the same workload run BEFORE the --warmup steps and the timed region (event-timed, reported as "
+                         "roofline.kernel_ms_steady): the device's clocks take tens of milliseconds of THIS kernel to settle -- the "
+                         "copy-rate measurement in front of them does not do it -- and a batch job runs thousands of steps; 0: none")
     ap.add_argument("--regions", type=int, default=9,
                     help="extra timed regions of --steps launches after the official one; their median is reported beside it")
     return ap.parse_args()
@@ -394,6 +398,14 @@ def main():
         del src, dst
 
 
+    # The device's clocks settle over tens of milliseconds of this kernel (`repeat_regions` below showed regions of 20 steps at
+    # 0.2093-0.2116 ms once a few hundred steps had run, against 0.221-0.237 ms for the same region 5 steps after the copy
+    # measurement): a leg of the same steps in front of the official warm-up, event-timed and reported (kernel_ms_steady).
+    steady_ms = None
+    if not dry and args.precondition > 0:
+        timed(args.precondition - args.precondition // 2)
+        _, steady_ms, _, _ = timed(max(args.precondition // 2, 1))   # (the second half: past most of the ramp)
+
     for _ in range(args.warmup):
         out, status = step()
     sync()
@@ -472,8 +484,7 @@ def main():
         gather_ms = (time.perf_counter() - g0) * 1e3
 
     # a longer steady-state leg (informational): the driver's --steps 20 is a ~4 ms region
-    steady_ms = None
-    if rank == 0 and not dry:
+    if steady_ms is None and rank == 0 and not dry:
         _, steady_ms, _, _ = timed(max(200, args.steps))
 
     # the official region is short at the driver's --steps (a few ms): repeat it and report the spread beside it
@@ -528,6 +539,9 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "preconditioning": ("%d steps of the same workload (the second half event-timed: roofline.kernel_ms_steady) ran before the %d warm-up steps: "
+                                "the device's clocks settle over tens of ms of this kernel; see repeat_regions" % (args.precondition, args.warmup))
+                               if (args.precondition > 0 and not dry) else None,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
