@@ -29,11 +29,25 @@ sys.path.insert(0, ROOT)
 WINDOWS = [(0, 0, np.array([1.0])), (1, 1, np.array([-0.5, 0.0, 0.5])), (1, 1, np.array([1.0, -2.0, 1.0]))]
 
 
-def gpu_time(fn, steps=10, warmup=2):
+def gpu_time(fn, steps=10, warmup=2, settle_ms=None):
+    """Median HIP-event time of one call.  After the warm-up calls the function is run for about `settle_ms` of device time
+    (default 25, NNMNKWII_BENCH_SETTLE_MS; at most 400 calls) before the timed calls: the device's clocks take tens of milliseconds
+    of work to settle and fall back within milliseconds of idling (profiles/r05_notes.md section 18), and every path here is
+    measured behind a pause."""
     import torch
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    if settle_ms is None:
+        settle_ms = float(os.environ.get("NNMNKWII_BENCH_SETTLE_MS", "25"))
+    if settle_ms > 0:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        for _ in range(int(min(400, settle_ms / max(a.elapsed_time(b), 1e-3)))):
+            fn()
     evs = []
     for _ in range(steps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
