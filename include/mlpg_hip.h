@@ -57,8 +57,8 @@ extern "C" {
 #define MLPG_HIP_ALGO_AUTO 0    /* strip kernel for wide streams, wave-per-system for narrow, else generic */
 #define MLPG_HIP_ALGO_GENERIC 1 /* thread-per-system, factor in HBM scratch       */
 #define MLPG_HIP_ALGO_WAVE 2    /* wave-per-system, factor in registers           */
-#define MLPG_HIP_ALGO_STRIP 3   /* lane-per-static-dim, wavefront per 16-frame chunk, any T.  A stream of 1 .. 32 static dims in a batch
-                                   without lengths (forward, three windows): the lanes of a wavefront run over
+#define MLPG_HIP_ALGO_STRIP 3   /* lane-per-static-dim, wavefront per 16-frame chunk, any T.  A stream of 1 .. 32 static dims (forward,
+                                   three windows): the lanes of a wavefront run over
                                    64 / dims consecutive utterances x the dims instead (the transposed form, round 5) */
 #define MLPG_HIP_ALGO_PIPE 4    /* retired in ABI 11 (the software-pipelined strip kernel of round 3, now under
                                    tools/experimental/pipe): selects the strip kernel */
@@ -233,8 +233,8 @@ void mlpg_hip_host_free(void *p);
  * of the strip kernel; global (ld_in,) or unit variances (round 5): of the
  * constant-coefficient kernel -- their static dims side by side on the lanes; a
  * stream may be cut to fill the last 64-lane group, its remaining dims then run
- * as a launch of their own; every other stream is one launch.  Without `lengths`, a
- * narrow stream (or such a remainder) takes the strip kernel's
+ * as a launch of their own; every other stream is one launch.  A narrow stream (or
+ * such a remainder) takes the strip kernel's
  * transposed form (see MLPG_HIP_ALGO_STRIP) behind the merged launch on `stream`.  Launches other than the widest go
  * to internal streams forked from and joined back into `stream` with events
  * (no host synchronisation; capturable): when the call returns, everything is

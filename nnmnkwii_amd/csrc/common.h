@@ -58,7 +58,8 @@ struct StreamMap {
   // tr_nd static dims (lane = u * tr_nd + d; total = tr_u * tr_nd <= 64), so that a stream of 1 .. 32 dims fills the 64 lanes
   // it would otherwise leave idle.  A system group is then a block of tr_u utterances (tr_B utterances in all: the last block may
   // be short); sd[0] is the window pitch, in_col[0] / out_col[0] / stat_col[0] the stream's columns, and tr_in / tr_out / tr_stat
-  // the element strides from one utterance to the next in the input, output and status arrays.  No lengths (one T for all lanes).
+  // the element strides from one utterance to the next in the input, output and status arrays.  With a lengths vector the group
+  // runs to its longest utterance and every lane masks its own dead frames (strip::assemble_eliminate<..., LT>).
   int tr_u, tr_nd, tr_B, tr_in, tr_out, tr_stat;
 };
 

@@ -69,11 +69,11 @@ bool strip_preferred(const Problem &p, const WinSet &ws, bool backward, int in_d
 // left over -- leaves most of the strip kernel's 64 lanes idle, and the wave-per-system kernel that took such streams walks each
 // (utterance, dim) system with one wavefront (512 x 2000 frames of lf0: 0.08 ms for 57 MB).  Here the lanes of a group run over
 // 64 / sd consecutive UTTERANCES x the stream's dims (StreamMap::tr_u): same kernel, same records, only the lane's columns carry the
-// utterance's offset.  All lanes of a wavefront then share one T: batches without a lengths vector only; forward, three windows of
-// extent <= 1 (what the MULTI instantiation is compiled for), any variance mode; every offset inside the 2 GB window of the group's
-// first utterance.
+// utterance's offset.  Forward, three windows of extent <= 1 (what the MULTI instantiation is compiled for), any variance mode, with or
+// without a lengths vector (a group runs to its longest utterance, a lane's own dead frames enter by per-lane selects); every offset
+// inside the 2 GB window of the group's first utterance.
 bool strip_tr_supported(const Problem &p, const WinSet &ws, bool backward, int in_dtype, int out_dtype) {
-  if (backward || in_dtype != out_dtype || p.lengths || ws.nw != 3) return false;
+  if (backward || in_dtype != out_dtype || ws.nw != 3) return false;
   if (p.sd < 1 || p.sd > 32 || p.B < 2 || !strip_supported(p, ws)) return false;
   const int u = 64 / p.sd;
   const long ld = p.ld_in > p.ld_out ? p.ld_in : p.ld_out;

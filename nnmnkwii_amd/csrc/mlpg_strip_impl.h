@@ -651,13 +651,16 @@ template <typename TIN>
 struct RingDepth { static constexpr int value = MLPG_STRIP_RING_F64; };   // frames of loads in flight per wavefront (float64: 36 loads, 18 KB)
 template <>
 struct RingDepth<float> { static constexpr int value = MLPG_STRIP_RING_F32; };  // float32 values take half the registers
-template <typename TIN, bool BWD, int VM, bool EDGE, int NW, bool MULTI = false, bool KEEP = false>
+// LT (the transposed form with a lengths vector): T is the frame count of the lane group's LONGEST utterance -- what the clamped loads
+// and everything wave-uniform go by -- and Tu this lane's own: its dead frames enter with precision 0 and mean 0 by per-lane
+// SELECTS (their values are padding: anything), its rows >= Tu become identity rows.
+template <typename TIN, bool BWD, int VM, bool EDGE, int NW, bool MULTI = false, bool KEEP = false, bool LT = false>
 __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, __amdgpu_buffer_rsrc_t vrs,
                                                    __amdgpu_buffer_rsrc_t grs, const TIN *__restrict__ vglob,
                                                    unsigned loff, long ldi, long ldg, int sd, int f0, int T, int mw,
                                                    const double (*wc)[9], const double one, double (&Pd)[kM], double (&P1)[kM],
                                                    double (&P2)[kM], double (&rhs)[kM], double &ca, double &cb,
-                                                   double &cc, double (&rec)[kRec], float (&tk)[kM + 1][NW]) {
+                                                   double &cc, double (&rec)[kRec], float (&tk)[kM + 1][NW], const int Tu = 0) {
   // KEEP (backward, float32 inputs): tk[i + 1][w] = the precision of frame f0 + i in window w as the assembly used it
   // (dead frames 0), i = -1 .. kM-1: what the epilogue multiplies the gradient rows with
   // No zero-fill: every accumulator is ASSIGNED by the first contribution that reaches it (window 0 of the frame
@@ -665,11 +668,13 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
   const unsigned ldi_bytes = (unsigned)ldi * (unsigned)sizeof(TIN), win_bytes = (unsigned)sd * (unsigned)sizeof(TIN);
   // live frames of a window: [0, T) for the static window, [mw, T - mw) for the dynamic ones (none if mw == 0)
   int lo[NW], hi[NW], cl[NW], ch[NW];
+  int hi_l[NW];  // LT: this lane's own end of the window's live frames
   WinCoef k[NW];
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
     lo[w] = w ? mw : 0;
     hi[w] = w ? (mw != 0 && T - mw > mw ? T - mw : mw) : T;
+    hi_l[w] = w ? (mw != 0 && Tu - mw > mw ? Tu - mw : mw) : Tu;
     cl[w] = lo[w] < T ? lo[w] : T - 1;            // a window without live frames still loads (frame cl) and weighs 0
     ch[w] = hi[w] > cl[w] ? hi[w] : cl[w] + 1;
     k[w] = win_coef<TIN, VM>(wc, w, vglob, sd);
@@ -711,10 +716,17 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       double tau = VM == MLPG_HIP_VAR_FRAME ? tau_of<TIN>(v[w]) : k[w].tau_glob;
-      if (EDGE) tau *= (t >= lo[w] && t < hi[w]) ? 1.0 : 0.0;  // wave-uniform weight
+      double mval = BWD ? 0.0 : (double)m[w];
+      if (EDGE && LT) {
+        const bool lv = t >= lo[w] && t < hi_l[w];  // per lane
+        tau = lv ? tau : 0.0;
+        mval = lv ? mval : 0.0;
+      } else if (EDGE) {
+        tau *= (t >= lo[w] && t < hi[w]) ? 1.0 : 0.0;  // wave-uniform weight
+      }
       if (KEEP && i < kM) tk[i + 1][w] = (float)tau;  // float32 inputs: exact (a float32 reciprocal, or 0); float64 inputs: rounded
       double tm = 0.0;
-      if (!BWD) tm = tau * (double)m[w];
+      if (!BWD) tm = tau * mval;
       const bool first = w == 0;  // first contribution to: Pd, rhs of row t+1; P1 of row t; P2 of row t-1
       if (i >= 0 && i < kM) {  // row t
         Pd[i] += k[w].c00 * tau;
@@ -748,6 +760,13 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
   // that is multiplied by 0 here can be Inf or NaN unless the input is): straight-line code for the allocator.
   auto fix_row = [&](const int i) __attribute__((always_inline)) {
     const int f = f0 + i;
+    if (LT) {
+      Pd[i] = f < Tu ? Pd[i] : 1.0;
+      P1[i] = f + 1 < Tu ? P1[i] : 0.0;
+      P2[i] = f + 2 < Tu ? P2[i] : 0.0;
+      rhs[i] = f < Tu ? rhs[i] : 0.0;
+      return;
+    }
     const double live = f < T ? 1.0 : 0.0, live1 = f + 1 < T ? 1.0 : 0.0, live2 = f + 2 < T ? 1.0 : 0.0;
     Pd[i] = Pd[i] * live + (1.0 - live);
     P1[i] *= live1;
@@ -762,7 +781,12 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
   auto elim_row = [&](const int i) __attribute__((always_inline)) {
     if (EDGE) {
       fix_row(i);
-      if (i == 0) {
+      if (i == 0 && LT) {
+        const bool keep = !(f0 == 0 || f0 >= Tu), keepc = keep && !(f0 + 1 >= Tu);
+        ca = keep ? ca : 0.0;
+        cb = keep ? cb : 0.0;
+        cc = keepc ? cc : 0.0;
+      } else if (i == 0) {
         const double keep = (f0 == 0 || f0 >= T) ? 0.0 : 1.0, keepc = f0 + 1 >= T ? 0.0 : 1.0;
         ca *= keep;
         cb *= keep;
@@ -913,14 +937,32 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   const long ldi = p.ld_in, ldg = p.ld_gout, ldo = p.ld_out;
   int T = (p.lengths && !TR) ? p.lengths[b] : Tmax;
   T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
-  const int Ract = (T + kW * kM - 1) / (kW * kM);  // strips of this utterance that hold live frames
-  const bool xwg = MLPG_STRIP_ABLATE ? false : Ract > 1;  // the utterance spans several strips: level 3 runs
+  int Ract = (T + kW * kM - 1) / (kW * kM);  // strips of this utterance that hold live frames
+  bool xwg = MLPG_STRIP_ABLATE ? false : Ract > 1;  // the utterance spans several strips: level 3 runs
   const int d0 = dg * a.dgw;
   const int sd_all = MULTI ? a.sm.total : p.sd;  // MULTI: the lanes run over the static dims of all streams
   const int nd = TR ? (a.sm.tr_B - b < a.sm.tr_u ? a.sm.tr_B - b : a.sm.tr_u) * a.sm.tr_nd
                     : (sd_all - d0 < a.dgw ? sd_all - d0 : a.dgw);
   const bool lane_ok = lane < nd;
   int d = d0 + (lane_ok ? lane : nd - 1);  // idle lanes shadow the group's last dim (never stored)
+  // TR with a lengths vector: Tu = this lane's utterance's frame count; T = the longest of the lane group (what every wave-uniform
+  // rule goes by: strips, clamped loads, stores), Tmin the shortest (chunks that are interior for EVERY lane need no masks)
+  int Tu = T, Tmin = T;
+  if (TR && p.lengths) {
+    Tu = p.lengths[b + d / a.sm.tr_nd];
+    Tu = Tu < 0 ? 0 : (Tu > Tmax ? Tmax : Tu);
+    int tmx = Tu, tmn = Tu;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const int o1 = __shfl_xor(tmx, off, 64), o2 = __shfl_xor(tmn, off, 64);
+      tmx = o1 > tmx ? o1 : tmx;
+      tmn = o2 < tmn ? o2 : tmn;
+    }
+    T = __builtin_amdgcn_readfirstlane(tmx);
+    Tmin = __builtin_amdgcn_readfirstlane(tmn);
+    Ract = (T + kW * kM - 1) / (kW * kM);
+    xwg = MLPG_STRIP_ABLATE ? false : Ract > 1;
+  }
   // sd: the pitch between a dim's windows in a row; d: its output (and status) column; din: its window-0 input column
   int sd = p.sd, din = d, dstat = d, dvar = d;
   if (MULTI) {
@@ -1014,7 +1056,7 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
     for (int sl = 0; sl < kEarly0; ++sl) ldf(tv[sl], sl - 1);
   };
   if (f0 < T) {
-    const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < T - mw;
+    const bool interior = mw != 0 && f0 - 1 >= mw && f0 + kM < (TR ? Tmin : T) - mw;
     if (NW3 && MLPG_STRIP_ABLATE < 2) {
       // the usual three windows: assembly and elimination streamed in frame order
       double wcl[3][9];
@@ -1040,7 +1082,7 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
         wcs = wcl;
       }
       if (interior) bad = assemble_eliminate<TIN, BWD, VM, false, 3, MULTI, kKeepTau>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, wcs, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec, tk);
-      else bad = assemble_eliminate<TIN, BWD, VM, true, 3, MULTI, kKeepTau>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, wcs, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec, tk);
+      else bad = assemble_eliminate<TIN, BWD, VM, true, 3, MULTI, kKeepTau, TR>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, wcs, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec, tk, Tu);
       STRIP_TICK(1);
 #ifdef MLPG_STRIP_TRACE
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1785,7 +1827,7 @@ __global__ void __launch_bounds__(256) verdict_kernel(const Problem p, const Win
   if (lane >= nd || !((m >> lane) & 1ull)) return;
   int d = d0 + lane, dstat = d;
   const int Tmax = p.Tmax;
-  int T = (p.lengths && !TR) ? p.lengths[b] : Tmax;
+  int T = p.lengths ? p.lengths[TR ? b + d / a.sm.tr_nd : b] : Tmax;  // (TR: this lane's utterance)
   T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
   int status = -1;
   if (MULTI) {

@@ -1,6 +1,6 @@
 """GPU parity tests (-m gpu) of the strip kernel's TRANSPOSED form (round 5): a narrow stream -- 1 .. 32 static dims -- whose lanes run
-over 64 / sd consecutive utterances x its dims (csrc/common.h StreamMap::tr_u; batches without a lengths vector, forward, three
-windows of extent <= 1; per-frame, global (D,) or unit variances).  Through the C ABI against the CPU oracle; MLPG_HIP_ALGO_STRIP takes the form wherever it
+over 64 / sd consecutive utterances x its dims (csrc/common.h StreamMap::tr_u; forward, three windows of extent <= 1; per-frame,
+global (D,) or unit variances; with or without a lengths vector).  Through the C ABI against the CPU oracle; MLPG_HIP_ALGO_STRIP takes the form wherever it
 applies, MLPG_HIP_ALGO_AUTO where it is preferred (launch counter kind 9)."""
 import numpy as np
 import pytest
@@ -41,11 +41,78 @@ def test_transposed_form_against_the_oracle(B, T, sd, dt):
     scale = np.abs(ref).max(axis=1, keepdims=True)
     scale[scale == 0] = 1.0
     assert (np.abs(out - ref) / scale).max() <= (1e-9 if dt == np.float64 else 5e-6)
-    # with a lengths vector the same call stays on the plain form (one T per wavefront is what the transposed form assumes)
+    # a lengths vector of full lengths: the same form (per-lane frame counts), the same numbers
     L = torch.full((B,), T, dtype=torch.int32, device="cuda")
     out3, _ = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_STRIP)
-    assert _count() == n0 + 2
+    assert _count() == n0 + 3
     assert float((out3.double().cpu() - torch.from_numpy(out)).abs().max()) <= (1e-9 if dt == np.float64 else 5e-6) * float(np.abs(ref).max())
+
+
+@pytest.mark.parametrize("B,T,sd", [(70, 700, 1), (33, 300, 5), (64, 1100, 2), (10, 130, 25), (130, 65, 3), (9, 2049, 16), (7, 3, 2)])
+@pytest.mark.parametrize("vm", ["frame", "global", "unit"])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_transposed_form_with_ragged_lengths(B, T, sd, vm, dt):
+    """A lengths vector: the lanes of a wavefront belong to utterances of different lengths.  The group runs to its longest
+    utterance; a lane's own dead frames enter by per-lane selects, so whatever the padding holds (NaN here) never reaches a
+    live frame; padding rows of the output are zero.  Lengths 0, 1, 2 and T included."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(B * 100 + T + sd + 3)
+    lengths = rng.randint(0, T + 1, size=B).astype(np.int32)
+    lengths[rng.randint(B)] = T
+    for k, val in enumerate((0, 1, 2, T - 1, 3)):
+        if k < B - 1:
+            lengths[(k * 7 + 1) % B] = max(0, min(T, val))
+    m = rng.randn(B, T, 3 * sd).astype(dt)
+    v = (rng.rand(B, T, 3 * sd) + 0.1).astype(dt) if vm == "frame" else ((rng.rand(3 * sd) + 0.1).astype(dt) if vm == "global" else np.ones(3 * sd, dtype=dt))
+    m_ref = m.copy()
+    for b in range(B):
+        m_ref[b, lengths[b]:] = 0
+    ref, _, rc = O.mlpg_batch(m_ref, np.where(np.isfinite(v), v, 1.0) if vm != "frame" else v, STD3, lengths)
+    assert rc == 0
+    for b in range(B):                    # padding: NaN in the means and (per-frame mode) in the variances
+        m[b, lengths[b]:] = np.nan
+        if vm == "frame":
+            v[b, lengths[b]:] = np.nan
+    mg = torch.from_numpy(m).cuda()
+    vg = None if vm == "unit" else torch.from_numpy(v).cuda()
+    L = torch.from_numpy(lengths).cuda()
+    n0 = _count()
+    out, st = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_STRIP)
+    assert _count() == n0 + 1 and int(st.abs().max()) == 0
+    out2, _ = _hip.forward(mg, vg, STD3, L, algo=_hip.ALGO_STRIP)
+    assert torch.equal(out, out2)
+    out = out.cpu().numpy().astype(np.float64)
+    assert np.isfinite(out).all()
+    for b in range(B):
+        assert not out[b, lengths[b]:].any(), b
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    scale[scale == 0] = 1.0
+    assert (np.abs(out - ref) / scale).max() <= (1e-9 if dt == np.float64 else 5e-6)
+
+
+def test_transposed_form_ragged_failing_pivots():
+    """Negative variances in live frames fail their systems, in the padding they do not: status = the natural-order kernel's."""
+    import torch
+    from nnmnkwii_amd import _hip
+    STD3 = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(19)
+    B, T, sd = 90, 500, 4
+    lengths = rng.randint(50, T + 1, size=B).astype(np.int32)
+    m = torch.from_numpy(rng.randn(B, T, 3 * sd)).cuda()
+    v = torch.from_numpy(rng.rand(B, T, 3 * sd) + 0.1).cuda()
+    for b in range(0, B, 7):
+        v[b, int(lengths[b]) - 3, b % sd] = -1e-3                    # live: fails
+        if lengths[b] < T:
+            v[b + 1, int(lengths[b + 1]):, (b + 1) % sd] = -1e-3       # padding only: no failure
+    L = torch.from_numpy(lengths).cuda()
+    out, st = _hip.forward(m, v, STD3, L, algo=_hip.ALGO_STRIP)
+    ref, st_ref = _hip.forward(m, v, STD3, L, algo=_hip.ALGO_GENERIC)
+    assert torch.equal(st, st_ref) and int((st != 0).sum()) == len(range(0, B, 7))
+    bad = (st.view(B, sd) != 0)[:, None, :].expand_as(out)
+    assert not bool((out != 0)[bad].any())
+    assert float((out - ref)[~bad].abs().max()) <= 1e-9 * float(ref[~bad].abs().max())
 
 
 @pytest.mark.parametrize("B,T,sd", [(70, 700, 1), (33, 300, 5), (64, 1100, 2), (10, 130, 25), (3, 1, 7), (130, 65, 3)])
@@ -172,11 +239,11 @@ def test_merged_launch_with_its_piece_on_the_transposed_form():
         ocol += sd
     out2, _ = _hip.forward_streams(mg, vg, streams)
     assert torch.equal(out, out2)
-    # with a lengths vector the piece stays on the wave-per-system kernel, same numbers
+    # with a lengths vector: the same routes (per-lane frame counts), same numbers
     L = torch.full((B,), T, dtype=torch.int32, device="cuda")
     n1 = _count()
     out3, _ = _hip.forward_streams(mg, vg, streams, L)
-    assert _count() == n1 and float((out3 - out).abs().max()) <= 1e-9 * float(out.abs().max())
+    assert _count() == n1 + 1 and float((out3 - out).abs().max()) <= 1e-9 * float(out.abs().max())
 
 
 def test_auto_takes_the_transposed_form_only_where_it_is_preferred():
