@@ -215,7 +215,7 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     // retired (tools/experimental/pipe): the strip scheme it pipelined, or the kernel AUTO would take
     algo = strip_supported(p, ws) ? MLPG_HIP_ALGO_STRIP : MLPG_HIP_ALGO_AUTO;
   }
-  // a narrow stream (or the piece a merged launch left over) of a batch without lengths: the strip kernel with its lanes over
+  // a narrow stream (or the piece a merged launch left over): the strip kernel with its lanes over
   // several utterances; a launch the grid cannot hold falls through to the other kernels
   if ((algo == MLPG_HIP_ALGO_AUTO && strip_tr_preferred(p, ws, backward, in_dtype, out_dtype)) ||
       (algo == MLPG_HIP_ALGO_STRIP && p.pitch && p.pitch != p.sd && strip_tr_supported(p, ws, backward, in_dtype, out_dtype))) {

@@ -45,7 +45,7 @@ def soak(budget=40.0, seed=4711):
             v = (rng.rand(B, T, D) + 0.1).astype(dt)
             lengths = rng.randint(1, T + 1, size=B).astype(np.int32)
             lengths[rng.randint(B)] = T
-            no_lengths = rng.rand() < 0.4     # batches without a lengths vector: narrow streams and pieces take the strip kernel's transposed form
+            no_lengths = rng.rand() < 0.4     # also batches without a lengths vector (round 5's first form of the transposed strip kernel needed that; now either way)
             if no_lengths:
                 lengths[:] = T
             for b in range(B):
