@@ -215,6 +215,11 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     // retired (tools/experimental/pipe): the strip scheme it pipelined, or the kernel AUTO would take
     algo = strip_supported(p, ws) ? MLPG_HIP_ALGO_STRIP : MLPG_HIP_ALGO_AUTO;
   }
+  // (the FIR form first: float32 unit variances without lengths -- it has no chain at all; not for a piece of a stream)
+  if (algo == MLPG_HIP_ALGO_AUTO && !(p.pitch && p.pitch != p.sd) && fir_shape_supported(p, ws, in_dtype, out_dtype) && fir_preferred(p, backward)) {
+    const int rc = launch_fir(st, backward, p, ws, device);
+    if (rc != kFirNotApplicable) return rc;
+  }
   // a narrow stream (or the piece a merged launch left over): the strip kernel with its lanes over
   // several utterances; a launch the grid cannot hold falls through to the other kernels
   if ((algo == MLPG_HIP_ALGO_AUTO && strip_tr_preferred(p, ws, backward, in_dtype, out_dtype)) ||
@@ -229,10 +234,6 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
       return MLPG_HIP_EINVAL;
     }
     algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
-  }
-  if (algo == MLPG_HIP_ALGO_AUTO && fir_shape_supported(p, ws, in_dtype, out_dtype) && fir_preferred(p, backward)) {
-    const int rc = launch_fir(st, backward, p, ws, device);
-    if (rc != kFirNotApplicable) return rc;
   }
   if (algo == MLPG_HIP_ALGO_AUTO) {
     if (const_preferred(p, ws)) algo = MLPG_HIP_ALGO_CONST;
@@ -357,6 +358,8 @@ bool stream_takes_tr(int dtype, int algo, const void *mean, const void *var, int
   if (stream_problem(dtype, mean, var, var_mode, ld_in, lengths, B, Tmax, sm, wl, wu, wc, out, ld_out, nullptr, 1, 0, d_first, d_count, &p, &ws))
     return false;
   if (p.pitch && (algo == MLPG_HIP_ALGO_CONST || algo == MLPG_HIP_ALGO_CHUNK || algo == MLPG_HIP_ALGO_FIR)) algo = MLPG_HIP_ALGO_AUTO;
+  // (dispatch_solve's order: the FIR form first)
+  if (algo == MLPG_HIP_ALGO_AUTO && !(p.pitch && p.pitch != p.sd) && fir_shape_supported(p, ws, dtype, dtype) && fir_preferred(p, false)) return false;
   return algo == MLPG_HIP_ALGO_AUTO ? strip_tr_preferred(p, ws, false, dtype, dtype)
                                     : algo == MLPG_HIP_ALGO_STRIP && strip_tr_supported(p, ws, false, dtype, dtype);
 }
