@@ -248,7 +248,8 @@ def mlpg(mean_frames, variance_frames, windows):
     measured in profiles/r05_auto_routing.json):
 
     * extents <= 1 (the usual static / delta / delta-delta set, also one or two windows): the fast kernels -- strip,
-      wave-per-system, constant-coefficient, FIR -- at 0.4-0.5 of the HBM roofline for wide streams;
+      wave-per-system, constant-coefficient, FIR -- at 0.4-0.5 of the HBM roofline for wide streams; batches of narrow
+      streams (1-32 static dims: lf0, bap) ride the strip kernel with its lanes over several utterances (DESIGN.md K1t);
     * extents of 2 (the reference's 5-tap test windows, tests/test_paramgen.py:21-26), up to three windows: the chunked
       kernel, which reads the inputs twice: 0.22 of the roofline;
     * more than three windows with an extent of 2, or extents of 3-4: the natural-order kernel, one lane per system and
