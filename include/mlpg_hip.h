@@ -78,7 +78,9 @@ const char *mlpg_hip_last_error(void);
 /* Test aid, not part of the reference's interface: launches per MLPG kernel family since the library was loaded --
  * 0 natural-order, 1 wave-per-system, 2 strip, 3 strip with several streams merged, 4 constant-coefficient, 5 fused, 6 chunked, 7 FIR,
  * 8 constant-coefficient with several streams merged, 9 strip in its transposed form (narrow streams: the lanes over several
- * utterances); -1 for any other `kind`.  (Tests use it to assert WHICH kernel a call took.) */
+ * utterances); and, counting CALLS rather than launches, 10 host-memory calls that took the short path with their inputs copied to the
+ * device, 11 with the kernel reading the pinned staging buffer itself (see mlpg_hip_forward_host); -1 for any other `kind`.
+ * (Tests use it to assert WHICH kernel / route a call took.) */
 long long mlpg_hip_launch_count(int kind);
 int mlpg_hip_device_count(void);
 /* Frees the per-device scratch caches. */
@@ -111,6 +113,17 @@ int mlpg_hip_unit_mse_step(int device, void *stream, int dtype, const void *mean
                            void *workspace, size_t workspace_bytes);
 size_t mlpg_hip_unit_mse_workspace_bytes(int B, int D, int num_windows);
 size_t mlpg_hip_unit_mse_workspace_bytes_t(int B, int Tmax, int D, int num_windows);
+/*
+ * Which form mlpg_hip_unit_mse_step takes for this problem when it is given the workspace of mlpg_hip_unit_mse_workspace_bytes_t:
+ * 2 the FIR form, 1 the one-launch kernel, 0 neither (the step would return MLPG_HIP_EINVAL: the caller runs forward, loss and
+ * backward as separate calls); negative: an error code.  The step decides with the same function.  The FIR form's conditions include
+ * a property of the window set's NUMBERS (its inverse must decay to 2^-26 within 24 frames -- false for, e.g., dynamic windows scaled
+ * by 4 or a static weight of 0.3), so the shape alone does not tell; the first query for a window set on a device builds the tap
+ * table (synchronous).  While `stream` is being captured a table that does not exist yet cannot be built: the answer is then 1 or
+ * 0, and may become 2 later (ABI 13).
+ */
+int mlpg_hip_unit_mse_form(int device, void *stream, int dtype, int has_lengths, int B, int Tmax, int D, int num_windows,
+                           const int32_t *win_l_h, const int32_t *win_u_h, const double *win_coef_h);
 
 /*
  * Measurement aid, not part of the reference's interface: a plain streaming copy of nbytes (a multiple of 16; both
@@ -150,6 +163,12 @@ int mlpg_hip_forward(int device, void *stream, int dtype, int algo,
  * memory is staged through pinned buffers by a few copy threads, memory from mlpg_hip_host_alloc (or any pinned /
  * registered host memory) is transferred in place.  All pointers are HOST pointers; shapes, dtypes, windows,
  * var_mode and status as for mlpg_hip_forward (lengths_h may be NULL).
+ * A SMALL call -- at most 6 MB of input (MLPG_HIP_HOST_SMALL_MB) on one device: the literal per-utterance
+ * paramgen.mlpg(mean_frames (T, D), variance_frames, windows) of the reference (_mlpg.py:92), 9.6 KB at T = 100 x 2 static
+ * dims, 2.9 MB at T = 1000 x 60 -- takes a short path instead: one stream, one cached pinned staging buffer, no chunk plan and
+ * no thread; the arrays are staged and sent one behind the other (up to 48 KB the kernel reads the pinned buffer itself), the
+ * kernel writes trajectory and verdicts straight into pinned host memory, and the host polls a sequence number written behind
+ * them (round 6; mlpg_hip_launch_count(10 / 11) counts these calls).
  */
 int mlpg_hip_forward_host(int device, int dtype, int algo, const void *mean_h,
                           const void *var_h, int var_mode,
@@ -206,6 +225,10 @@ long long mlpg_hip_host_chunk_plan(long long n_items, long long target_items, in
 /* Pinned host memory for arrays that are handed to mlpg_hip_forward_host repeatedly (transferred in place). */
 void *mlpg_hip_host_alloc(size_t bytes);
 void mlpg_hip_host_free(void *p);
+/* Test aid, no GPU involved: dst[0, bytes) = src[0, bytes) by the short path's staging copy -- the calling thread and a few helper
+ * threads (MLPG_HIP_HOST_HELPERS, default 3) share 64 KB slices claimed through one atomic word; the helpers spin for
+ * MLPG_HIP_HOST_SPIN_US (default 250) after a copy, then sleep.  mlpg_hip_shutdown joins them. */
+int mlpg_hip_host_copy(void *dst, const void *src, size_t bytes);
 
 /*
  * Multi-stream MLPG forward over one padded acoustic feature batch (SURVEY 8(f)

@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 F32, F64 = 0, 1
-ABI_VERSION = 12               # mlpg_hip_abi_version() of the library this binding was written for
+ABI_VERSION = 13               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE, ALGO_STRIP, ALGO_PIPE, ALGO_CONST, ALGO_CHUNK, ALGO_FIR = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -54,6 +54,8 @@ EXPORTS = (
     "mlpg_hip_unit_mse_step",
     "mlpg_hip_unit_mse_workspace_bytes",
     "mlpg_hip_unit_mse_workspace_bytes_t",
+    "mlpg_hip_unit_mse_form",
+    "mlpg_hip_host_copy",
 )
 
 
@@ -132,6 +134,8 @@ def lib():
         L.mlpg_hip_host_chunk_plan.argtypes = [ctypes.c_longlong, ctypes.c_longlong, ci, ctypes.c_longlong, vp, vp, vp, vp]
         L.mlpg_hip_host_alloc.restype = vp
         L.mlpg_hip_host_alloc.argtypes = [ctypes.c_size_t]
+        L.mlpg_hip_host_copy.restype = ci
+        L.mlpg_hip_host_copy.argtypes = [vp, vp, ctypes.c_size_t]
         L.mlpg_hip_host_free.restype = None
         L.mlpg_hip_host_free.argtypes = [vp]
         L.mlpg_hip_forward_streams.restype = ci
@@ -173,6 +177,8 @@ def lib():
         L.mlpg_hip_unit_mse_workspace_bytes.argtypes = [ci, ci, ci]
         L.mlpg_hip_unit_mse_workspace_bytes_t.restype = ctypes.c_size_t
         L.mlpg_hip_unit_mse_workspace_bytes_t.argtypes = [ci, ci, ci, ci]
+        L.mlpg_hip_unit_mse_form.restype = ci
+        L.mlpg_hip_unit_mse_form.argtypes = [ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp]
         L.mlpg_hip_stream_copy.restype = ci
         L.mlpg_hip_stream_copy.argtypes = [ci, vp, vp, vp, ctypes.c_size_t]
         if L.mlpg_hip_abi_version() != ABI_VERSION:
@@ -266,6 +272,34 @@ def _nw(windows):
     return windows[3] if isinstance(windows, PackedWindows) else len(windows)
 
 
+_WIN_CACHE = {}     # id(window list) -> (the list, its signature, PackedWindows): the literal per-utterance calls pass the same list
+
+
+def cached_windows(windows):
+    """PackedWindows of a window list, remembered per list OBJECT (a loop of paramgen.mlpg calls passes the same list every
+    time: packing costs 5 us, a config-1 call 30).  The remembered tables are used only if the list still holds the same
+    (l, u, coefficient object) triples with the same coefficient bytes; anything else is packed afresh."""
+    if isinstance(windows, PackedWindows):
+        return windows
+    ent = _WIN_CACHE.get(id(windows))
+    try:
+        if ent is not None and ent[0] is windows and len(windows) == len(ent[1]):
+            for w, g in zip(windows, ent[1]):
+                c = w[2]
+                if w[0] != g[0] or w[1] != g[1] or c is not g[2] or (c.tobytes() if type(c) is np.ndarray else tuple(c)) != g[3]:
+                    break
+            else:
+                return ent[2]
+        packed = prepack_windows(windows)
+        sig = tuple((w[0], w[1], w[2], w[2].tobytes() if type(w[2]) is np.ndarray else tuple(w[2])) for w in windows)
+    except (TypeError, IndexError):      # not a list of (l, u, coeff) triples this cache understands: no caching
+        return prepack_windows(windows)
+    if len(_WIN_CACHE) >= 64:
+        _WIN_CACHE.clear()
+    _WIN_CACHE[id(windows)] = (windows, sig, packed)
+    return packed
+
+
 def _dt(t):
     torch = torch_mod()
     if t.dtype == torch.float32:
@@ -331,7 +365,7 @@ def forward(mean, var, windows, lengths=None, algo=ALGO_AUTO, want_status=True):
 def current_device_index(device=None):
     """GPU index for the host-pointer entry points: an explicit int / "cuda:1" / object with .index, otherwise the
     process's current device (what torch.cuda.set_device(local_rank) selected in a one-process-per-GPU job; 0 when
-    torch has not been imported -- the entry points themselves need no torch)."""
+    torch has not been imported or has not touched the GPU yet -- the entry points themselves need no torch)."""
     if device is not None:
         idx = device if isinstance(device, str) else getattr(device, "index", device)
         if isinstance(idx, str):
@@ -339,7 +373,7 @@ def current_device_index(device=None):
         if idx is not None:
             return int(idx)
     t = sys.modules.get("torch")
-    if t is not None and t.cuda.is_available():
+    if t is not None and t.cuda.is_initialized():
         return int(t.cuda.current_device())
     return 0
 
@@ -368,36 +402,52 @@ def host_chunk_plan(n_items, target_items, num_devices):
     return entry, slot, first, count
 
 
+_host_gpu_seen = False     # mlpg_hip_device_count() > 0 has been seen (it does not change afterwards)
+
+
 def forward_host(mean, var, windows, lengths=None, algo=ALGO_AUTO, device=None):
-    """Batched MLPG, numpy in -> numpy out through mlpg_hip_forward_host_multi (no torch involved): mean (B, T, D)
+    """Batched MLPG, numpy in -> numpy out through mlpg_hip_forward_host[_multi] (no torch involved): mean (B, T, D)
     float32/float64 C-contiguous, var same shape / (D,) / None, lengths int32 (B,) or None; device: GPU index
     (default: the current device, see current_device_index), a list of indices, or "all" (every visible device; the
-    utterance chunks are dealt round-robin, see device_list).
+    utterance chunks are dealt round-robin, see device_list).  One device: mlpg_hip_forward_host, whose small calls
+    (a single utterance: the literal paramgen.mlpg call) take the library's short path.
     Returns (out (B, T, sd) ndarray, status int32 (B, sd))."""
+    global _host_gpu_seen
     L = lib()
-    devs = device_list(device)
-    if L.mlpg_hip_device_count() <= 0:
-        raise HipExtensionError("nnmnkwii_amd needs an AMD GPU (none visible to the HIP runtime); there is no CPU fallback")
+    if not _host_gpu_seen:
+        if L.mlpg_hip_device_count() <= 0:
+            raise HipExtensionError("nnmnkwii_amd needs an AMD GPU (none visible to the HIP runtime); there is no CPU fallback")
+        _host_gpu_seen = True
     assert mean.ndim == 3 and mean.flags.c_contiguous and mean.dtype in (np.float32, np.float64)
     B, T, D = mean.shape
-    nw = _nw(windows)
-    wl, wu, wc = pack_windows(windows)
+    pw = cached_windows(windows)
+    nw = pw[3]
+    pl, pu, pc = pw.ptrs()
     dt = F32 if mean.dtype == np.float32 else F64
     if var is None:
-        mode = VAR_UNIT
+        mode, pv = VAR_UNIT, None
     else:
         assert var.dtype == mean.dtype and var.flags.c_contiguous
         mode = VAR_GLOBAL if var.ndim == 1 else VAR_FRAME
         assert var.shape == ((D,) if var.ndim == 1 else mean.shape)
+        pv = var.ctypes.data
+    plen = None
     if lengths is not None:
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
         assert lengths.shape == (B,)
+        plen = lengths.ctypes.data
     out = np.empty((B, T, D // nw), dtype=mean.dtype)
     status = np.zeros((B, D // nw), dtype=np.int32)
-    rc = L.mlpg_hip_forward_host_multi(_np(devs) if len(devs) else None, len(devs), dt, algo, _np(mean),
-                                       None if var is None else _np(var), mode, None if lengths is None else _np(lengths),
-                                       B, T, D, nw, _np(wl), _np(wu), _np(wc), _np(out), _np(status))
-    _check(rc, "mlpg_hip_forward_host_multi")
+    if isinstance(device, (list, tuple, np.ndarray)) or (isinstance(device, str) and device == "all"):
+        devs = device_list(device)
+        rc = L.mlpg_hip_forward_host_multi(_np(devs) if len(devs) else None, len(devs), dt, algo, mean.ctypes.data, pv, mode, plen,
+                                           B, T, D, nw, pl, pu, pc, out.ctypes.data, status.ctypes.data)
+        _check(rc, "mlpg_hip_forward_host_multi")
+    else:
+        rc = L.mlpg_hip_forward_host(current_device_index(device), dt, algo, mean.ctypes.data, pv, mode, plen,
+                                     B, T, D, nw, pl, pu, pc, out.ctypes.data, status.ctypes.data)
+        if rc != 0:
+            _check(rc, "mlpg_hip_forward_host")
     return out, status
 
 
@@ -741,13 +791,40 @@ def gather_path(src, path, path_len, Tout):
 _MSE_WORKSPACE = {}           # (device, stream) -> [tensor, used inside a stream capture]
 _MSE_WORKSPACE_RETIRED = []   # outgrown workspaces a captured graph may still replay kernels on (only those: see below)
 _MSE_NEED = {}                # (B, T, D, nw, with FIR dy buffer) -> bytes (mlpg_hip_unit_mse_workspace_bytes[_t])
+_MSE_FORM = {}                # (device, dtype, lengths given, B, T, D, id(packed windows)) -> (packed windows, form): settled answers only
+
+
+def unit_mse_form(device, dtype, has_lengths, B, T, D, windows):
+    """Which form mlpg_hip_unit_mse_step takes (mlpg_hip_unit_mse_form: the library's own decision, not a copy of it):
+    2 the FIR form, 1 the one-launch kernel, 0 neither.  Answers for a PackedWindows object are remembered, except a
+    "not 2" given while the stream is being captured (the tap table could not be built then; it may exist later)."""
+    torch = torch_mod()
+    packed = isinstance(windows, PackedWindows)
+    key = (device.index, dtype, bool(has_lengths), B, T, D, id(windows)) if packed else None
+    if key is not None:
+        hit = _MSE_FORM.get(key)
+        if hit is not None and hit[0] is windows:
+            return hit[1]
+    nw, pl, pu, pc, _keep = _win_args(windows)
+    form = lib().mlpg_hip_unit_mse_form(device.index, _stream(device), F32 if dtype == torch.float32 else F64, 1 if has_lengths else 0,
+                                        B, T, D, nw, pl, pu, pc)
+    if form < 0:
+        _check(form, "mlpg_hip_unit_mse_form")
+    if key is not None and (form == 2 or not torch.cuda.is_current_stream_capturing()):
+        if len(_MSE_FORM) > 1024:
+            _MSE_FORM.clear()
+        _MSE_FORM[key] = (windows, form)
+    return form
 
 
 def _mse_workspace(device, B, T, D, nw, fir_form):
     """The per-(device, stream) workspace of mlpg_hip_unit_mse_step.  Zeroed once (the kernel leaves its arrival counter
     zero); grown geometrically (length-bucketed or ascending batches would otherwise reallocate at almost every new
-    maximum); the FIR form's dy buffer (B * T * sd floats) is only asked for by batches that can take that form; an
-    outgrown buffer is kept alive only if a stream capture has used it (a graph may still replay kernels on it)."""
+    maximum); the FIR form's dy buffer (B * T * sd floats) is only asked for by batches that take that form.  A workspace
+    is never created or grown while its stream is being captured -- the allocation would come from the graph's private
+    pool and its one-time zero fill would become a node of the graph, replayed behind other launches' backs: warm up one
+    step of the largest shape before capturing.  An outgrown buffer is kept alive only if a stream capture has used it (a
+    graph may still replay kernels on it)."""
     torch = torch_mod()
     nk = (B, T, D, nw, fir_form)
     need = _MSE_NEED.get(nk)
@@ -762,6 +839,10 @@ def _mse_workspace(device, B, T, D, nw, fir_form):
     ent = _MSE_WORKSPACE.get(key)
     capturing = torch.cuda.is_current_stream_capturing()
     if ent is None or ent[0].numel() < need:
+        if capturing:
+            raise HipExtensionError(
+                "unit_mse_step: the workspace of this stream does not exist yet or is too small (%d bytes needed) and cannot be "
+                "allocated while the stream is being captured -- run one eager step of this shape on the stream first" % need)
         size = need if ent is None else max(need, ent[0].numel() * 3 // 2)
         if ent is not None and ent[1]:
             _MSE_WORKSPACE_RETIRED.append(ent[0])
@@ -776,7 +857,7 @@ def unit_mse_step(mean, target, windows, lengths=None, n_elems=None, want_y=Fals
     """Fused unit-variance MLPG + MSE training step on device tensors (mlpg_hip_unit_mse_step): mean (B, T, D), target
     (B, T, D / nw), float32 or float64.  Returns (loss float64 0-dim tensor, grad_mean (B, T, D), y or None, status or None).
     One launch (the wave-per-system kernel: window extents <= 1, T <= 1024), or two in the FIR form (float32, no lengths, T >= 96,
-    window extents <= 2, any T)."""
+    window extents <= 2, any T, a window set whose inverse decays: unit_mse_form says which)."""
     torch = torch_mod()
     assert mean.is_cuda and mean.dim() == 3 and mean.is_contiguous() and target.is_contiguous()
     B, T, D = mean.shape
@@ -791,8 +872,10 @@ def unit_mse_step(mean, target, windows, lengths=None, n_elems=None, want_y=Fals
     y = torch.empty_like(target) if want_y else None
     loss = torch.empty((), dtype=torch.float64, device=mean.device)
     status = torch.empty((B * sd,), dtype=torch.int32, device=mean.device) if want_status else None
-    # (the FIR form -- float32 batches without lengths of T >= 96 -- needs room for its dy buffer)
-    ws, stream = _mse_workspace(mean.device, B, T, D, nw, mean.dtype == torch.float32 and lengths is None and T >= 96)
+    # (the FIR form needs room for its dy buffer: the library says whether this call takes it)
+    fir_form = mean.dtype == torch.float32 and lengths is None and T >= 96 and \
+        unit_mse_form(mean.device, mean.dtype, False, B, T, D, windows) == 2
+    ws, stream = _mse_workspace(mean.device, B, T, D, nw, fir_form)
     rc = lib().mlpg_hip_unit_mse_step(mean.device.index, stream, _dt(mean), _p(mean), _p(target), _p(lengths),
                                       B, T, D, nw, pl, pu, pc, float(n_elems), _p(y), _p(grad), _p(loss),
                                       _p(status), _p(ws), ws.numel())

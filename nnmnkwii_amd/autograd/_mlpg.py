@@ -50,6 +50,11 @@ class MLPG(Function):
         ctx.windows = windows
         ctx.save_for_backward(means, variances)
         assert means.size() == variances.size()
+        if not means.is_cuda and not variances.is_cuda:
+            # CPU tensors (what the reference's tensors are, autograd/_impl/mlpg.py:50-53: paramgen.mlpg on .numpy()): the
+            # host-memory entry point's short path -- no torch device tensor, no torch stream, one C call
+            y = G.mlpg(means.detach().numpy(), variances.detach().numpy(), windows)
+            return torch.from_numpy(y).to(torch.float32)
         dev = _hip.require_gpu(means.device if means.is_cuda else None)
         m = _to_gpu(means, dev)
         if m.dtype not in (torch.float32, torch.float64):
@@ -281,22 +286,15 @@ class _UnitVarianceMLPGWindows(Function):
 
 
 def _fused_step_applies(windows, means, target):
-    """What mlpg_hip_unit_mse_step accepts (csrc/capi.hip: the FIR form for float32 batches of T >= 96 with window extents
-    <= 2 and a single-tap static window, any length; otherwise the one-launch kernel, csrc/mlpg_wave_fused.hip
-    unit_mse_supported: T <= 1024, window extents <= 1) and what the fused node can differentiate: no gradient wanted for
-    the target."""
+    """Does mlpg_hip_unit_mse_step take this call -- asked of the library itself (mlpg_hip_unit_mse_form: the FIR form for
+    float32 batches of T >= 96 whose window set passes its decay test, any length; otherwise the one-launch kernel,
+    T <= 1024 and window extents <= 1) -- and can the fused node differentiate it: no gradient wanted for the target."""
     if torch.is_tensor(target) and target.requires_grad:
         return False
-    if isinstance(windows, _hip.PackedWindows):          # (l[], u[], coeff[], nw): what _identify_R hands back
-        ls, us = np.asarray(windows[0]), np.asarray(windows[1])
-    else:
-        ls, us = np.asarray([int(l) for l, _, _ in windows]), np.asarray([int(u) for _, u, _ in windows])
-    ext = int(max(ls.max(), us.max())) if len(ls) else 0
-    T = means.shape[-2]
-    if ext <= 1 and T <= 1024:
-        return True
-    fir = means.dtype == torch.float32 and T >= 96 and ext <= 2 and 1 <= len(ls) <= 3 and int(ls[0]) == 0 and int(us[0]) == 0
-    return bool(fir)
+    dev = _hip.require_gpu(means.device if means.is_cuda else None)
+    dt = means.dtype if means.dtype in (torch.float32, torch.float64) else torch.float32
+    B = means.shape[0] if means.dim() == 3 else 1
+    return _hip.unit_mse_form(dev, dt, False, B, means.shape[-2], means.shape[-1], windows) != 0
 
 
 def unit_variance_mlpg_mse_loss(R_or_windows, means, target):

@@ -371,7 +371,7 @@ using namespace mlpg;
 
 extern "C" {
 
-__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 12; }
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 13; }
 
 __attribute__((visibility("default"))) long long mlpg_hip_launch_count(int kind) {
   return kind >= 0 && kind < kCountKinds ? g_launches[kind].load() : -1;
@@ -706,6 +706,46 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
   return 0;
 }
 
+namespace {
+// The form mlpg_hip_unit_mse_step takes for a problem -- decided HERE and nowhere else (the step and mlpg_hip_unit_mse_form both ask):
+// 2 the FIR form (two launches; needs the workspace of mlpg_hip_unit_mse_workspace_bytes_t), 1 the one-launch wave-per-system kernel,
+// 0 neither.  `with_fir_workspace`: the caller can provide the larger workspace.
+int unit_mse_form(hipStream_t st, int device, int dtype, const Problem &p, const WinSet &ws, bool with_fir_workspace) {
+  if (with_fir_workspace && dtype == MLPG_HIP_F32 && fir_shape_supported(p, ws, dtype, dtype) && fir_table_ready(st, device, ws)) return 2;
+  return unit_mse_supported(p.Tmax, ws) ? 1 : 0;
+}
+}  // namespace
+
+__attribute__((visibility("default"))) int mlpg_hip_unit_mse_form(int device, void *stream, int dtype, int has_lengths, int B,
+                                                                  int Tmax, int D, int num_windows, const int32_t *win_l_h,
+                                                                  const int32_t *win_u_h, const double *win_coef_h) {
+  if (int rc = check_common(B, Tmax, D, num_windows)) return rc;
+  if (dtype != MLPG_HIP_F32 && dtype != MLPG_HIP_F64) {
+    set_error("dtype must be MLPG_HIP_F32 or MLPG_HIP_F64");
+    return MLPG_HIP_EINVAL;
+  }
+  WinSet ws;
+  if (int rc = pack_windows(num_windows, win_l_h, win_u_h, win_coef_h, &ws)) return rc;
+  if (B == 0 || Tmax == 0 || D == 0) return 1;  // (the step answers an empty batch itself: loss 0)
+  DeviceGuard g(device);
+  if (!g.ok) {
+    set_error("cannot select device %d", device);
+    return MLPG_HIP_ERUNTIME;
+  }
+  Problem p = {};
+  static const int32_t some_lengths = 0;
+  p.lengths = has_lengths ? &some_lengths : nullptr;  // (only looked at as "given or not")
+  p.var_mode = MLPG_HIP_VAR_UNIT;
+  p.B = B;
+  p.Tmax = Tmax;
+  p.D = D;
+  p.sd = D / num_windows;
+  p.ld_in = D;
+  p.ld_out = D;
+  p.ld_status = D / num_windows;
+  return unit_mse_form((hipStream_t)stream, device, dtype, p, ws, true);
+}
+
 __attribute__((visibility("default"))) int mlpg_hip_unit_mse_step(int device, void *stream, int dtype, const void *mean,
                                                                   const void *target, const int32_t *lengths, int B,
                                                                   int Tmax, int D, int num_windows,
@@ -759,14 +799,17 @@ __attribute__((visibility("default"))) int mlpg_hip_unit_mse_step(int device, vo
   p.ld_out = D;
   p.ld_status = D / num_windows;
   // float32 batches without lengths, given the larger workspace (mlpg_hip_unit_mse_workspace_bytes_t): the FIR form, two launches
-  if (dtype == MLPG_HIP_F32 && fir_shape_supported(p, ws, dtype, dtype) && workspace && !((uintptr_t)workspace & 127) &&
-      workspace_bytes >= fir_mse_workspace_bytes(B, Tmax, p.sd)) {
+  const bool fir_ws = workspace && !((uintptr_t)workspace & 127) && workspace_bytes >= fir_mse_workspace_bytes(B, Tmax, p.sd);
+  const int form = unit_mse_form(st, device, dtype, p, ws, fir_ws);
+  if (form == 2) {
     const int rc = launch_fir_mse(st, p, ws, device, target, y_out, n_elems, loss, workspace);
     if (rc != kFirNotApplicable) return rc;
   }
   if (!unit_mse_supported(Tmax, ws)) {
     set_error("unit_mse_step: needs window extents <= 1 and T <= 1024 (T=%d, half-bandwidth %d), or a float32 batch without lengths "
-              "of T >= 96 with the workspace of mlpg_hip_unit_mse_workspace_bytes_t", Tmax, ws.q);
+              "of T >= 96 whose window set passes the FIR form's decay test (mlpg_hip_unit_mse_form says which), with the workspace of "
+              "mlpg_hip_unit_mse_workspace_bytes_t; inside a stream capture the FIR form needs its tap table built by an earlier call",
+              Tmax, ws.q);
     return MLPG_HIP_EINVAL;
   }
   if (!workspace || workspace_bytes < unit_mse_workspace_bytes(B, D / num_windows) || ((uintptr_t)workspace & 127)) {

@@ -19,6 +19,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -200,6 +201,221 @@ int ensure(HostCtx &c, size_t in_bytes, size_t out_bytes, size_t dev_bytes) {
 
 inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// ---- the short path: ONE small call (round 6) -------------------------------------------------------------------
+// The literal drop-in call is paramgen.mlpg(mean_frames (T, D), variance_frames, windows) on numpy arrays, once per
+// utterance (paramgen/_mlpg.py:92; the loop around it: util/__init__.py:56-66): 9.6 KB in at BASELINE config 1, 2.9 MB
+// at one config-2 utterance.  At those sizes the chunk plan above is all overhead (a collector thread is created and
+// joined per call: 30 us; five copies and an event per chunk; the reference itself needs 40 us at config 1).  The short
+// path has one stream, one pinned staging buffer and no thread (tools/dbg/small_call_latency.hip measured the pieces):
+//   * inputs go pageable -> pinned by memcpy, means first, and each array's host -> device copy is enqueued as soon as
+//     it is staged, so the variances are staged under the means' transfer; a batch of at most kSmallDirectIn bytes is
+//     not copied to the device at all -- the kernel reads the pinned buffer over PCIe (one copy-engine hop, 3 us, less);
+//   * the kernel writes trajectory and verdicts straight into pinned host memory (no device -> host copy: 10-12 us less
+//     at 0.5 MB), followed by a one-thread kernel that writes a sequence number behind them;
+//   * the host polls that word instead of hipStreamSynchronize (6.3 against 10.9 us for an empty launch), looking at
+//     hipStreamQuery every few thousand polls so that a failed launch is an error, not a hang.
+// MLPG_HIP_HOST_SMALL_MB: calls of at most this many MB of input take the short path (default 6; 0: never).
+struct SmallCtx {
+  hipStream_t st = nullptr;
+  char *pin_in = nullptr, *pin_out = nullptr, *dev = nullptr;
+  size_t pin_in_bytes = 0, pin_out_bytes = 0, dev_bytes = 0;
+  unsigned *flag = nullptr;  // one pinned cache line
+  unsigned seq = 0;
+};
+SmallCtx g_small[kMaxHostDevices];
+constexpr size_t kSmallDirectIn = 48u << 10;
+
+__global__ void small_flag_kernel(volatile unsigned *flag, unsigned v) {
+  *flag = v;
+  __threadfence_system();
+}
+
+size_t small_limit_bytes() {
+  static const size_t lim = [] {
+    const char *e = getenv("MLPG_HIP_HOST_SMALL_MB");
+    const double v = e ? atof(e) : 6.0;
+    return (size_t)(v <= 0 ? 0 : v * 1048576.0);
+  }();
+  return lim;
+}
+// MLPG_HIP_HOST_SMALL_WAIT=sync: hipStreamSynchronize instead of polling the flag word (A/B runs)
+bool small_wait_by_flag() {
+  static const bool flag = [] { const char *e = getenv("MLPG_HIP_HOST_SMALL_WAIT"); return !(e && e[0] == 's'); }();
+  return flag;
+}
+
+// Staging helpers of the short path: a few threads that share the pageable <-> pinned copies of one call with the calling
+// thread (a config-2 utterance: 2.9 MB in, 58 us for one core; the host -> device transfer behind it takes 60 us, so every
+// microsecond of staging in front of the first transfer is on the call's critical path).  Not created per call (thread
+// creation is 30 us): they spin on the job word for MLPG_HIP_HOST_SPIN_US microseconds after their last job (default 250: a
+// loop of per-utterance calls keeps them awake) and then sleep on a condition variable.  A job is a list of 64 KB slices
+// claimed through ONE 64-bit word (generation << 32 | next slice), so a helper that wakes up late cannot claim a slice of a
+// job that is already over.  MLPG_HIP_HOST_HELPERS: number of helpers (default 3, at most half the cores - 1; 0: none).
+class CopyPool {
+ public:
+  static CopyPool *get() {
+    std::lock_guard<std::mutex> lk(inst_mu_);
+    if (!inst_) {
+      const char *e = getenv("MLPG_HIP_HOST_HELPERS");
+      long n = e ? atol(e) : 3;
+      const long cap = (long)std::thread::hardware_concurrency() / 2 - 1;
+      n = std::max<long>(0, std::min<long>(std::min<long>(n, cap), kMaxHelpers));
+      const char *s = getenv("MLPG_HIP_HOST_SPIN_US");
+      inst_ = new CopyPool((int)n, s ? atof(s) : 250.0);
+    }
+    return inst_;
+  }
+  static void shutdown() {
+    CopyPool *p = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(inst_mu_);
+      p = inst_;
+      inst_ = nullptr;
+    }
+    if (!p) return;
+    {
+      std::lock_guard<std::mutex> lk(p->mu_);
+      p->quit_.store(true);
+    }
+    p->cv_.notify_all();
+    for (auto &t : p->th_) t.join();
+    delete p;
+  }
+  // dst[0, bytes) = src[0, bytes), shared with the helpers; returns when every byte is in place
+  void copy(void *dst, const void *src, size_t bytes) {
+    if (th_.empty() || bytes < 2 * kSlice) {
+      memcpy(dst, src, bytes);
+      return;
+    }
+    const unsigned nslices = (unsigned)((bytes + kSlice - 1) / kSlice);
+    dst_.store((char *)dst, std::memory_order_relaxed);
+    src_.store((const char *)src, std::memory_order_relaxed);
+    bytes_.store(bytes, std::memory_order_relaxed);
+    nslices_.store(nslices, std::memory_order_relaxed);
+    done_.store(0, std::memory_order_relaxed);
+    const uint64_t g = (uint64_t)(++gen_) << 32;
+    ticket_.store(g, std::memory_order_seq_cst);  // the job is published
+    if (sleepers_.load(std::memory_order_seq_cst) > 0) {
+      { std::lock_guard<std::mutex> lk(mu_); }
+      cv_.notify_all();
+    }
+    work(gen_);
+    while (done_.load(std::memory_order_acquire) != nslices) __builtin_ia32_pause();
+  }
+
+ private:
+  static constexpr size_t kSlice = 64u << 10;
+  static constexpr int kMaxHelpers = 7;
+  CopyPool(int n, double spin_us) : spin_us_(spin_us) {
+    for (int k = 0; k < n; ++k) th_.emplace_back([this] { helper(); });
+  }
+  // claims and copies slices of job `gen` until none is left (or the job is over)
+  void work(unsigned gen) {
+    for (;;) {
+      uint64_t t = ticket_.load(std::memory_order_acquire);
+      if ((unsigned)(t >> 32) != gen) return;
+      const unsigned idx = (unsigned)t;
+      if (idx >= nslices_.load(std::memory_order_relaxed)) return;
+      if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
+      // the claim succeeded on a ticket of generation `gen`: the job fields are that job's (the caller does not publish the
+      // next one before every claimed slice is counted in done_)
+      const size_t off = (size_t)idx * kSlice;
+      memcpy(dst_.load(std::memory_order_relaxed) + off, src_.load(std::memory_order_relaxed) + off,
+             std::min(kSlice, bytes_.load(std::memory_order_relaxed) - off));
+      done_.fetch_add(1, std::memory_order_release);
+    }
+  }
+  void helper() {
+    unsigned seen = 0;
+    auto last = std::chrono::steady_clock::now();
+    for (unsigned long spins = 0;; ++spins) {
+      const unsigned g = (unsigned)(ticket_.load(std::memory_order_acquire) >> 32);
+      if (g != seen) {
+        seen = g;
+        work(g);
+        last = std::chrono::steady_clock::now();
+        continue;
+      }
+      if (quit_.load(std::memory_order_relaxed)) return;
+      __builtin_ia32_pause();
+      if ((spins & 255) == 255 &&
+          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - last).count() > spin_us_) {
+        std::unique_lock<std::mutex> lk(mu_);
+        sleepers_.fetch_add(1, std::memory_order_seq_cst);
+        cv_.wait(lk, [&] { return quit_.load() || (unsigned)(ticket_.load(std::memory_order_seq_cst) >> 32) != seen; });
+        sleepers_.fetch_sub(1, std::memory_order_seq_cst);
+        if (quit_.load()) return;
+        last = std::chrono::steady_clock::now();
+      }
+    }
+  }
+  static CopyPool *inst_;
+  static std::mutex inst_mu_;
+  std::vector<std::thread> th_;
+  double spin_us_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::atomic<bool> quit_{false};
+  std::atomic<int> sleepers_{0};
+  std::atomic<uint64_t> ticket_{0};
+  std::atomic<unsigned> done_{0};
+  unsigned gen_ = 0;
+  std::atomic<unsigned> nslices_{0};
+  std::atomic<char *> dst_{nullptr};
+  std::atomic<const char *> src_{nullptr};
+  std::atomic<size_t> bytes_{0};
+};
+CopyPool *CopyPool::inst_ = nullptr;
+std::mutex CopyPool::inst_mu_;
+
+int small_ensure(SmallCtx &c, size_t in_bytes, size_t out_bytes, size_t dev_bytes) {
+  if (!c.st) {
+    MLPG_HIP_CHECK(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
+    MLPG_HIP_CHECK(hipHostMalloc((void **)&c.flag, 64, hipHostMallocDefault));
+    *c.flag = 0;
+  }
+  auto grow = [&](char *&buf, size_t &have, size_t want, bool host) -> int {
+    if (have >= want) return 0;
+    MLPG_HIP_CHECK(hipStreamSynchronize(c.st));
+    if (buf) (void)(host ? hipHostFree(buf) : hipFree(buf));
+    buf = nullptr;
+    have = 0;
+    const size_t sz = std::max<size_t>(want + want / 2, 256u << 10);
+    if (host) MLPG_HIP_CHECK(hipHostMalloc((void **)&buf, sz, hipHostMallocDefault));
+    else MLPG_HIP_CHECK(hipMalloc((void **)&buf, sz));
+    have = sz;
+    return 0;
+  };
+  if (int rc = grow(c.pin_in, c.pin_in_bytes, in_bytes, true)) return rc;
+  if (int rc = grow(c.pin_out, c.pin_out_bytes, out_bytes, true)) return rc;
+  return grow(c.dev, c.dev_bytes, dev_bytes, false);
+}
+
+// Waits for everything enqueued on c.st: a sequence number written to pinned memory behind it, polled.
+int small_wait(SmallCtx &c) {
+  if (!small_wait_by_flag()) {
+    MLPG_HIP_CHECK(hipStreamSynchronize(c.st));
+    return 0;
+  }
+  const unsigned v = ++c.seq;
+  hipLaunchKernelGGL(small_flag_kernel, dim3(1), dim3(1), 0, c.st, (volatile unsigned *)c.flag, v);
+  MLPG_HIP_CHECK(hipGetLastError());
+  volatile unsigned *f = c.flag;
+  for (unsigned long spins = 1;; ++spins) {
+    if (*f == v) return 0;
+    __builtin_ia32_pause();
+    if ((spins & 0x3fff) == 0) {  // (every ~16 k polls: a few hundred microseconds)
+      const hipError_t q = hipStreamQuery(c.st);
+      if (q == hipSuccess) return 0;  // the stream has drained: the word is there
+      if (q != hipErrorNotReady) {
+        set_error("host call: the stream failed: %s", hipGetErrorString(q));
+        (void)hipGetLastError();
+        return MLPG_HIP_ERUNTIME;
+      }
+    }
+  }
+}
+
 __global__ void widen_f32(const float *__restrict__ src, double *__restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (double)src[i];
 }
@@ -208,6 +424,19 @@ __global__ void widen_f32(const float *__restrict__ src, double *__restrict__ ds
 
 void host_api_shutdown() {
   std::lock_guard<std::mutex> lk(g_host_mu);
+  CopyPool::shutdown();
+  for (int d = 0; d < kMaxHostDevices; ++d) {
+    SmallCtx &c = g_small[d];
+    if (!c.st) continue;
+    (void)hipSetDevice(d);
+    (void)hipStreamSynchronize(c.st);
+    (void)hipStreamDestroy(c.st);
+    if (c.flag) (void)hipHostFree(c.flag);
+    if (c.pin_in) (void)hipHostFree(c.pin_in);
+    if (c.pin_out) (void)hipHostFree(c.pin_out);
+    if (c.dev) (void)hipFree(c.dev);
+    c = SmallCtx();
+  }
   for (int dr = 0; dr < kMaxHostDevices * kMaxRep; ++dr) {
     const int d = dr / kMaxRep;
     HostCtx &c = g_host[d][dr % kMaxRep];
@@ -362,6 +591,88 @@ int run_chunks(const DevList &dl, long nchunks, Submit submit, Collect collect) 
   return rc;
 }
 
+// One small MLPG call on one device (see SmallCtx); g_host_mu is held by the caller.
+int forward_host_small(int device, int dtype, int algo, const void *mean_h, const void *var_h, int var_mode, const int32_t *lengths_h,
+                       int B, int Tmax, int D, int num_windows, const WinSet &ws, void *out_h, int32_t *status_h) {
+  HostTrace tr;
+  int prev = -1;
+  MLPG_HIP_CHECK(hipGetDevice(&prev));
+  if (prev != device) MLPG_HIP_CHECK(hipSetDevice(device));
+  struct Restore {
+    int prev, dev;
+    ~Restore() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+  } restore{prev, device};
+  SmallCtx &c = g_small[device];
+  const size_t esz = dtype == MLPG_HIP_F32 ? 4 : 8;
+  const int sd = D / num_windows;
+  const bool fvar = var_mode == MLPG_HIP_VAR_FRAME;
+  const size_t mean_bytes = (size_t)B * Tmax * D * esz, out_bytes = (size_t)B * Tmax * sd * esz;
+  const size_t var_bytes = fvar ? mean_bytes : (var_mode == MLPG_HIP_VAR_GLOBAL ? (size_t)D * esz : 0);
+  const size_t len_bytes = lengths_h ? (size_t)B * sizeof(int32_t) : 0, st_bytes = (size_t)B * sd * sizeof(int32_t);
+  const size_t o_var = up256(mean_bytes), o_len = o_var + up256(var_bytes), in_total = o_len + up256(len_bytes);
+  const size_t o_status = up256(out_bytes), out_total = o_status + up256(st_bytes);
+  const bool direct_in = in_total <= kSmallDirectIn;  // the kernel reads the pinned staging buffer itself
+  if (int rc = small_ensure(c, in_total, out_total, direct_in ? 0 : in_total)) return rc;
+  note_launch(direct_in ? kCountHostSmallDirect : kCountHostSmall);
+  char *src = direct_in ? c.pin_in : c.dev;
+  CopyPool *pool = CopyPool::get();  // (small copies are plain memcpys of the calling thread)
+  // Staged piece by piece (768 KB: the copy engine starts 15 us into the call instead of 30 at a config-2 utterance, and every
+  // further transfer costs 3 us), each piece's transfer enqueued behind its staging: the next piece is staged under it.  (Enqueued
+  // copies are submitted at once -- measured: a hipStreamSynchronize behind a host-side pause of the copy's length returns in
+  // 0.6 us -- and two streams do not move a pair of halves faster than one moves them in a row.)
+  auto stage_send = [&](size_t off, const void *from, size_t bytes, size_t tail) -> int {  // tail: staged bytes right behind, sent along
+    constexpr size_t kPiece = 768u << 10;
+    for (size_t o = 0; o < bytes; o += kPiece) {
+      const size_t n = std::min(kPiece, bytes - o);
+      pool->copy(c.pin_in + off + o, (const char *)from + o, n);
+      const bool last = o + n >= bytes;
+      if (!direct_in) MLPG_HIP_CHECK(hipMemcpyAsync(c.dev + off + o, c.pin_in + off + o, n + (last ? tail : 0), hipMemcpyHostToDevice, c.st));
+      if (last) break;
+    }
+    return 0;
+  };
+  if (int rc = stage_send(0, mean_h, mean_bytes, 0)) return rc;
+  if (len_bytes) memcpy(c.pin_in + o_len, lengths_h, len_bytes);
+  // (variances and lengths are neighbours in the staging buffer: the lengths ride on the variances' last transfer)
+  if (var_bytes) {
+    if (int rc = stage_send(o_var, var_h, var_bytes, len_bytes ? o_len + len_bytes - (o_var + var_bytes) : 0)) return rc;
+  } else if (len_bytes && !direct_in) {
+    MLPG_HIP_CHECK(hipMemcpyAsync(c.dev + o_len, c.pin_in + o_len, len_bytes, hipMemcpyHostToDevice, c.st));
+  }
+  Problem p;
+  p.mean = src;
+  p.var = var_bytes ? src + o_var : nullptr;
+  p.grad_out = nullptr;
+  p.lengths = len_bytes ? (const int32_t *)(src + o_len) : nullptr;
+  p.out = c.pin_out;  // pinned host memory: written by the kernel over PCIe
+  p.status = (int32_t *)(c.pin_out + o_status);
+  p.var_mode = var_mode;
+  p.B = B;
+  p.Tmax = Tmax;
+  p.D = D;
+  p.sd = sd;
+  p.ld_in = D;
+  p.ld_gout = 0;
+  p.ld_out = sd;
+  p.ld_status = sd;
+  const double ts = tr.on ? HostTrace::now() : 0.0;
+  int rc = dispatch_solve(c.st, dtype, dtype, algo, false, p, ws, device);
+  if (!rc) rc = small_wait(c);
+  if (rc) {  // nothing is left in flight
+    (void)hipStreamSynchronize(c.st);
+    (void)hipGetLastError();
+    return rc;
+  }
+  const double tw = tr.on ? HostTrace::now() : 0.0;
+  pool->copy(out_h, c.pin_out, out_bytes);
+  if (status_h) memcpy(status_h, c.pin_out + o_status, st_bytes);
+  if (tr.on)
+    fprintf(stderr, "[mlpg_hip host] short path (%s inputs): %.1f us total = %.1f staging/enqueue + %.1f launch/wait + %.1f copying results\n",
+            direct_in ? "pinned, read by the kernel" : "copied to the device", 1e6 * (HostTrace::now() - tr.t0), 1e6 * (ts - tr.t0), 1e6 * (tw - ts),
+            1e6 * (HostTrace::now() - tw));
+  return 0;
+}
+
 int ensure_all(const DevList &dl, size_t in_bytes, size_t out_bytes, size_t dev_bytes) {
   int prev = -1;
   MLPG_HIP_CHECK(hipGetDevice(&prev));
@@ -390,6 +701,17 @@ __attribute__((visibility("default"))) void *mlpg_hip_host_alloc(size_t bytes) {
     return nullptr;
   }
   return p;
+}
+
+// Test aid: the staging copy of the short path (the calling thread and the helper threads share 64 KB slices); no GPU involved.
+__attribute__((visibility("default"))) int mlpg_hip_host_copy(void *dst, const void *src, size_t bytes) {
+  if (bytes && (!dst || !src)) {
+    set_error("host_copy: NULL pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  std::lock_guard<std::mutex> lk(g_host_mu);  // (the pool serves one copy at a time: the host entry points hold this lock too)
+  CopyPool::get()->copy(dst, src, bytes);
+  return 0;
 }
 
 __attribute__((visibility("default"))) void mlpg_hip_host_free(void *p) {
@@ -447,11 +769,14 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_host_multi(const int
   DevList dl;
   if (int rc = resolve_devices(devices, num_devices, &dl)) return rc;
   const bool fvar = var_mode == MLPG_HIP_VAR_FRAME;
-  const bool mean_pinned = is_pinned(mean_h), var_pinned = fvar && is_pinned(var_h), out_pinned = is_pinned(out_h);
-
   const size_t esz = dtype == MLPG_HIP_F32 ? 4 : 8;
   const int sd = D / num_windows;
   const size_t utt_in = (size_t)Tmax * D * esz, utt_out = (size_t)Tmax * sd * esz;
+  // one small call on one device: the short path (no chunk plan, no thread, one stream)
+  if (dl.n == 1 && (size_t)B * utt_in * (fvar ? 2 : 1) <= small_limit_bytes())
+    return forward_host_small(dl.dev[0], dtype, algo, mean_h, var_h, var_mode, lengths_h, B, Tmax, D, num_windows, ws, out_h, status_h);
+  const bool mean_pinned = is_pinned(mean_h), var_pinned = fvar && is_pinned(var_h), out_pinned = is_pinned(out_h);
+
   // ~64 MB of input per chunk
   static const long chunk_mb = [] { const char *e = getenv("MLPG_HIP_HOST_CHUNK_MB"); const long v = e ? atol(e) : 0; return v > 0 ? v : 64; }();
   const long cb = host_chunk_items(B, (long)(((size_t)chunk_mb << 20) / (utt_in * (fvar ? 2 : 1))), dl.n);
@@ -640,8 +965,17 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw_host_multi(const int
   auto collect = [&](int e, int slot, long chunk) -> int {
     const long b0 = chunk * cb, nb = std::min<long>(cb, N - b0);
     const char *o = (const char *)dl.ctx[e]->pin_out[slot];
-    memcpy(path_i_h + (size_t)b0 * pl, o, (size_t)nb * pl * 4);
-    memcpy(path_j_h + (size_t)b0 * pl, o + so_pj, (size_t)nb * pl * 4);
+    // (the path slots behind a pair's path are whatever the device buffer held: handed over as zeros, so that the arrays of
+    // two identical calls are identical)
+    const int32_t *plen = (const int32_t *)(o + so_pl);
+    for (long n = 0; n < nb; ++n) {
+      const size_t k = (size_t)std::min<long>(std::max<long>(plen[n], 0), (long)pl);
+      int32_t *di = path_i_h + (size_t)(b0 + n) * pl, *dj = path_j_h + (size_t)(b0 + n) * pl;
+      memcpy(di, o + (size_t)n * pl * 4, k * 4);
+      memcpy(dj, o + so_pj + (size_t)n * pl * 4, k * 4);
+      memset(di + k, 0, (pl - k) * 4);
+      memset(dj + k, 0, (pl - k) * 4);
+    }
     memcpy(path_len_h + b0, o + so_pl, (size_t)nb * 4);
     if (lenx_out_h) memcpy(lenx_out_h + b0, o + so_lx, (size_t)nb * 4);
     if (leny_out_h) memcpy(leny_out_h + b0, o + so_ly, (size_t)nb * 4);

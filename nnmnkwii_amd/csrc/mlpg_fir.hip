@@ -767,6 +767,13 @@ bool fir_shape_supported(const Problem &p, const WinSet &ws, int in_dtype, int o
   return rows_fit_buffer(p);
 }
 
+// Does the FIR form serve this window set on this device: the tap table exists (it is built here, synchronously, on first use -- not
+// while `st` is being captured) and passed its decay test.  The ONE answer both mlpg_hip_unit_mse_step and mlpg_hip_unit_mse_form give.
+bool fir_table_ready(hipStream_t st, int device, const WinSet &ws) {
+  const fir::Table *tb = fir::table_for(st, device, ws);
+  return tb && tb->ok;
+}
+
 // Measured (profiles/r04_notes.md section 11): backward it is the fastest kernel at 64 and at 256 utterances; forward the
 // constant-coefficient kernel (one workgroup per sequence) overtakes it once there are sequences enough to fill the chip with those.
 // mlpg_hip_shutdown: the tap tables

@@ -156,7 +156,7 @@ def _mlpg_batch_host(means, variances, windows, lengths, algo, check, device):
                 m = m.astype(np.float64)
     # default: the process's current GPU, not GPU 0; a list of indices or "all": the chunks dealt over those devices
     out, status = _hip.forward_host(m, v, windows, lengths, algo=algo, device=device)
-    if check:
+    if check and status.any():
         st = status.ravel()
         bad = np.flatnonzero(st)
         if bad.size:

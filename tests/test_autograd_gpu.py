@@ -264,3 +264,114 @@ def test_fused_mse_loss_falls_back_where_the_fused_kernel_does_not_apply():
         assert np.abs(means.grad.cpu().numpy() - go).max() <= 1e-9 * np.abs(go).max(), wname
         if tgrad:
             assert np.abs(target.grad.cpu().numpy() - gt).max() <= 1e-12 * np.abs(gt).max()
+
+
+def _dense_unit_mse(windows, m, t):
+    """loss and d loss / d means of mse_loss(R mu, target) from the dense float64 definition (paramgen/_mlpg.py:297-373
+    without the float32 cast), built from the oracle's window matrices."""
+    from oracle import mlpg as O
+    T = m.shape[-2]
+    nw = len(windows)
+    sd = m.shape[-1] // nw
+    mw = int(max(max(l, u) for l, u, _ in windows))
+    mask = O._edge_mask(T, mw)
+    Ws = [O.window_matrix(l, u, np.asarray(c, dtype=np.float64), T) for (l, u, c) in windows]
+    Wt = [W if w == 0 else mask[:, None] * W for w, W in enumerate(Ws)]
+    P = sum(Wt[w].T @ Ws[w] for w in range(nw))
+    R = np.linalg.solve(P, np.concatenate([Wt[w].T for w in range(nw)], axis=1))
+    mm = m.reshape(-1, T, nw, sd).transpose(0, 2, 1, 3).reshape(-1, nw * T, sd)
+    r = np.einsum("tk,bkd->btd", R, mm) - t.reshape(-1, T, sd)
+    g = np.einsum("tk,btd->bkd", R, 2.0 * r / r.size).reshape(-1, nw, T, sd).transpose(0, 2, 1, 3).reshape(m.shape)
+    return (r ** 2).mean(), g
+
+
+_SLOW = {
+    # legal window sets whose P^-1 does NOT decay to 2^-26 within 24 frames: the FIR form's table test refuses them
+    "dynamic-x4": [(0, 0, np.array([1.0])), (1, 1, 4.0 * np.array([-0.5, 0.0, 0.5])), (1, 1, 4.0 * np.array([1.0, -2.0, 1.0]))],
+    "static-0.3": [(0, 0, np.array([0.3])), (1, 1, np.array([-0.5, 0.0, 0.5])), (1, 1, np.array([1.0, -2.0, 1.0]))],
+    "wide3-x3": [(0, 0, np.array([1.0])), (2, 2, 3.0 * np.array([1.0, -8.0, 0.0, 8.0, -1.0]) / 12.0),
+                 (2, 2, 3.0 * np.array([-1.0, 16.0, -30.0, 16.0, -1.0]) / 12.0)],
+}
+
+
+@pytest.mark.parametrize("wname,T", [("std3", 1100), ("wide3", 200), ("wide3", 1100), ("dynamic-x4", 1100), ("dynamic-x4", 300),
+                                     ("static-0.3", 1100), ("static-0.3", 128), ("wide3-x3", 1100)])
+def test_fused_mse_loss_float32_routes_ask_the_library(wname, T):
+    """Round-5 ADVICE: for float32 batches with T > 1024 or window extents of 2 the fused node used to be chosen by shape
+    alone, and mlpg_hip_unit_mse_step then returned EINVAL for window sets that fail the FIR form's decay test.  Now
+    mlpg_hip_unit_mse_form -- the function the step itself decides with -- is asked: whatever it says, the loss and the
+    gradient equal the dense float64 definition (float32 tolerance), and the call never raises."""
+    import torch
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd import autograd as AF
+    windows = _SLOW.get(wname) or WINDOW_SETS[wname]
+    nw = len(windows)
+    B, sd = 3, 5
+    torch.manual_seed(T)
+    means = torch.rand(B, T, nw * sd, dtype=torch.float32, device="cuda", requires_grad=True)
+    target = torch.rand(B, T, sd, dtype=torch.float32, device="cuda")
+    form = _hip.unit_mse_form(means.device, torch.float32, False, B, T, nw * sd, windows)
+    ext = max(max(l, u) for l, u, _ in windows)
+    if wname in _SLOW:
+        assert form != 2, "the FIR form must refuse a window set whose inverse decays this slowly"
+    if form == 0:
+        assert T > 1024 or ext > 1                  # (the one-launch kernel takes everything else)
+    n0 = int(_hip.lib().mlpg_hip_launch_count(7)), int(_hip.lib().mlpg_hip_launch_count(5))
+    loss = AF.unit_variance_mlpg_mse_loss(windows, means, target)
+    loss.backward()
+    n1 = int(_hip.lib().mlpg_hip_launch_count(7)), int(_hip.lib().mlpg_hip_launch_count(5))
+    if form == 2:
+        assert n1[0] - n0[0] == 2 and n1[1] == n0[1]      # the FIR form: two launches inside one call
+    elif form == 1:
+        assert n1[1] - n0[1] == 1                          # the one-launch fused kernel
+    else:
+        assert n1[1] == n0[1]                              # two-node form: no fused launch
+    lo, go = _dense_unit_mse(windows, means.detach().cpu().numpy().astype(np.float64), target.cpu().numpy().astype(np.float64))
+    assert abs(float(loss) - lo) <= 2e-5 * lo, (wname, T, form)
+    assert np.abs(means.grad.cpu().numpy() - go).max() <= 2e-5 * np.abs(go).max(), (wname, T, form)
+    # the R-matrix form of the call reaches the same route
+    if T <= 300:
+        from nnmnkwii_amd import paramgen as G
+        R = torch.from_numpy(G.unit_variance_mlpg_matrix(windows, T)).cuda()
+        m2 = means.detach().clone().requires_grad_()
+        l2 = AF.unit_variance_mlpg_mse_loss(R, m2, target)
+        l2.backward()
+        assert abs(float(l2) - lo) <= 2e-5 * lo
+        assert np.abs(m2.grad.cpu().numpy() - go).max() <= 2e-5 * np.abs(go).max()
+
+
+def test_fused_step_inside_a_stream_capture_needs_a_warm_up_and_says_so():
+    """The step's workspace is never created or grown while its stream is being captured (round-5 ADVICE): the call raises
+    a HipExtensionError that says what to do; after one eager step on the stream the capture works and replays."""
+    import torch
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd import autograd as AF
+    windows = WINDOW_SETS["std3"]
+    B, T, sd = 4, 160, 6
+    means = torch.rand(B, T, 3 * sd, device="cuda", requires_grad=True)
+    target = torch.rand(B, T, sd, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        try:
+            with pytest.raises((_hip.HipExtensionError, RuntimeError)):
+                with torch.cuda.graph(g, stream=side):
+                    AF.unit_variance_mlpg_mse_loss(windows, means, target)
+        finally:
+            torch.cuda.synchronize()
+        for _ in range(2):                               # the warm-up the message asks for
+            means.grad = None
+            AF.unit_variance_mlpg_mse_loss(windows, means, target).backward()
+        torch.cuda.synchronize()
+        want_loss = float(AF.unit_variance_mlpg_mse_loss(windows, means, target))
+        want_grad = means.grad.clone()
+        means.grad = None
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=side):
+            loss = AF.unit_variance_mlpg_mse_loss(windows, means, target)
+            loss.backward()
+        g2.replay()
+        torch.cuda.synchronize()
+        assert float(loss) == want_loss
+        assert torch.equal(means.grad, want_grad)

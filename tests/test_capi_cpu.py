@@ -31,7 +31,7 @@ def test_exports_match_header(L):
     assert declared == set(_hip.EXPORTS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.mlpg_hip_abi_version() == _hip.ABI_VERSION == 12
+    assert L.mlpg_hip_abi_version() == _hip.ABI_VERSION == 13
 
 
 def test_argument_validation_without_gpu(L):
@@ -69,6 +69,83 @@ def test_argument_validation_without_gpu(L):
     rc = L.mlpg_hip_fastdtw_l2(0, None, fake, fake, fake, fake, 1, 4, 4, 2, 0, fake, fake, fake, fake)
     assert rc == -1
     assert L.mlpg_hip_device_count() >= 0
+
+
+def test_unit_mse_form_validates_without_gpu(L):
+    wl = np.array([0, 1], dtype=np.int32)
+    wu = np.array([0, 1], dtype=np.int32)
+    wc = np.array([1.0, -0.5, 0.0, 0.5])
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    assert L.mlpg_hip_unit_mse_form(0, None, 0, 0, 2, 100, 5, 2, p(wl), p(wu), p(wc)) == -1      # D not a multiple of nw
+    assert b"multiple" in L.mlpg_hip_last_error()
+    assert L.mlpg_hip_unit_mse_form(0, None, 9, 0, 2, 100, 4, 2, p(wl), p(wu), p(wc)) == -1      # bad dtype
+    assert L.mlpg_hip_unit_mse_form(0, None, 0, 0, 0, 100, 4, 2, p(wl), p(wu), p(wc)) == 1       # an empty batch: the step answers it
+    assert L.mlpg_hip_launch_count(10) >= 0 and L.mlpg_hip_launch_count(11) >= 0 and L.mlpg_hip_launch_count(12) == -1
+
+
+def test_host_copy_pool_copies_every_byte_and_survives_shutdown(L):
+    """mlpg_hip_host_copy: the staging copy of the short host path (calling thread + helper threads, 64 KB slices claimed
+    through one atomic word) -- sizes around the slice boundaries, back-to-back jobs (helpers awake), jobs behind a pause
+    (helpers asleep), from two Python threads, and again after mlpg_hip_shutdown joined the helpers."""
+    import threading
+    import time
+    rng = np.random.RandomState(0)
+    src = rng.randint(0, 256, size=(9 << 20) + 13, dtype=np.uint8)
+
+    def check(n, off=0):
+        dst = np.full(n + 64, 0xA5, dtype=np.uint8)
+        assert L.mlpg_hip_host_copy(dst.ctypes.data + 32, src.ctypes.data + off, n) == 0
+        assert np.array_equal(dst[32:32 + n], src[off:off + n])
+        assert (dst[:32] == 0xA5).all() and (dst[32 + n:] == 0xA5).all()       # nothing outside the range is touched
+
+    for n in (0, 1, 65535, 65536, 65537, 131071, 131072, 131073, 1440000, 2880000, (9 << 20) + 13):
+        check(n)
+    for k in range(200):                         # back to back: the helpers are spinning
+        check(int(rng.randint(1, 3 << 20)), int(rng.randint(0, 1 << 20)))
+    for _ in range(3):                           # behind a pause: the helpers sleep and are woken
+        time.sleep(0.01)
+        check(1440000, 7)
+    errs = []
+
+    def run(seed):
+        r = np.random.RandomState(seed)
+        try:
+            for _ in range(60):
+                check(int(r.randint(1, 2 << 20)), int(r.randint(0, 1 << 20)))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=run, args=(s,)) for s in (1, 2, 3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    L.mlpg_hip_shutdown()                        # joins the helpers; the next copy brings them up again
+    check(2880000)
+    L.mlpg_hip_shutdown()
+    assert L.mlpg_hip_host_copy(None, None, 0) == 0 and L.mlpg_hip_host_copy(None, src.ctypes.data, 8) == -1
+
+
+def test_cached_windows_follow_the_list():
+    from nnmnkwii_amd import _hip
+    w = [(0, 0, np.array([1.0])), (1, 1, np.array([-0.5, 0.0, 0.5]))]
+    a = _hip.cached_windows(w)
+    assert _hip.cached_windows(w) is a and a[3] == 2 and a[2].tolist() == [1.0, -0.5, 0.0, 0.5]
+    w[1][2][0] = -0.25                                   # edited in place: packed afresh
+    b = _hip.cached_windows(w)
+    assert b is not a and b[2].tolist() == [1.0, -0.25, 0.0, 0.5]
+    w.append((1, 1, np.array([1.0, -2.0, 1.0])))
+    c = _hip.cached_windows(w)
+    assert c[3] == 3 and _hip.cached_windows(w) is c
+    assert _hip.cached_windows(c) is c                   # already packed
+    wl = [(0, 0, [1.0]), (1, 0, (-1.0, 1.0))]            # plain sequences as coefficients
+    d = _hip.cached_windows(wl)
+    assert d[2].tolist() == [1.0, -1.0, 1.0] and _hip.cached_windows(wl) is d
+    wl[1] = (1, 0, (-2.0, 2.0))
+    assert _hip.cached_windows(wl)[2].tolist() == [1.0, -2.0, 2.0]
+    with pytest.raises(AssertionError):
+        _hip.cached_windows([(1, 1, np.array([1.0]))])
 
 
 def test_pack_windows():
@@ -206,7 +283,7 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, env=env)
     assert out.returncode == 0, out.stdout
-    assert out.stdout.split() == ["12", "5", "3"], out.stdout
+    assert out.stdout.split() == ["13", "5", "3"], out.stdout
 
 
 def test_host_chunk_plan_deals_round_robin_and_covers_the_batch():

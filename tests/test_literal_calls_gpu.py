@@ -1,0 +1,233 @@
+"""The LITERAL drop-in calls (-m gpu): one numpy -> numpy ``paramgen.mlpg(mean_frames (T, D), variance_frames, windows)``
+per utterance, as the reference's users write it (paramgen/_mlpg.py:92; the loop: util/__init__.py:56-66).
+
+Such a call is small -- 9.6 KB at BASELINE config 1, 2.9 MB at one config-2 utterance -- and takes the SHORT PATH of
+mlpg_hip_forward_host (csrc/host_api.hip forward_host_small: one stream, one pinned staging buffer, no thread, the kernel
+writing into pinned host memory, a polled sequence number).  Checked here: WHICH route a call takes (the library's call
+counters 10 / 11), parity of that route with the oracle in every variance mode / dtype / with lengths / at the edge
+lengths, the reference's exception for a failing pivot, that the per-list window cache follows in-place edits, growth of
+the cached buffers, and calls from two threads.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from cases import WINDOW_SETS
+from oracle import mlpg as O
+
+pytestmark = pytest.mark.gpu
+
+W = WINDOW_SETS["std3"]
+ROUTE_COPIED, ROUTE_DIRECT = 10, 11
+
+
+def _routes():
+    from nnmnkwii_amd import _hip
+    L = _hip.lib()
+    return int(L.mlpg_hip_launch_count(ROUTE_COPIED)), int(L.mlpg_hip_launch_count(ROUTE_DIRECT))
+
+
+def _rel(y, yo):
+    return float(np.abs(y - yo).max() / max(np.abs(yo).max(), 1e-300))
+
+
+def test_config1_call_takes_the_direct_route_and_matches_the_oracle():
+    """BASELINE config 1 as SURVEY 8(d) states it: means = rng.rand(100, 6), variances = rng.rand(6) tiled."""
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(1234)
+    m = rng.rand(100, 6)
+    vg = rng.rand(6)
+    v = np.tile(vg, (100, 1))
+    c0, d0 = _routes()
+    y = G.mlpg(m, v, W)
+    c1, d1 = _routes()
+    assert (c1 - c0, d1 - d0) == (0, 1)              # 9.6 KB: the kernel reads the pinned staging buffer itself
+    assert y.shape == (100, 2) and y.dtype == np.float64
+    assert _rel(y, O.mlpg(m, v, W)) <= 1e-12
+    yg = G.mlpg(m, vg, W)                            # global (D,) variances: the same trajectory
+    assert _rel(yg, O.mlpg(m, vg, W)) <= 1e-12
+    assert _routes() == (c1, d1 + 1)
+    # float32 in -> float32 out (the dtype of the means, _mlpg.py:166,183)
+    y32 = G.mlpg(m.astype(np.float32), v.astype(np.float32), W)
+    assert y32.dtype == np.float32 and _rel(y32, O.mlpg(m.astype(np.float32), v.astype(np.float32), W)) <= 2e-6
+
+
+def test_config2_utterance_takes_the_copied_route_and_matches_the_oracle():
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(7)
+    m = rng.randn(1000, 180)
+    v = rng.rand(1000, 180) + 0.1
+    c0, d0 = _routes()
+    y = G.mlpg(m, v, W)
+    assert _routes() == (c0 + 1, d0)                 # 2.9 MB: staged, copied to the device array by array
+    assert _rel(y, O.mlpg(m, v, W)) <= 1e-12
+    # the same utterance as a batch of one through mlpg_batch, and against the device-tensor entry point
+    import torch
+    from nnmnkwii_amd import _hip
+    yb = G.mlpg_batch(m[None], v[None], W)
+    assert np.array_equal(yb[0], y)
+    yd, st = _hip.forward(torch.from_numpy(m[None]).cuda(), torch.from_numpy(v[None]).cuda(), W)
+    assert int(st.abs().max()) == 0 and np.array_equal(yd[0].cpu().numpy(), y)
+    y32 = G.mlpg(m.astype(np.float32), v.astype(np.float32), W)
+    assert y32.dtype == np.float32 and _rel(y32, O.mlpg(m.astype(np.float32), v.astype(np.float32), W)) <= 2e-6
+
+
+def test_a_config2_batch_does_not_take_the_short_path():
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(3)
+    M_ = rng.randn(12, 500, 180)                      # 17 MB of means and variances: the chunked path
+    V_ = rng.rand(12, 500, 180) + 0.1
+    r0 = _routes()
+    y = G.mlpg_batch(M_, V_, W)
+    assert _routes() == r0
+    yo, _, rc = O.mlpg_batch(M_, V_, W)
+    assert rc == 0 and _rel(y, yo) <= 1e-12
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 17, 64, 100, 333])
+@pytest.mark.parametrize("sd", [1, 2, 25, 60])
+def test_short_path_edge_lengths_and_widths(T, sd):
+    """T = 1, 2: every dynamic precision is zeroed (_mlpg.py:191-193) and y equals the static means."""
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(100 * T + sd)
+    m = rng.randn(T, 3 * sd)
+    v = rng.rand(T, 3 * sd) + 0.05
+    r0 = _routes()
+    y = G.mlpg(m, v, W)
+    assert sum(_routes()) == sum(r0) + 1
+    yo = O.mlpg(m, v, W)
+    assert _rel(y, yo) <= 1e-12
+    if T <= 2:
+        assert np.allclose(y, m[:, :sd], rtol=1e-14, atol=0.0)      # (tau mu) / tau: the static means to the last bit or two
+
+
+@pytest.mark.parametrize("wname", ["std3", "wide3", "asym2"])
+@pytest.mark.parametrize("mode", ["frame", "global", "unit"])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_short_path_small_batches_with_lengths(wname, mode, dt):
+    """mlpg_batch on a small padded batch with ragged lengths (incl. 1 and the full length) and junk in the padding."""
+    from nnmnkwii_amd import paramgen as G
+    if wname not in WINDOW_SETS:
+        pytest.skip("no such window set in tests/golden/cases.py")
+    w = WINDOW_SETS[wname]
+    nw = len(w)
+    rng = np.random.RandomState(11)
+    B, T, sd = 5, 90, 7
+    M_ = rng.randn(B, T, nw * sd).astype(dt)
+    V_ = (rng.rand(B, T, nw * sd) + 0.1).astype(dt)
+    lengths = np.array([T, 1, 37, 2, 64], dtype=np.int32)
+    for b in range(B):
+        M_[b, lengths[b]:] = 1e30                     # the padding may hold anything
+    var = {"frame": V_, "global": V_[0, 0].copy(), "unit": None}[mode]
+    r0 = _routes()
+    y = G.mlpg_batch(M_, var, w, lengths)
+    assert sum(_routes()) == sum(r0) + 1
+    vo = var if var is not None else np.ones(nw * sd, dtype=dt)
+    yo, _, rc = O.mlpg_batch(M_, vo, w, lengths)
+    assert rc == 0 and y.dtype == dt
+    tol = 1e-10 if dt == np.float64 else 5e-6
+    for b in range(B):
+        n = lengths[b]
+        assert _rel(y[b, :n], yo[b, :n]) <= tol
+        assert not y[b, n:].any()                     # output frames beyond the length are zero
+
+
+def test_short_path_failing_pivot_raises_the_references_error():
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(5)
+    m = rng.randn(200, 6)
+    v = rng.rand(200, 6) + 0.1
+    v[57, 1] = -1e-3
+    with pytest.raises(np.linalg.LinAlgError) as e:
+        G.mlpg(m, v, W)
+    assert str(e.value) == "58-th leading minor not positive definite"   # linalg.pyx:79-82: k = first failing frame + 1
+    # ... and the next call is fine
+    v[57, 1] = 0.3
+    assert _rel(G.mlpg(m, v, W), O.mlpg(m, v, W)) <= 1e-12
+    with pytest.raises(AssertionError):
+        G.mlpg(m, v[:, :5], W)                        # shape mismatch: the reference's assert (_mlpg.py:171)
+
+
+def test_window_cache_follows_the_window_list():
+    """The packed window tables are remembered per list object; an edit of the list or of a coefficient array in place
+    must be seen by the next call."""
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(9)
+    m = rng.randn(120, 6)
+    v = rng.rand(120, 6) + 0.1
+    w = [(0, 0, np.array([1.0])), (1, 1, np.array([-0.5, 0.0, 0.5])), (1, 1, np.array([1.0, -2.0, 1.0]))]
+    y0 = G.mlpg(m, v, w)
+    assert _rel(y0, O.mlpg(m, v, w)) <= 1e-12
+    assert np.array_equal(G.mlpg(m, v, w), y0)
+    w[1][2][:] = [-0.25, 0.0, 0.25]                  # a coefficient array edited in place
+    y1 = G.mlpg(m, v, w)
+    assert _rel(y1, O.mlpg(m, v, w)) <= 1e-12 and not np.array_equal(y1, y0)
+    w[2] = (1, 1, np.array([0.5, -1.0, 0.5]))         # an entry replaced
+    y2 = G.mlpg(m, v, w)
+    assert _rel(y2, O.mlpg(m, v, w)) <= 1e-12 and not np.array_equal(y2, y1)
+    w.pop()                                          # two windows; D = 4
+    y3 = G.mlpg(m[:, :4], v[:, :4], w)
+    assert _rel(y3, O.mlpg(np.ascontiguousarray(m[:, :4]), np.ascontiguousarray(v[:, :4]), w)) <= 1e-12
+    # windows given as plain lists / tuples of numbers
+    wl = [(0, 0, [1.0]), (1, 1, (-0.5, 0.0, 0.5))]
+    assert np.array_equal(G.mlpg(m[:, :4], v[:, :4], wl), G.mlpg(m[:, :4], v[:, :4], [(0, 0, np.array([1.0])), (1, 1, np.array([-0.5, 0.0, 0.5]))]))
+
+
+def test_short_path_buffers_grow_and_shrinking_calls_reuse_them():
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(21)
+    for T, sd in ((10, 1), (900, 60), (40, 3), (1900, 60), (100, 2), (2000, 30), (5, 60)):
+        m = rng.randn(T, 3 * sd)
+        v = rng.rand(T, 3 * sd) + 0.1
+        r0 = _routes()
+        y = G.mlpg(m, v, W)
+        assert sum(_routes()) == sum(r0) + 1
+        assert _rel(y, O.mlpg(m, v, W)) <= 1e-12
+    # non-contiguous and non-float inputs behave as in the reference
+    m = rng.randn(64, 12)
+    v = rng.rand(64, 12) + 0.1
+    assert np.array_equal(G.mlpg(m[:, ::2], v[:, ::2], W), G.mlpg(np.ascontiguousarray(m[:, ::2]), np.ascontiguousarray(v[:, ::2]), W))
+    mi = (m * 10).astype(np.int64)
+    yi = G.mlpg(mi, v, W)
+    assert yi.dtype == np.int64 or yi.dtype == np.float64     # (the reference casts the result to the means' dtype)
+
+
+def test_the_loop_over_utterances_and_two_threads():
+    """[paramgen.mlpg(m, v, windows) for m, v in utterances] (util/__init__.py:56-66), then the same from two threads."""
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(31)
+    utts = [(rng.randn(T, 18), rng.rand(T, 18) + 0.1) for T in rng.randint(1, 400, size=40)]
+    want = [O.mlpg(m, v, W) for m, v in utts]
+    got = [G.mlpg(m, v, W) for m, v in utts]
+    assert max(_rel(a, b) for a, b in zip(got, want)) <= 1e-12
+    out = [None, None]
+
+    def run(k):
+        out[k] = [G.mlpg(m, v, W) for m, v in utts[k::2]]
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        assert all(np.array_equal(a, b) for a, b in zip(out[k], got[k::2]))
+
+
+def test_a_config2_utterance_call_is_faster_than_the_reference_by_a_wide_margin():
+    """Not a benchmark (tools/bench_paths.py --only lit is): a guard that the short path has not fallen back to something
+    slow -- one config-2 utterance takes the reference 2.9 ms on the box's host; the call must stay below 1 ms."""
+    import time
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(2)
+    m = rng.randn(1000, 180)
+    v = rng.rand(1000, 180) + 0.1
+    for _ in range(10):
+        G.mlpg(m, v, W)
+    ts = []
+    for _ in range(50):
+        t0 = time.perf_counter()
+        G.mlpg(m, v, W)
+        ts.append(time.perf_counter() - t0)
+    assert float(np.median(ts)) < 1e-3, np.median(ts)

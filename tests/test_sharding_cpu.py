@@ -138,3 +138,34 @@ def test_bench_self_launches_its_ranks():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
                            capture_output=True, text=True, timeout=120, env=env)
         assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+def test_bench_at_world_size_8_under_the_drivers_launcher():
+    """The driver's own command form for the 8-GPU leg -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...` -- as a gloo dry run: 8 ranks rendezvous, the barriers and
+    the max-over-ranks reduction run, the per-rank `secondary` entries (configs 4 and 5) are reduced to the slowest rank and to
+    whole-job rates, and rank 0 prints ONE line with n_gpus = 8."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--dry-run-cpu"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 alone prints
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["dry_run"] is True and len(res["per_rank_ms_per_step"]) == 8
+    assert res["scaling"] == "weak" and res["ms_per_step"] == max(res["per_rank_ms_per_step"])
+    sec = res["secondary"]
+    c4, c5 = sec["c4-fastdtw-kernel"], sec["c5-forward_streams-one-call"]
+    assert c4["ms_slowest_rank"] == 8.0 and c5["ms_slowest_rank"] == 16.0          # rank r reported 1 + r / 2 (1 + r) ms
+    assert abs(c4["pairs_per_s_whole_job"] - 8 * 128e3 / 8.0) < 1e-6               # 8 ranks' shares at the slowest rank's time
+    assert abs(c5["frames_per_s_whole_job"] - 8 * 512 * 2000e3 / 16.0) < 1e-3

@@ -3,6 +3,9 @@
 
     python tools/bench_paths.py [--quick]
 
+  lit : the LITERAL drop-in calls: one numpy -> numpy paramgen.mlpg per utterance at BASELINE config 1 and at one config-2
+        utterance, the reference's loop shape over 256 utterances, autograd.mlpg on CPU tensors, DTWAligner.transform on one
+        pair -- wall clock per call beside the reference's on the same host (litq: without the reference's 7 s mlpg_grad)
   c2h : config 2 end to end from host memory (numpy -> numpy), PCIe-inclusive wall clock
   c2g : config 2 with global (D,) variances and with unit variances (32 B per (frame, dim))
   c3  : autograd.unit_variance_mlpg forward+backward, B=64 x T=500 x 180, float32 tensors on the GPU
@@ -103,6 +106,137 @@ def fastdtw_window_cells(x, y, radius=1):
     return cells + tot
 
 
+def _wall_us(fn, n, warm=5):
+    """(median, min) wall-clock microseconds of one call of fn (host clock: these are host-memory calls)."""
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e6, float(np.min(ts)) * 1e6
+
+
+def literal_calls(emit, quick=False, long_reference_backward=True):
+    """The drop-in API exactly as `north_star` names it and as the reference's users call it: ONE numpy -> numpy
+    `paramgen.mlpg(mean_frames (T, D), variance_frames, windows)` per utterance (paramgen/_mlpg.py:92), in a Python loop
+    over utterances (util/__init__.py:56-66); `autograd.mlpg` on a CPU tensor; `DTWAligner.transform` on one pair.  Each
+    beside the reference's own time on this host (oracle/_ref: the reference compiled unmodified; the checker, timed) and
+    with the deviation from it.  Wall clock per call, everything included (staging, transfers, launch, synchronisation)."""
+    import torch
+    from nnmnkwii_amd import autograd as AF
+    from nnmnkwii_amd import paramgen as G
+    from nnmnkwii_amd.preprocessing.alignment import DTWAligner
+    from oracle import dtw as OD
+    from oracle import mlpg as O
+    from oracle import ref
+    Gref = ref.load() if ref.available() else None
+    ref_mlpg = Gref.mlpg if Gref is not None else O.mlpg
+    ref_kind = "reference (oracle/_ref)" if Gref is not None else "port (oracle/mlpg_oracle.c)"
+    rng = np.random.RandomState(1234)
+    n_small = 50 if quick else 300
+
+    def one(name, m, v, n):
+        y = G.mlpg(m, v, WINDOWS)
+        yr = ref_mlpg(m, v, WINDOWS)
+        err = float(np.abs(y - yr).max() / max(np.abs(yr).max(), 1e-300))
+        us, us_min = _wall_us(lambda: G.mlpg(m, v, WINDOWS), n)
+        rus, rus_min = _wall_us(lambda: ref_mlpg(m, v, WINDOWS), max(10, n // 5), warm=2)
+        emit(path=name, us_per_call=us, us_per_call_min=us_min, cpu_us_per_call=rus, cpu_us_per_call_min=rus_min, cpu_kind=ref_kind,
+             speedup_vs_cpu=rus / us, T=int(m.shape[0]), D=int(m.shape[1]), frames_per_s=m.shape[0] / us * 1e6,
+             rel_err_vs_cpu=err, out_dtype=str(y.dtype))
+
+    # BASELINE config 1: T = 100, 2 static dims, 3 windows (SURVEY 8(d): means = rng.rand(100, 6), vars = rng.rand(6) tiled)
+    m1 = rng.rand(100, 6)
+    v1g = rng.rand(6)
+    v1 = np.tile(v1g, (100, 1))
+    one("lit-c1-paramgen.mlpg-T100-sd2", m1, v1, n_small)
+    one("lit-c1-paramgen.mlpg-T100-sd2-global-variances", m1, v1g, n_small)
+    # one utterance of BASELINE config 2: T = 1000, 60 static dims, per-frame variances
+    m2 = rng.randn(1000, 180)
+    v2 = rng.rand(1000, 180) + 0.1
+    one("lit-c2utt-paramgen.mlpg-T1000-sd60", m2, v2, n_small)
+    m2f, v2f = m2.astype(np.float32), v2.astype(np.float32)
+    one("lit-c2utt-paramgen.mlpg-T1000-sd60-float32", m2f, v2f, n_small)
+    # the reference's loop shape over config 2: 256 utterances, one call each (distinct arrays: 5.8 MB per utterance)
+    nu = 64 if quick else 256
+    utts = [(rng.randn(1000, 180), rng.rand(1000, 180) + 0.1) for _ in range(nu)]
+    for m, v in utts[:8]:
+        G.mlpg(m, v, WINDOWS)
+    t0 = time.perf_counter()
+    ys = [G.mlpg(m, v, WINDOWS) for m, v in utts]
+    loop_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    yr = [ref_mlpg(m, v, WINDOWS) for m, v in utts[:32]]
+    ref_s = (time.perf_counter() - t0) * nu / 32
+    err = max(float(np.abs(a - b).max() / np.abs(b).max()) for a, b in zip(ys, yr))
+    t0 = time.perf_counter()
+    yb = G.mlpg_batch(np.stack([m for m, _ in utts]), np.stack([v for _, v in utts]), WINDOWS)
+    batch_s = time.perf_counter() - t0
+    assert np.array_equal(yb[3], ys[3]) or float(np.abs(yb[3] - ys[3]).max()) < 1e-12
+    emit(path="lit-c2-loop-per-utterance-calls", utterances=nu, ms=loop_s * 1e3, us_per_call=loop_s / nu * 1e6, frames_per_s=nu * 1000 / loop_s,
+         cpu_ms=ref_s * 1e3, cpu_kind=ref_kind + ", 32 utterances timed, scaled", speedup_vs_cpu=ref_s / loop_s, rel_err_vs_cpu=err,
+         ms_one_mlpg_batch_call_incl_stacking=batch_s * 1e3,
+         note="[paramgen.mlpg(m, v, windows) for m, v in utterances]: the reference's own loop shape (util/__init__.py:56-66), numpy in, numpy out")
+    del utts, ys, yr, yb
+    # autograd.mlpg on CPU tensors (the reference's tensors are CPU tensors: autograd/_impl/mlpg.py:50-67), forward + backward
+    for name, T, sd, nrep in (("lit-c1-autograd.mlpg-cpu-tensor-T100-sd2", 100, 2, n_small), ("lit-c2utt-autograd.mlpg-cpu-tensor-T1000-sd60", 1000, 60, 30)):
+        torch.manual_seed(1234)
+        mt = torch.rand(T, 3 * sd, requires_grad=True)
+        vt = torch.rand(T, 3 * sd) + 0.1
+
+        def fb():
+            mt.grad = None
+            AF.mlpg(mt, vt, WINDOWS).sum().backward()
+
+        us_f, _ = _wall_us(lambda: AF.mlpg(mt.detach(), vt, WINDOWS), nrep)
+        us_fb, _ = _wall_us(fb, nrep)
+        mn, vn = mt.detach().numpy(), vt.numpy()
+
+        class RefMLPG(torch.autograd.Function):
+            # what the reference's node does (autograd/_impl/mlpg.py:50-67): paramgen.mlpg / mlpg_grad on .numpy() views
+            @staticmethod
+            def forward(ctx, means, variances):
+                ctx.save_for_backward(means, variances)
+                return torch.from_numpy(ref_mlpg(means.detach().numpy(), variances.detach().numpy(), WINDOWS))
+
+            @staticmethod
+            def backward(ctx, go):
+                means, variances = ctx.saved_tensors
+                return torch.from_numpy(Gref.mlpg_grad(means.detach().numpy(), variances.detach().numpy(), WINDOWS, go.numpy())), None
+
+        rus_f, _ = _wall_us(lambda: RefMLPG.apply(mt.detach(), vt), 10, warm=1)
+        rus_b = None
+        if Gref is not None and (T <= 100 or (long_reference_backward and not quick)):
+            go = np.ones((T, sd), dtype=np.float32)
+            t0 = time.perf_counter()
+            gr = Gref.mlpg_grad(mn, vn, WINDOWS, go)
+            rus_b = (time.perf_counter() - t0) * 1e6
+            fb()
+            gerr = float(np.abs(mt.grad.numpy() - gr).max())
+        else:
+            gerr = None
+        emit(path=name, us_forward=us_f, us_forward_backward=us_fb, cpu_us_forward=rus_f, cpu_us_backward_mlpg_grad=rus_b,
+             cpu_kind=ref_kind + " inside a torch.autograd.Function, as the reference's node calls it",
+             grad_abs_err_vs_cpu=gerr, T=T, D=3 * sd)
+    # DTWAligner.transform on ONE pair (alignment.py:41-76 is a per-pair loop)
+    a, b = 812, 777
+    X = np.zeros((1, 900, 25))
+    Y = np.zeros((1, 900, 25))
+    X[0, :a] = np.cumsum(rng.randn(a, 25), 0) * 0.1
+    Y[0, :b] = np.cumsum(rng.randn(b, 25), 0) * 0.1
+    al = DTWAligner()
+    Xa, Ya = al.transform((X, Y))
+    Xo, Yo = OD.dtw_align(X, Y, 1, use_c=True)[:2]
+    same = bool(np.array_equal(Xa, Xo) and np.array_equal(Ya, Yo))
+    us, us_min = _wall_us(lambda: al.transform((X, Y)), 50 if quick else 200)
+    cus, _ = _wall_us(lambda: OD.dtw_align(X, Y, 1, use_c=True), 10, warm=1)
+    emit(path="lit-dtw-DTWAligner.transform-one-pair", us_per_call=us, us_per_call_min=us_min, cpu_us_per_call=cus,
+         cpu_kind="oracle/dtw_oracle.c through oracle/dtw.py dtw_align (C restatement of fastdtw; the reference's pure-Python fastdtw package is absent)",
+         aligned_arrays_equal_oracle=same, Tx=a, Ty=b, D=25)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -186,6 +320,29 @@ def _run(only, quick, device_index):
         ms = gpu_time(lambda: _hip.forward(m2, v2, WINDOWS, algo=3, want_status=False), steps=5)
         emit(path="long-T4000-forward-tight-dynamic-variances-strip", ms=ms, frames_per_s=B2 * T2 / ms * 1e3, alg_bytes=by2, GBps=by2 / ms / 1e6)
         del m, v, x, m2, v2
+
+    # ---- c2t: the config-2 shape with TIGHT dynamic variances through AUTO (the strip kernel's slower level-3 rungs) ----
+    # Variances as acoustic models have them: the dynamic features 10 x - 1000 x tighter than the static ones.  The trajectory is
+    # then smooth over hundreds of frames; the strip kernel's 3-strip level-3 window is rejected by its damping bound and the
+    # strips climb the ladder (5 / 9 / 33 strips, the whole utterance).  bench.py's metric data (variances ~ U(0.1, 1.1) in all
+    # three windows) never leaves the 3-strip window: these entries put the other rungs into the driver's record.
+    if want("c2t"):
+        B, T, sd = 256, 1000, 60
+        m = torch.randn(B, T, 3 * sd, dtype=torch.float64, device=dev, generator=gen)
+        v = torch.rand(B, T, 3 * sd, dtype=torch.float64, device=dev, generator=gen) + 0.1
+        by = 56.0 * sd * B * T
+        for name, s1, s2 in (("10x-100x", 1e-1, 1e-2), ("100x-1000x", 1e-2, 1e-3)):
+            vt = v.clone()
+            vt[:, :, sd:2 * sd] *= s1
+            vt[:, :, 2 * sd:] *= s2
+            ms = gpu_time(lambda: _hip.forward(m, vt, WINDOWS, want_status=False), steps=20)
+            y, st = _hip.forward(m, vt, WINDOWS)
+            yo = O.mlpg(m[B - 1].cpu().numpy(), vt[B - 1].cpu().numpy(), WINDOWS)
+            err = float(np.abs(y[B - 1].cpu().numpy() - yo).max() / np.abs(yo).max())
+            emit(path="c2t-forward-dynamic-variances-tighter-" + name, ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by, GBps=by / ms / 1e6,
+                 status_max=int(st.abs().max().item()), rel_err_vs_oracle_last_utterance=err)
+            del vt
+        del m, v
 
     # ---- c2g: global / unit variances ----
     if want("c2g"):
@@ -272,6 +429,10 @@ def _run(only, quick, device_index):
              GBps=by / wall / 1e9, note="pinned inputs, pageable output: PCIe floor 12.9 ms (737 MB up at 57 GB/s, the 123 MB down overlapped); median of 6 calls into fresh output pages")
         yh = None
         del mh, vh, yh, mp, vp
+
+    # ---- lit: the LITERAL drop-in calls -- one numpy -> numpy call per utterance, as a user of the reference writes them ----
+    if want("lit") or want("litq"):
+        literal_calls(emit, quick=args.quick, long_reference_backward=want("lit"))
 
     # ---- c2b: backward (mlpg_hip_backward) at config-2 scale, float64 and float32 ----
     if want("c2b"):
