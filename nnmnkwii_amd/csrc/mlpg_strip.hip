@@ -103,7 +103,7 @@ void strip_scratch_forget(hipStream_t st, int device) {
 }
 // scratch (control words + records) of one launch and whether its control area is known to be zero already
 void *strip_scratch(hipStream_t st, int device, size_t nsg, int R, bool *zero_ctrl) {
-  const size_t ctrl = (((1 + 16 + nsg) * 32 + nsg * (size_t)((R + 31) / 32 * 32) + 2048) * sizeof(int) + 255) / 256 * 256;  // >= strip::ctrl_bytes
+  const size_t ctrl = (((1 + 16 + nsg) * 32 + nsg * (size_t)((R + 31) / 32 * 32)) * sizeof(int) + 255) / 256 * 256;  // >= strip::ctrl_bytes
   unsigned long long gen = 0;
   void *sc = scratch(device, st, 3, ctrl + nsg * R * kRecBytes, &gen);
   if (!sc) return nullptr;

@@ -152,14 +152,12 @@ constexpr int kCtrlLine = 32;
 #define MLPG_STRIP_RING_F64 6
 #endif
 #ifndef MLPG_STRIP_STAGGER_DEFAULT_US
-#define MLPG_STRIP_STAGGER_DEFAULT_US 0  // span of the start ramp in microseconds (see launch_impl); MLPG_STRIP_STAGGER_US overrides it at run time
+#define MLPG_STRIP_STAGGER_DEFAULT_US 0  // span of the start ramp in microseconds (see launch_impl); MLPG_STRIP_STAGGER_US overrides it at run time.
+                                         // Off: 20 us is worth -2.4 % on config 2's forward pass (variances of one order of magnitude: the 3-strip
+                                         // window) but costs +3 % where the strips wait for whole utterances (dynamic variances 100 x tighter, the
+                                         // usual case for unnormalised acoustic features) and +3 % on the float32 backward (profiles/r06_notes.md)
 #endif
-#ifndef MLPG_STRIP_DMA
-#define MLPG_STRIP_DMA 0  // round 6 experiment: the LAST n frames of a chunk (of its kM + 2) arrive by LDS-DMA (buffer_load ... lds, no
-                          // registers), requested in the prologue beside the register ring's first frames -- the LDS is idle during
-                          // level 1 -- so that 12 instead of 6 frames are in flight per wavefront from the start; forward, three
-                          // windows, one dim group, dense rows, interior chunks
-#endif
+
 #ifndef MLPG_STRIP_ROUTE1_TOL
 #define MLPG_STRIP_ROUTE1_TOL 0x1p-66  // own transfer factor below which the 3-strip window is tried first (0: never), see kDamp1Tol
 #endif
@@ -208,11 +206,9 @@ __device__ __forceinline__ int row_of(const Order &o, int pos) {
   return o.r;
 }
 __host__ __device__ inline int flag_pitch(int R) { return (R + kCtrlLine - 1) / kCtrlLine * kCtrlLine; }
-constexpr int kCuKeys = 2048;  // (XCC_ID, SE_ID, SH_ID, CU_ID) of HW_REG_HW_ID: one word per compute unit, see Args::pair
-__host__ __device__ inline size_t cu_table_off(int nsg, int R) {
+__host__ __device__ inline size_t ctrl_ints(int nsg, int R) {
   return (size_t)(1 + kMaxLists + nsg) * kCtrlLine + (size_t)nsg * flag_pitch(R);
 }
-__host__ __device__ inline size_t ctrl_ints(int nsg, int R) { return cu_table_off(nsg, R) + kCuKeys; }
 
 struct Args {
   int *ctrl;
@@ -231,8 +227,6 @@ struct Args {
   StreamMap sm;  // MULTI kernels only: the streams whose static dims sit side by side on the lanes
   int stagger;   // start ramp: the workgroup that draws ticket tk < wpl of a list as its FIRST item starts it tk * stagger / wpl ticks
   int wpl;       // (100 MHz) late; wpl = workgroups per list.  0: everybody starts at once.  See launch_impl.
-  int throttle;  // > 0: at most this many workgroups of an XCD are in their load phase (level 1) at a time (round 6 experiment)
-  int pair;      // > 0: the two workgroups of a CU take turns at level 1 when their utterances have different colours (see launch_impl)
 };
 
 // Ticket tk of work list lst -> (system group, strip).  The lists hold whole blocks of consecutive strips in the order of
@@ -670,20 +664,13 @@ struct RingDepth<float> { static constexpr int value = MLPG_STRIP_RING_F32; };  
 // LT (the transposed form with a lengths vector): T is the frame count of the lane group's LONGEST utterance -- what the clamped loads
 // and everything wave-uniform go by -- and Tu this lane's own: its dead frames enter with precision 0 and mean 0 by per-lane
 // SELECTS (their values are padding: anything), its rows >= Tu become identity rows.
-template <typename TIN, bool BWD, int VM, bool EDGE, int NW, bool MULTI = false, bool KEEP = false, bool LT = false, int DMA = 0>
+template <typename TIN, bool BWD, int VM, bool EDGE, int NW, bool MULTI = false, bool KEEP = false, bool LT = false>
 __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, __amdgpu_buffer_rsrc_t vrs,
                                                    __amdgpu_buffer_rsrc_t grs, const TIN *__restrict__ vglob,
                                                    unsigned loff, long ldi, long ldg, int sd, int f0, int T, int mw,
                                                    const double (*wc)[9], const double one, double (&Pd)[kM], double (&P1)[kM],
                                                    double (&P2)[kM], double (&rhs)[kM], double &ca, double &cb,
-                                                   double &cc, double (&rec)[kRec], float (&tk)[kM + 1][NW], const int Tu = 0,
-                                                   unsigned char *zone = nullptr) {
-  static_assert(DMA == 0 || (!EDGE && !MULTI && !LT && !BWD && DMA <= kM + 2 - RingDepth<TIN>::value), "LDS-DMA frames: interior forward chunks, behind the ring's first frames");
-  // DMA > 0: frames kM + 1 - DMA .. kM of the chunk (the last DMA ones) are copied into this wavefront's LDS zone -- an image of
-  // the rows as they lie in memory (dense rows: a frame's NW windows are contiguous, and so are consecutive frames): means at
-  // zone, variances behind them.  Requested right behind the ring's first frames; read back with ds_read where the ring would
-  // have been refilled with them.  (The copies are older than every refill: a refill that has landed implies they have.)
-  constexpr int kDmaFirst = kM + 1 - DMA;  // frame index (f0 + i) of the first copied frame
+                                                   double &cc, double (&rec)[kRec], float (&tk)[kM + 1][NW], const int Tu = 0) {
   // KEEP (backward, float32 inputs): tk[i + 1][w] = the precision of frame f0 + i in window w as the assembly used it
   // (dead frames 0), i = -1 .. kM-1: what the epilogue multiplies the gradient rows with
   // No zero-fill: every accumulator is ASSIGNED by the first contribution that reaches it (window 0 of the frame
@@ -718,15 +705,6 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
     // were the placed coefficient loads -- karg_f64x6 -- this alone did not.)
     unsigned frame_off = (unsigned)(f0 + i) * ldi_bytes;
     if (BWD && !EDGE) asm volatile("" : "+s"(frame_off));
-    if (DMA > 0 && i >= kDmaFirst) {
-      const unsigned zb = (unsigned)(i - kDmaFirst) * ldi_bytes;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        m[w] = *(const TIN *)(zone + zb + (unsigned)w * win_bytes + loff);
-        if (VM == MLPG_HIP_VAR_FRAME) v[w] = *(const TIN *)(zone + (unsigned)DMA * ldi_bytes + zb + (unsigned)w * win_bytes + loff);
-      }
-      return;
-    }
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       int t = f0 + i;
@@ -858,18 +836,6 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
 #pragma unroll
   for (int sl = 0; sl < kRing; ++sl) load_frame(rv[sl], rm[sl], sl - 1);
   static_assert(kRing >= 2 && kRing <= kM + 2, "ring depth");
-  if (DMA > 0) {
-    // 16 bytes per lane and instruction, 1 KB per instruction; LDS address = zone + k KB + lane * 16 (wave-uniform base + lane x size)
-    const unsigned total = (unsigned)DMA * ldi_bytes, src0 = (unsigned)(f0 + kDmaFirst) * ldi_bytes;
-    const unsigned l16 = (unsigned)(threadIdx.x & 63) * 16u;
-    typedef __attribute__((address_space(3))) void lds_void;
-    for (unsigned off = 0; off < total; off += 1024u) {
-      if (off + l16 < total) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(mrs, (lds_void *)(zone + off), 16, off + l16, src0, 0, 0);
-        if (VM == MLPG_HIP_VAR_FRAME) __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void *)(zone + total + off), 16, off + l16, src0, 0, 0);
-      }
-    }
-  }
   if (BWD) {
 #pragma unroll
     for (int i = 0; i < kM; ++i) {
@@ -974,31 +940,6 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   // traffic is agent scope), only for speed.
   const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;  // hwreg(HW_REG_XCC_ID, 0, 4)
   const int R = a.R;
-  // the load-phase token of this workgroup (Args::throttle): word 16 of its XCD's ticket line; held from the ticket draw to the
-  // barrier behind level 1
-  int *const load_tokens = a.ctrl + (1 + (xcd % kMaxLists)) * kCtrlLine + 16;
-  bool token_held = false;  // (thread 0's business)
-  auto token_release = [&]() __attribute__((always_inline)) {
-    if (tid == 0 && token_held) {
-      (void)__hip_atomic_fetch_add(load_tokens, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      token_held = false;
-    }
-  };
-  // The CU's level-1 turn (Args::pair): one word per compute unit, low half = workgroups of colour 0 in level 1, high half = of
-  // colour 1.  Advisory only: a workgroup that does not get its turn within the bounded wait goes ahead anyway.
-  int *cu_word = nullptr;
-  if (a.pair > 0) {
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID: CU_ID 11:8, SH_ID 12, SE_ID 15:13
-    const int key = (xcd << 8) | (int)(((hw >> 13) & 7u) << 5) | (int)(((hw >> 12) & 1u) << 4) | (int)((hw >> 8) & 15u);
-    cu_word = a.ctrl + cu_table_off(a.nsg, a.R) + (key & (kCuKeys - 1));
-  }
-  int turn_held = 0;  // what this workgroup added to its CU's word (thread 0's business)
-  auto turn_release = [&]() __attribute__((always_inline)) {
-    if (tid == 0 && turn_held) {
-      (void)__hip_atomic_fetch_add(cu_word, -turn_held, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      turn_held = 0;
-    }
-  };
   auto body = [&](const int g, const int r) __attribute__((always_inline)) {
   // (TR: group g = the block of utterances b .. b + tr_u - 1, one dim group)
   const int b = TR ? g * a.sm.tr_u : g / a.ndg, dg = TR ? 0 : g - b * a.ndg;
@@ -1150,14 +1091,7 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
         karg_f64x9<kKargWc + 2 * 72>(wcl[2]);
         wcs = wcl;
       }
-      constexpr int kDma = (!BWD && !MULTI && MLPG_STRIP_DMA > 0) ? MLPG_STRIP_DMA : 0;
-      // (dense rows of one dim group whose copied range is a whole number of 16-byte pieces; the zones of the kW wavefronts fit the LDS)
-      const bool dma_ok = kDma > 0 && a.ndg == 1 && ldi == 3 * (long)sd && ((unsigned)kDma * (unsigned)ldi * (unsigned)sizeof(TIN)) % 16u == 0 &&
-                          (size_t)kW * 2 * kDma * (size_t)ldi * sizeof(TIN) <= kLdsBytes - kLdsMisc;
-      if (interior && dma_ok)
-        bad = assemble_eliminate<TIN, BWD, VM, false, 3, MULTI, kKeepTau, false, kDma>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, wcs, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec, tk, 0,
-                                                                                     smem + (size_t)wv * 2 * kDma * (size_t)ldi * sizeof(TIN));
-      else if (interior) bad = assemble_eliminate<TIN, BWD, VM, false, 3, MULTI, kKeepTau>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, wcs, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec, tk);
+      if (interior) bad = assemble_eliminate<TIN, BWD, VM, false, 3, MULTI, kKeepTau>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, wcs, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec, tk);
       else bad = assemble_eliminate<TIN, BWD, VM, true, 3, MULTI, kKeepTau, TR>(mrs, vrs, grs, vglob, loff, ldi, ldg, sd, f0, T, mw, wcs, a.one, Pd, P1, P2, rhs, ca, cb, cc, rec, tk, Tu);
       STRIP_TICK(1);
 #ifdef MLPG_STRIP_TRACE
@@ -1193,15 +1127,12 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
     }
   }
   if (bad) rec[rD11] = __builtin_nan("");  // poisons every later level: the system is reported, not solved
-  if (!BWD && !MULTI && MLPG_STRIP_DMA > 0) __syncthreads();  // the records land where other wavefronts' copied frames lie: those have been read
 #pragma unroll
   for (int k = 0; k < kRec; ++k) lds_rec[(wv * kRec + k) * 64 + lane] = rec[k];
   if (kEarly > 0 && wv != 0) early_issue();  // (wavefront 0: behind level 3 -- its chain has no registers to spare)
   STRIP_TICK(2);
   __syncthreads();
   STRIP_TICK(3);
-  if (a.throttle > 0) token_release();  // every wavefront's frames have landed
-  if (a.pair > 0) turn_release();
 
   // ---- levels 2 and 3.  Wavefront 0 runs the sequential parts (the strip's separators, then the sweep over
   // the utterance's records); wavefronts 1..3 stage the records for it.  The two roles are separate code paths
@@ -1846,8 +1777,9 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   if (!kSplitTail) tail(std::false_type{}, std::integral_constant<int, kEarly>{});
   };  // body
 
-  // (Starting the second workgroup of each CU half an item late was measured in round 2 -- no gain: two workgroups per CU that draw
-  // tickets desynchronise by themselves -- and removed in round 5.)
+  // (Starting the second workgroup of each CU half an item late was measured in round 2 -- no gain -- and removed in round 5; round 6's
+  // trace shows why: whatever the start, the workgroups of an utterance's strips re-align within two items.  See the start ramp in
+  // launch_impl for the part of a staggered start that does pay.)
   bool first_item = true;
   const long long t_launch = (long long)__builtin_amdgcn_s_memrealtime();
   for (int k = 0; k < a.nlists; ++k) {
@@ -1864,31 +1796,9 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
         if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lim) tk = atomicAdd(ticket, 1);
         if (first_item && a.stagger > 0 && tk < a.wpl && tk < lim) {
           // the start ramp (round 6): the first-round workgroups of a list start their first item spread over `stagger` ticks in
-          // ticket order, so that from then on the same share of them is loading at any time (see launch_impl)
+          // ticket order, so that the launch does not open with every workgroup loading at once (see launch_impl)
           const long long until = t_launch + (long long)tk * a.stagger / a.wpl;
           while ((long long)__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
-        }
-        if (a.throttle > 0 && tk < lim) {
-          // a load-phase token: a look first, then the claim; given back if the claim overshot (bounded: after 2^16 looks the
-          // workgroup loads anyway)
-          for (int spins = 0; spins < (1 << 16); ++spins) {
-            if (__hip_atomic_load(load_tokens, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.throttle) {
-              if (atomicAdd(load_tokens, 1) < a.throttle) { token_held = true; break; }
-              (void)__hip_atomic_fetch_add(load_tokens, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __builtin_amdgcn_s_sleep(16);
-          }
-        }
-        if (a.pair > 0 && tk < lim) {
-          // colour = parity of the utterance's place in its list; wait (bounded) while workgroups of the other colour are in level 1 here
-          const int colour = (tk / a.bs) & 1, mine = colour ? 0x10000 : 1, theirs = colour ? 0xffff : ~0xffff;
-          for (int spins = 0;; ++spins) {
-            const int old = atomicAdd(cu_word, mine);
-            if (!(old & theirs) || spins >= a.pair) { turn_held = mine; break; }
-            (void)__hip_atomic_fetch_add(cu_word, -mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_s_sleep(20);
-            while ((__hip_atomic_load(cu_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & theirs) && ++spins < a.pair) __builtin_amdgcn_s_sleep(20);
-          }
         }
         lds_misc[0] = tk;
       }
@@ -1903,8 +1813,6 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
       int g_it, r_it;
       ticket_item<MULTI>(a, tk, lst, g_it, r_it);
       if (r_it < R) body(g_it, r_it);  // (the last block of a long utterance may be short: tickets past its end are nobody's)
-      if (a.throttle > 0) token_release();  // (an item that returned before its level 1)
-      if (a.pair > 0) turn_release();
       __syncthreads();
     }
     __syncthreads();
@@ -1928,10 +1836,8 @@ __global__ void __launch_bounds__(256) verdict_kernel(const Problem p, const Win
   __builtin_amdgcn_wave_barrier();
   if (lane < 5) line[lane] = 0;
   for (int i = lane; i < flag_pitch(a.R); i += 64) a.ctrl[(1 + kMaxLists + a.nsg) * kCtrlLine + (size_t)g * flag_pitch(a.R) + i] = 0;
-  if (g == 0) {
+  if (g == 0)
     for (int i = lane; i < (1 + kMaxLists) * kCtrlLine; i += 64) a.ctrl[i] = 0;
-    for (int i = lane; i < kCuKeys; i += 64) a.ctrl[cu_table_off(a.nsg, a.R) + i] = 0;
-  }
   if (m == 0ull) return;
   const int b = TR ? g * a.sm.tr_u : g / a.ndg, dg = TR ? 0 : g - b * a.ndg;
   const int d0 = dg * a.dgw;
@@ -2064,28 +1970,25 @@ int launch_impl(hipStream_t st, const Problem &p, const WinSet &ws, void *scratc
       static const long capg = [] { const char *e = getenv("MLPG_STRIP_GRID_CAP"); return e ? atol(e) : 0L; }();
       if (capg >= 16 * kMaxLists && capg < grid && R <= capg / (2 * kMaxLists)) grid = capg;
     }
-    // The start ramp.  Workgroups that start together stay together: a strip waits for its neighbours' records, so the workgroups
-    // that drew consecutive tickets finish their items together and draw the next ones together -- the in-kernel trace of round 6
-    // (tools/dbg/strip_trace.py) shows all 512 loading for the first 12 us, then none for 5 us, and the count swinging between
-    // 80 and 330 with a period of 26-28 us to the end of the launch: the memory system is overrun and idle in turns.  Spreading the
-    // FIRST items of a list's workgroups over about one item period in ticket order (neighbouring strips then start a fraction of a
-    // microsecond apart, which the wait for the right-hand neighbour absorbs) keeps the same share of workgroups loading at any
-    // time.  Only launches that give every workgroup several items.  MLPG_STRIP_STAGGER_US overrides the span (0: off).
+    // The start ramp (round 6).  Left alone all 512 workgroups load their first item at once: the in-kernel trace
+    // (tools/dbg/strip_trace.py, profiles/r06_strip_trace_*.txt) shows 512 of them loading for the first 12 us -- the memory system
+    // overrun -- and then none at all for 5 us while every one of them runs its level-2/3 chain.  Spreading the FIRST items of a
+    // list's workgroups over about one item period in ticket order (neighbouring strips then start a fraction of a microsecond
+    // apart, which the wait for the right-hand neighbour absorbs) removes that first pile-up: config 2 under bench.py's protocol,
+    // interleaved, nine pairs: 0.2137-0.2166 -> 0.2098-0.2115 ms per step (-2.1 %) at 16 / 20 / 24 us alike -- but where every strip
+    // waits for its whole utterance (tight dynamic variances) a late start is only late: 0.257 -> 0.265 ms, and the float32 backward
+    // loses 3 % as well, so the ramp ships switched off (MLPG_STRIP_STAGGER_DEFAULT_US).  It does NOT keep the
+    // workgroups apart: a strip waits for its neighbours' records, so the workgroups that hold an utterance's strips finish together
+    // and draw their next tickets together, and by the third item the loading count swings between 80 and 330 again (period 26-28
+    // us, autocorrelation 0.6-0.8) as it does without the ramp.  Measured against that and not kept (profiles/r06_notes.md): a cap
+    // on the workgroups of an XCD that may be in level 1 at a time (12-40 % slower: the waits add up along an utterance), the two
+    // workgroups of a CU taking turns at level 1 (no gain), a chunk's last six frames by LDS-DMA (no gain: level 1 is not short of
+    // bytes in flight).  Only launches that give every workgroup several items.  MLPG_STRIP_STAGGER_US overrides the span (0: off).
     a.stagger = 0;
     a.wpl = (int)(grid / a.nlists);
     {
       static const double us = [] { const char *e = getenv("MLPG_STRIP_STAGGER_US"); return e ? atof(e) : (double)MLPG_STRIP_STAGGER_DEFAULT_US; }();
       if (us > 0 && a.wpl >= 2 && nitems >= 3 * grid) a.stagger = (int)(us * 100.0);
-    }
-    a.pair = 0;
-    {
-      static const int pair_ = [] { const char *e = getenv("MLPG_STRIP_PAIR"); return e ? atoi(e) : 0; }();
-      if (pair_ > 0 && a.nlists == kMaxLists && a.nb == 1 && !MULTI && nitems >= 3 * grid) a.pair = pair_;
-    }
-    a.throttle = 0;
-    {
-      static const int cap_ = [] { const char *e = getenv("MLPG_STRIP_THROTTLE"); return e ? atoi(e) : 0; }();
-      if (cap_ > 0 && a.nlists == kMaxLists && nitems >= 3 * grid) a.throttle = cap_;
     }
     note_launch(TR ? kCountStripTr : MULTI ? kCountStripMulti : kCountStrip);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kW * 64), kLdsBytes, st, p, ws, a);
