@@ -309,7 +309,10 @@ def main():
     import torch
     import torch.distributed as dist
     dry = args.dry_run_cpu
-    if world > 1:
+    # the process group (and with it every barrier, reduction and gather below) also at world size 1 when the launcher's environment is
+    # there and NNMNKWII_BENCH_FORCE_DIST=1: how a one-GPU box runs the RCCL path of the N > 1 legs (tests/test_host_multi_gpu.py)
+    use_dist = world > 1 or (os.environ.get("NNMNKWII_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
@@ -317,7 +320,7 @@ def main():
     D = 3 * sd
     if dry:
         dev = torch.device("cpu")
-        if world > 1:
+        if use_dist:
             dist.init_process_group("gloo")
         out = status = None
 
@@ -332,7 +335,7 @@ def main():
             sys.exit("bench.py: rank %d has no GPU (device_count = %d)" % (rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        if world > 1:
+        if use_dist:
             dist.init_process_group("nccl", device_id=dev)
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         means = torch.randn(B, T, D, dtype=torch.float64, device=dev, generator=gen)
@@ -345,7 +348,7 @@ def main():
             torch.cuda.synchronize(dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             if dry:
                 dist.barrier()
             else:
@@ -417,7 +420,7 @@ def main():
         c_el, c_km, _, _ = timed(args.steps)
         barrier()
         tc = torch.tensor([c_el], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_dist:
             allc = [torch.zeros_like(tc) for _ in range(world)]
             dist.all_gather(allc, tc)
             c_el = max(float(x.item()) for x in allc)
@@ -491,14 +494,14 @@ def main():
 
     per_rank = [elapsed]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         per_rank = [float(x.item()) for x in allt]
     elapsed = max(per_rank)
 
     gather_ms = None
-    if args.gather and world > 1 and not dry:
+    if args.gather and use_dist and not dry:
         full = torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=dev)
         dist.all_gather_into_tensor(full, out)
         sync()
@@ -637,7 +640,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not dry:
             res["cpu_baseline"] = cpu_baseline(T, D, args.cpu_seconds)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

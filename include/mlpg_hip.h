@@ -60,8 +60,8 @@ extern "C" {
 #define MLPG_HIP_ALGO_STRIP 3   /* lane-per-static-dim, wavefront per 16-frame chunk, any T.  A stream of 1 .. 32 static dims (forward,
                                    three windows): the lanes of a wavefront run over
                                    64 / dims consecutive utterances x the dims instead (the transposed form, round 5) */
-#define MLPG_HIP_ALGO_PIPE 4    /* retired in ABI 11 (the software-pipelined strip kernel of round 3, now under
-                                   tools/experimental/pipe): selects the strip kernel */
+#define MLPG_HIP_ALGO_PIPE 4    /* retired in ABI 11 (the software-pipelined strip kernel of round 3; its sources left the tree in
+                                   round 6 and are in the git history under tools/experimental/pipe): selects the strip kernel */
 #define MLPG_HIP_ALGO_CONST 5   /* global (D,) / unit variances: the matrix of a static dim is the same for every
                                    utterance (_mlpg.py:169-170 tiles the variances) -- factorised once per launch, the
                                    solves are constant-coefficient recurrences, lane-per-static-dim, any T */
@@ -79,7 +79,8 @@ const char *mlpg_hip_last_error(void);
  * 0 natural-order, 1 wave-per-system, 2 strip, 3 strip with several streams merged, 4 constant-coefficient, 5 fused, 6 chunked, 7 FIR,
  * 8 constant-coefficient with several streams merged, 9 strip in its transposed form (narrow streams: the lanes over several
  * utterances); and, counting CALLS rather than launches, 10 host-memory calls that took the short path with their inputs copied to the
- * device, 11 with the kernel reading the pinned staging buffer itself (see mlpg_hip_forward_host); -1 for any other `kind`.
+ * device, 11 with the kernel reading the pinned staging buffer itself (see mlpg_hip_forward_host); 100 + d: chunks the chunked
+ * host-memory calls (mlpg_hip_forward_host_multi / mlpg_hip_fastdtw_host_multi) have enqueued on device d; -1 for any other `kind`.
  * (Tests use it to assert WHICH kernel / route a call took.) */
 long long mlpg_hip_launch_count(int kind);
 int mlpg_hip_device_count(void);

@@ -212,7 +212,7 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     return rc;
   }
   if (algo == MLPG_HIP_ALGO_PIPE) {
-    // retired (tools/experimental/pipe): the strip scheme it pipelined, or the kernel AUTO would take
+    // retired (round 3's software-pipelined kernel; in the history up to round 5: tools/experimental/pipe): the strip scheme it pipelined, or the kernel AUTO would take
     algo = strip_supported(p, ws) ? MLPG_HIP_ALGO_STRIP : MLPG_HIP_ALGO_AUTO;
   }
   // (the FIR form first: float32 unit variances without lengths -- it has no chain at all; not for a piece of a stream)
@@ -365,6 +365,7 @@ bool stream_takes_tr(int dtype, int algo, const void *mean, const void *var, int
 }
 
 }  // namespace
+long long host_chunks_on_device(int device);  // host_api.hip
 }  // namespace mlpg
 
 using namespace mlpg;
@@ -374,6 +375,7 @@ extern "C" {
 __attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 13; }
 
 __attribute__((visibility("default"))) long long mlpg_hip_launch_count(int kind) {
+  if (kind >= 100) return host_chunks_on_device(kind - 100);  // chunks the host-memory calls enqueued on device kind - 100
   return kind >= 0 && kind < kCountKinds ? g_launches[kind].load() : -1;
 }
 

@@ -54,6 +54,7 @@ constexpr int kMaxRep = 4;           // staging contexts per device (occurrences
 constexpr int kMaxList = 32;         // entries of a device list
 HostCtx g_host[kMaxHostDevices][kMaxRep];
 std::mutex g_host_mu;
+std::atomic<long long> g_host_chunks[kMaxHostDevices];  // chunks the *_host_multi calls enqueued per device (a test aid)
 
 // A resolved device list: entry k runs on device dev[k] with staging context ctx[k].
 struct DevList {
@@ -422,6 +423,8 @@ __global__ void widen_f32(const float *__restrict__ src, double *__restrict__ ds
 
 }  // namespace
 
+long long host_chunks_on_device(int device) { return device >= 0 && device < kMaxHostDevices ? g_host_chunks[device].load() : -1; }
+
 void host_api_shutdown() {
   std::lock_guard<std::mutex> lk(g_host_mu);
   CopyPool::shutdown();
@@ -554,6 +557,7 @@ int run_chunks(const DevList &dl, long nchunks, Submit submit, Collect collect) 
       cur = dl.dev[e];
     }
     const double ts = tr.on ? HostTrace::now() : 0.0;
+    g_host_chunks[dl.dev[e]].fetch_add(1);
     if ((rc = submit(e, slot, c))) break;
     if (hipEventRecord(dl.ctx[e]->done[slot], dl.ctx[e]->st[slot]) != hipSuccess) {
       set_error("hipEventRecord failed: %s", hipGetErrorString(hipGetLastError()));

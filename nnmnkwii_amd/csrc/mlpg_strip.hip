@@ -130,13 +130,14 @@ void *strip_scratch(hipStream_t st, int device, size_t nsg, int R, bool *zero_ct
 // the waiting ones would spin on strips nobody draws.  Asked of the hardware itself, once per device: a grid of small
 // workgroups, each adding one to the counter of its HW_REG_XCC_ID.
 namespace {
-__global__ void xcc_probe_kernel(int *hist) {
-  if (threadIdx.x == 0) atomicAdd(hist + (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7), 1);
+__global__ void xcc_probe_kernel(int *hist) {  // hist: pinned host memory (system-scope atomics)
+  if (threadIdx.x == 0) atomicAdd_system(hist + (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7), 1);
 }
 }  // namespace
 bool strip_xcd_lists_ok(hipStream_t st) {
   static std::mutex mu;
   static std::map<int, bool> seen;
+  static std::map<int, int> failed;  // probes that could not run (per device): after three the answer is "no" for good
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   std::lock_guard<std::mutex> lk(mu);
@@ -147,25 +148,34 @@ bool strip_xcd_lists_ok(hipStream_t st) {
     (void)hipGetLastError();
     return false;  // (not cached: the first launch outside a capture probes)
   }
+  // The probe runs inside an asynchronous launch path (the first long utterance on a device), so it must not synchronise the device
+  // or disturb anybody's stream capture: its own non-blocking stream, counters in pinned host memory that the
+  // kernel updates itself (no device allocation, no blocking copy, nothing on the NULL stream), a wait on that stream only; and for
+  // its duration this thread's calls are in relaxed capture mode, so that another thread's global-mode capture is not invalidated.
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  const bool mode_set = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
   bool ok = false, probed = false;
-  int *d = nullptr;
-  int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int *h = nullptr;
+  hipStream_t ps = nullptr;
   constexpr int kBlocks = 4096;
-  if (hipMalloc(&d, sizeof(h)) == hipSuccess) {
-    // (the default stream: synchronous with respect to the caller's work only through this function's own waits)
-    if (hipMemset(d, 0, sizeof(h)) == hipSuccess) {
-      hipLaunchKernelGGL(xcc_probe_kernel, dim3(kBlocks), dim3(64), 0, 0, d);
-      if (hipGetLastError() == hipSuccess && hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+  if (hipHostMalloc((void **)&h, 8 * sizeof(int), hipHostMallocDefault) == hipSuccess) {
+    for (int k = 0; k < 8; ++k) h[k] = 0;
+    if (hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) == hipSuccess) {
+      hipLaunchKernelGGL(xcc_probe_kernel, dim3(kBlocks), dim3(64), 0, ps, h);
+      if (hipGetLastError() == hipSuccess && hipStreamSynchronize(ps) == hipSuccess) {
         int lo = h[0], hi = h[0];
         for (int k = 1; k < 8; ++k) { lo = h[k] < lo ? h[k] : lo; hi = h[k] > hi ? h[k] : hi; }
         ok = lo > 0 && 2 * lo >= hi;
         probed = true;
       }
+      (void)hipStreamDestroy(ps);
     }
-    (void)hipFree(d);
+    (void)hipHostFree(h);
   }
   (void)hipGetLastError();
-  if (probed) seen[dev] = ok;  // (a runtime failure -- e.g. another stream's capture forbids the allocation -- is not cached)
+  if (mode_set) (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (probed) seen[dev] = ok;
+  else if (++failed[dev] >= 3) seen[dev] = false;  // (a runtime that keeps refusing the probe: stop asking on every launch)
   return ok;
 }
 

@@ -340,16 +340,3 @@ def test_header_constants_match_the_python_binding():
              "DIST_SCALED_SQL2_NP": _hip.DIST_SCALED_SQL2_NP, "TIE_FIRST_MIN": _hip.TIE_FIRST_MIN, "TIE_DIAG_LAST": _hip.TIE_DIAG_LAST}
     for name, val in pairs.items():
         assert defs.get(name) == val, (name, defs.get(name), val)
-
-
-def test_experimental_strip_fold_patch_still_applies():
-    """tools/experimental/strip_fold/fold.patch (measured and not shipped, see its README) is kept against the current
-    csrc/mlpg_strip_impl.h, so that the A/B scripts that name its switches stay reproducible."""
-    import shutil
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    patch = os.path.join(root, "tools", "experimental", "strip_fold", "fold.patch")
-    if shutil.which("patch") is None:
-        pytest.skip("no patch(1)")
-    r = subprocess.run(["patch", "-p1", "--dry-run", "-i", patch], cwd=root, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr

@@ -117,3 +117,60 @@ print("ok")
 """ % (root, os.path.join(root, "tests", "golden"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-300:], out.stderr[-800:])
+
+
+def test_every_visible_device_gets_its_share_of_the_chunks():
+    """devices="all": the chunks of one call are dealt round-robin over every visible GPU (the library's per-device chunk
+    counter, mlpg_hip_launch_count(100 + d)).  On a one-GPU box this checks the single device's count; on a node with
+    several GPUs that each device ran ceil / floor of its share and that the result equals the single-device call's."""
+    import torch
+    from nnmnkwii_amd import _hip
+    L = _hip.lib()
+    nd = torch.cuda.device_count()
+    windows = WINDOW_SETS["std3"]
+    rng = np.random.RandomState(77)
+    B, T, sd = 64, 500, 60                      # 69 MB of input: several chunks per device
+    M_ = rng.randn(B, T, 3 * sd)
+    V_ = rng.rand(B, T, 3 * sd) + 0.1
+    entry, slot, first, count = _hip.host_chunk_plan(B, max(1, (64 << 20) // (2 * T * 3 * sd * 8)), nd)
+    before = [int(L.mlpg_hip_launch_count(100 + d)) for d in range(nd)]
+    y = _hip.forward_host(M_, V_, windows, device="all")[0]
+    after = [int(L.mlpg_hip_launch_count(100 + d)) for d in range(nd)]
+    got = [a - b for a, b in zip(after, before)]
+    want = [int((entry == d).sum()) for d in range(nd)]
+    assert got == want and sum(got) == len(entry) and min(got) >= 1
+    y0 = _hip.forward_host(M_, V_, windows, device=0)[0]
+    assert np.array_equal(y, y0)
+    if nd > 1:
+        # an explicit list in another order, and a device listed twice next to one listed once
+        y2 = _hip.forward_host(M_, V_, windows, device=list(range(nd))[::-1])[0]
+        y3 = _hip.forward_host(M_, V_, windows, device=[0, 1, 0])[0]
+        assert np.array_equal(y2, y0) and np.array_equal(y3, y0)
+
+
+def test_bench_under_the_drivers_launcher_with_the_rccl_backend_at_world_size_one():
+    """`python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1 --gather`: the launch form the driver uses for the
+    N > 1 legs, with the nccl (= RCCL) backend's init, barriers and all-gathers actually running on the GPU -- at world size 1,
+    which is what a one-GPU box allows.  Plus tools/dbg/nccl_world1.py: the collectives sharding.py makes."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["NNMNKWII_BENCH_FORCE_DIST"] = "1"      # initialise the process group even at world size 1
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--batch", "32", "--frames", "300", "--precondition", "0", "--regions", "0", "--no-cpu-baseline", "--no-secondary",
+                        "--no-traffic", "--gather"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["allgather_ms"] is not None and res["parity_rel_err_vs_oracle"] < 1e-9
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "nccl_world1.py")], capture_output=True, text=True, timeout=300,
+                       env=dict(env, MASTER_PORT=str(port + 1 if port < 65000 else port - 1)), cwd=root)
+    assert r.returncode == 0 and "nccl world-1 ok" in r.stdout, (r.stdout + r.stderr)[-2000:]

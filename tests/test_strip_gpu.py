@@ -446,7 +446,7 @@ def test_strip_whole_utterance_route_while_another_stream_holds_cus():
 
 
 def test_retired_pipe_algo_selects_the_strip_kernel():
-    """MLPG_HIP_ALGO_PIPE (= 4; the software-pipelined kernel of round 3, now under tools/experimental/pipe) is still accepted and
+    """MLPG_HIP_ALGO_PIPE (= 4; the software-pipelined kernel of round 3, removed from the tree in round 6; git history: tools/experimental/pipe) is still accepted and
     runs the strip kernel: same bits, one strip launch."""
     import torch
     from nnmnkwii_amd import _hip
