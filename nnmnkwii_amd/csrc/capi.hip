@@ -175,8 +175,45 @@ int check_common(int B, int Tmax, int D, int nw) {
 
 }  // namespace
 
-// Kernel choice: AUTO = strip kernel for wide streams (static dims on lanes), wave-per-system kernel for narrow
-// ones, generic kernel for window extents > 1 or utterances longer than either supports.
+// Kernel choice, in ONE place (round 6): which kernel a problem goes to, as a pure function of the problem -- used by
+// dispatch_solve, which launches it (and asks again with a kernel excluded when that kernel declines at launch time: the FIR form
+// whose tap table fails its decay test, the transposed strip form the grid cannot hold), and by mlpg_hip_forward_streams, which must
+// know beforehand whether a stream will occupy the device with a persistent grid (stream_takes_tr).
+// AUTO = the FIR form for float32 unit variances without lengths; the strip kernel's transposed form for narrow streams; the
+// constant-coefficient kernel for global / unit variances; the chunked kernel for window extents of 2; the strip kernel for wide
+// streams (static dims on lanes); the wave-per-system kernel for narrow ones and small launches; else the natural-order kernel.
+enum Route { kRouteFir, kRouteStripTr, kRouteConst, kRouteChunk, kRouteStrip, kRouteWave, kRouteGeneric, kRoutePieceBackward };
+enum { kExcludeFir = 1, kExcludeTr = 2 };
+static Route route_of(int in_dtype, int out_dtype, int algo, bool backward, const Problem &p, const WinSet &ws, unsigned exclude) {
+  const bool piece = p.pitch && p.pitch != p.sd;  // some of a stream's static dims: window pitch != number of dims
+  if (algo == MLPG_HIP_ALGO_PIPE) algo = strip_supported(p, ws) ? MLPG_HIP_ALGO_STRIP : MLPG_HIP_ALGO_AUTO;  // retired: the scheme it pipelined
+  if (algo == MLPG_HIP_ALGO_FIR) return kRouteFir;
+  // (the FIR form first: it has no chain at all; not for a piece of a stream)
+  if (algo == MLPG_HIP_ALGO_AUTO && !piece && !(exclude & kExcludeFir) && fir_shape_supported(p, ws, in_dtype, out_dtype) && fir_preferred(p, backward))
+    return kRouteFir;
+  // a narrow stream (or the piece a merged launch left over): the strip kernel with its lanes over several utterances
+  if (!(exclude & kExcludeTr) && ((algo == MLPG_HIP_ALGO_AUTO && strip_tr_preferred(p, ws, backward, in_dtype, out_dtype)) ||
+                                 (algo == MLPG_HIP_ALGO_STRIP && piece && strip_tr_supported(p, ws, backward, in_dtype, out_dtype))))
+    return kRouteStripTr;
+  if (piece) {  // otherwise the kernels that take the pitch separately
+    if (backward) return kRoutePieceBackward;
+    return wave_supported(p, ws) ? kRouteWave : kRouteGeneric;
+  }
+  if (algo == MLPG_HIP_ALGO_AUTO) {
+    if (const_preferred(p, ws)) return kRouteConst;
+    if (in_dtype == out_dtype && chunk_preferred(p, ws, backward)) return kRouteChunk;
+    if (strip_preferred(p, ws, backward, in_dtype) || (strip_supported(p, ws) && !wave_supported(p, ws))) return kRouteStrip;
+    return wave_supported(p, ws) ? kRouteWave : kRouteGeneric;
+  }
+  switch (algo) {
+    case MLPG_HIP_ALGO_CONST: return kRouteConst;
+    case MLPG_HIP_ALGO_CHUNK: return kRouteChunk;
+    case MLPG_HIP_ALGO_STRIP: return kRouteStrip;
+    case MLPG_HIP_ALGO_WAVE: return kRouteWave;
+    default: return kRouteGeneric;
+  }
+}
+
 int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool backward, const Problem &p,
                    const WinSet &ws, int device) {
   if (algo < MLPG_HIP_ALGO_AUTO || algo > MLPG_HIP_ALGO_FIR) {
@@ -199,53 +236,40 @@ int dispatch_solve(hipStream_t st, int in_dtype, int out_dtype, int algo, bool b
     set_error("MLPG_HIP_ALGO_CHUNK: input dtype = output dtype, 1-3 windows of extent 1 or 2 (%d windows, extent %d)", ws.nw, ws.mw);
     return MLPG_HIP_EINVAL;
   }
-  if (algo == MLPG_HIP_ALGO_FIR) {
-    if (!fir_shape_supported(p, ws, in_dtype, out_dtype)) {
-      set_error("MLPG_HIP_ALGO_FIR: unit variances, float32 in and out, no lengths, T >= 96, 1-3 windows of extent <= 2 (the first a single tap)");
-      return MLPG_HIP_EINVAL;
+  if (algo == MLPG_HIP_ALGO_FIR && !fir_shape_supported(p, ws, in_dtype, out_dtype)) {
+    set_error("MLPG_HIP_ALGO_FIR: unit variances, float32 in and out, no lengths, T >= 96, 1-3 windows of extent <= 2 (the first a single tap)");
+    return MLPG_HIP_EINVAL;
+  }
+  unsigned exclude = 0;
+  for (;;) {
+    switch (route_of(in_dtype, out_dtype, algo, backward, p, ws, exclude)) {
+      case kRouteFir: {
+        const int rc = launch_fir(st, backward, p, ws, device);
+        if (rc != kFirNotApplicable) return rc;
+        if (algo == MLPG_HIP_ALGO_FIR) {
+          set_error("MLPG_HIP_ALGO_FIR: the inverse of this window set does not decay to 2^-26 within 24 frames (or the stream is being captured before the tap table exists)");
+          return MLPG_HIP_EINVAL;
+        }
+        exclude |= kExcludeFir;  // the other kernels take the call
+        continue;
+      }
+      case kRouteStripTr: {
+        const int rc = launch_strip_tr(st, in_dtype, p, ws, device);
+        if (rc != kStripMultiNotResident) return rc;
+        exclude |= kExcludeTr;  // a launch the grid cannot hold: the other kernels
+        continue;
+      }
+      case kRoutePieceBackward:
+        set_error("a stream piece (pitch %d, %d dims) has no backward pass", p.pitch, p.sd);
+        return MLPG_HIP_EINVAL;
+      case kRouteConst: return launch_const(st, in_dtype, out_dtype, backward, p, ws, device);
+      case kRouteChunk: return launch_chunk(st, in_dtype, out_dtype, backward, p, ws, device);
+      // (the strip launcher tries the transposed form itself when asked for by name: not again after it declined here)
+      case kRouteStrip: return launch_strip(st, in_dtype, out_dtype, backward, p, ws, device, !(exclude & kExcludeTr));
+      case kRouteWave: return launch_wave(st, in_dtype, out_dtype, backward, p, ws, device);
+      default: return launch_generic(st, in_dtype, out_dtype, backward, p, ws, device);
     }
-    const int rc = launch_fir(st, backward, p, ws, device);
-    if (rc == kFirNotApplicable) {
-      set_error("MLPG_HIP_ALGO_FIR: the inverse of this window set does not decay to 2^-26 within 24 frames (or the stream is being captured before the tap table exists)");
-      return MLPG_HIP_EINVAL;
-    }
-    return rc;
   }
-  if (algo == MLPG_HIP_ALGO_PIPE) {
-    // retired (round 3's software-pipelined kernel; in the history up to round 5: tools/experimental/pipe): the strip scheme it pipelined, or the kernel AUTO would take
-    algo = strip_supported(p, ws) ? MLPG_HIP_ALGO_STRIP : MLPG_HIP_ALGO_AUTO;
-  }
-  // (the FIR form first: float32 unit variances without lengths -- it has no chain at all; not for a piece of a stream)
-  if (algo == MLPG_HIP_ALGO_AUTO && !(p.pitch && p.pitch != p.sd) && fir_shape_supported(p, ws, in_dtype, out_dtype) && fir_preferred(p, backward)) {
-    const int rc = launch_fir(st, backward, p, ws, device);
-    if (rc != kFirNotApplicable) return rc;
-  }
-  // a narrow stream (or the piece a merged launch left over): the strip kernel with its lanes over
-  // several utterances; a launch the grid cannot hold falls through to the other kernels
-  if ((algo == MLPG_HIP_ALGO_AUTO && strip_tr_preferred(p, ws, backward, in_dtype, out_dtype)) ||
-      (algo == MLPG_HIP_ALGO_STRIP && p.pitch && p.pitch != p.sd && strip_tr_supported(p, ws, backward, in_dtype, out_dtype))) {
-    const int rc = launch_strip_tr(st, in_dtype, p, ws, device);
-    if (rc != kStripMultiNotResident) return rc;
-  }
-  if (p.pitch && p.pitch != p.sd) {
-    // a piece of a stream (window pitch != number of dims): the kernels that take the pitch separately
-    if (backward) {
-      set_error("a stream piece (pitch %d, %d dims) has no backward pass", p.pitch, p.sd);
-      return MLPG_HIP_EINVAL;
-    }
-    algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
-  }
-  if (algo == MLPG_HIP_ALGO_AUTO) {
-    if (const_preferred(p, ws)) algo = MLPG_HIP_ALGO_CONST;
-    else if (in_dtype == out_dtype && chunk_preferred(p, ws, backward)) algo = MLPG_HIP_ALGO_CHUNK;
-    else if (strip_preferred(p, ws, backward, in_dtype) || (strip_supported(p, ws) && !wave_supported(p, ws))) algo = MLPG_HIP_ALGO_STRIP;
-    else algo = wave_supported(p, ws) ? MLPG_HIP_ALGO_WAVE : MLPG_HIP_ALGO_GENERIC;
-  }
-  if (algo == MLPG_HIP_ALGO_CONST) return launch_const(st, in_dtype, out_dtype, backward, p, ws, device);
-  if (algo == MLPG_HIP_ALGO_CHUNK) return launch_chunk(st, in_dtype, out_dtype, backward, p, ws, device);
-  if (algo == MLPG_HIP_ALGO_STRIP) return launch_strip(st, in_dtype, out_dtype, backward, p, ws, device);
-  if (algo == MLPG_HIP_ALGO_WAVE) return launch_wave(st, in_dtype, out_dtype, backward, p, ws, device);
-  return launch_generic(st, in_dtype, out_dtype, backward, p, ws, device);
 }
 
 namespace {
@@ -358,10 +382,7 @@ bool stream_takes_tr(int dtype, int algo, const void *mean, const void *var, int
   if (stream_problem(dtype, mean, var, var_mode, ld_in, lengths, B, Tmax, sm, wl, wu, wc, out, ld_out, nullptr, 1, 0, d_first, d_count, &p, &ws))
     return false;
   if (p.pitch && (algo == MLPG_HIP_ALGO_CONST || algo == MLPG_HIP_ALGO_CHUNK || algo == MLPG_HIP_ALGO_FIR)) algo = MLPG_HIP_ALGO_AUTO;
-  // (dispatch_solve's order: the FIR form first)
-  if (algo == MLPG_HIP_ALGO_AUTO && !(p.pitch && p.pitch != p.sd) && fir_shape_supported(p, ws, dtype, dtype) && fir_preferred(p, false)) return false;
-  return algo == MLPG_HIP_ALGO_AUTO ? strip_tr_preferred(p, ws, false, dtype, dtype)
-                                    : algo == MLPG_HIP_ALGO_STRIP && strip_tr_supported(p, ws, false, dtype, dtype);
+  return route_of(dtype, dtype, algo, false, p, ws, 0) == kRouteStripTr;  // (the decision dispatch_solve will take)
 }
 
 }  // namespace

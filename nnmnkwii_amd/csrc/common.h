@@ -90,7 +90,7 @@ bool strip_tr_supported(const Problem &p, const WinSet &w, bool backward, int in
 bool strip_tr_preferred(const Problem &p, const WinSet &w, bool backward, int in_dtype, int out_dtype);
 int launch_strip_tr(hipStream_t s, int dtype, const Problem &p, const WinSet &w, int device);
 int launch_strip(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w,
-                 int device);
+                 int device, bool try_tr = true);
 // launch_strip_multi's "nothing was enqueued" result: fewer workgroups can be resident than an utterance has strips
 constexpr int kStripMultiNotResident = -1000;
 // forward pass of several streams (p: the parent arrays, sd/D unused) -- per-frame variances, three windows of extent <= 1

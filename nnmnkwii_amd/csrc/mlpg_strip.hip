@@ -204,9 +204,10 @@ int launch_strip_tr(hipStream_t st, int dtype, const Problem &p, const WinSet &w
 }
 
 int launch_strip(hipStream_t st, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &ws,
-                 int device) {
-  // a narrow stream asked for by name: the transposed form where it applies (the plain form would run 64 / sd times the items)
-  if (strip_tr_supported(p, ws, backward, dtype, out_dtype)) {
+                 int device, bool try_tr) {
+  // a narrow stream asked for by name: the transposed form where it applies (the plain form would run 64 / sd times the items);
+  // try_tr = false: the caller has just been told that the grid cannot hold that form
+  if (try_tr && strip_tr_supported(p, ws, backward, dtype, out_dtype)) {
     const int rc = launch_strip_tr(st, dtype, p, ws, device);
     if (rc != kStripNotResident) return rc;
   }
