@@ -552,6 +552,8 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_streams(
       members[cnt++] = k;
       total += sm.static_dim;
     }
+    // (Round 6 measured NOT merging for global / unit variances when every narrow member would take the transposed strip form on its own:
+    // config 5 in one call 0.73 ms against 0.64-0.65 ms merged -- although the same three launches as three calls sum to 0.61 ms.  Merged.)
     int cap = total;
     if (total > 64 && total % 64 < 32) cap = total - total % 64;
     // widest first (insertion sort, stable), then greedy

@@ -624,14 +624,17 @@ int forward_host_small(int device, int dtype, int algo, const void *mean_h, cons
   // further transfer costs 3 us), each piece's transfer enqueued behind its staging: the next piece is staged under it.  (Enqueued
   // copies are submitted at once -- measured: a hipStreamSynchronize behind a host-side pause of the copy's length returns in
   // 0.6 us -- and two streams do not move a pair of halves faster than one moves them in a row.)
+  // (A shorter very first piece -- 64 / 192 / 384 KB, so that the copy engine starts earlier -- was measured in round 6: no difference
+  // beyond the 8 % a config-2 utterance's call varies from process to process.)
   auto stage_send = [&](size_t off, const void *from, size_t bytes, size_t tail) -> int {  // tail: staged bytes right behind, sent along
     constexpr size_t kPiece = 768u << 10;
-    for (size_t o = 0; o < bytes; o += kPiece) {
+    for (size_t o = 0; o < bytes;) {
       const size_t n = std::min(kPiece, bytes - o);
       pool->copy(c.pin_in + off + o, (const char *)from + o, n);
       const bool last = o + n >= bytes;
       if (!direct_in) MLPG_HIP_CHECK(hipMemcpyAsync(c.dev + off + o, c.pin_in + off + o, n + (last ? tail : 0), hipMemcpyHostToDevice, c.st));
       if (last) break;
+      o += n;
     }
     return 0;
   };
