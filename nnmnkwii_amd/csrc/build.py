@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["capi.hip", "host_api.hip", "mlpg_generic.hip", "mlpg_wave.hip", "mlpg_wave_fwd_f64.hip", "mlpg_wave_fwd_f32.hip",
            "mlpg_wave_bwd_f64.hip", "mlpg_wave_bwd_f32.hip", "mlpg_wave_fused.hip", "mlpg_strip.hip", "mlpg_strip_fwd_f64.hip",
            "mlpg_strip_fwd_f32.hip", "mlpg_strip_bwd_f64.hip", "mlpg_strip_bwd_f32.hip", "mlpg_strip_multi_f64.hip", "mlpg_strip_multi_f32.hip", "mlpg_const.hip", "mlpg_const_fwd_f64.hip", "mlpg_const_fwd_f32.hip", "mlpg_const_bwd_f64.hip", "mlpg_const_bwd_f32.hip", "mlpg_const_multi_f64.hip", "mlpg_const_multi_f32.hip", "mlpg_chunk.hip", "mlpg_fir.hip", "dtw.hip", "dtw_fast.hip", "dtw_costs.hip", "modspec.hip", "modspec_dft.hip"]
-HEADERS = ["common.h", "assemble.h", "mlpg_wave_impl.h", "mlpg_strip_impl.h", "mlpg_walk_impl.h", "mlpg_const_impl.h", "mlpg_chunk_impl.h", os.path.join("..", "..", "include", "mlpg_hip.h")]
+HEADERS = ["common.h", "assemble.h", "mlpg_wave_impl.h", "mlpg_strip_impl.h", "mlpg_const_impl.h", "mlpg_chunk_impl.h", os.path.join("..", "..", "include", "mlpg_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # The DTW kernels must round exactly like the CPU oracle (separate multiply and add); the MLPG
 # kernels are free to fuse multiply-adds.
@@ -38,13 +38,11 @@ def _stale(target, deps):
 
 def _headers_of(src):
     """Headers a source depends on (the two big kernel headers only matter to their own instantiation files)."""
-    hs = [h for h in HEADERS if h not in ("mlpg_wave_impl.h", "mlpg_strip_impl.h", "mlpg_walk_impl.h", "mlpg_const_impl.h", "mlpg_chunk_impl.h")]
+    hs = [h for h in HEADERS if h not in ("mlpg_wave_impl.h", "mlpg_strip_impl.h", "mlpg_const_impl.h", "mlpg_chunk_impl.h")]
     if src.startswith("mlpg_wave_"):
         hs.append("mlpg_wave_impl.h")
     if src.startswith("mlpg_strip_"):
         hs.append("mlpg_strip_impl.h")
-    if src.startswith("mlpg_strip_fwd"):
-        hs.append("mlpg_walk_impl.h")
     if src.startswith("mlpg_const_"):
         hs.append("mlpg_const_impl.h")
     if src.startswith("mlpg_chunk"):

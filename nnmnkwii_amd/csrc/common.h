@@ -72,7 +72,7 @@ inline bool rows_fit_buffer(const Problem &p) {
 
 void set_error(const char *fmt, ...);
 // launches per kernel family since the library was loaded (mlpg_hip_launch_count: a test aid)
-enum { kCountGeneric = 0, kCountWave, kCountStrip, kCountStripMulti, kCountConst, kCountFused, kCountChunk, kCountFir, kCountConstMulti, kCountStripTr, kCountHostSmall, kCountHostSmallDirect, kCountWalk, kCountKinds };
+enum { kCountGeneric = 0, kCountWave, kCountStrip, kCountStripMulti, kCountConst, kCountFused, kCountChunk, kCountFir, kCountConstMulti, kCountStripTr, kCountHostSmall, kCountHostSmallDirect, kCountKinds };
 void note_launch(int kind);
 // Grow-only scratch, cached per (device, stream, slot): slot 0 generic factor, 1 fastdtw pyramids,
 // 2 generic status, 3 strip records, 4 constant-coefficient kernel (factor table), 5 fastdtw from host costs (D rows, back-pointers), 6 chunked kernel (records, block factors, separator solutions, marks).  Returns nullptr (and sets the error) on failure.

@@ -1,6 +1,5 @@
 // strip MLPG kernels: forward, float
-#define MLPG_STRIP_WALK 1  // this translation unit also holds the walk form of the forward pass (mlpg_walk_impl.h)
-#include "mlpg_walk_impl.h"
+#include "mlpg_strip_impl.h"
 namespace mlpg {
 int launch_strip_fwd_f32(hipStream_t st, int out_dtype, const Problem &p, const WinSet &ws, void *scratch, int R, int ndg, int dgw, bool zero_ctrl) {
   (void)out_dtype;

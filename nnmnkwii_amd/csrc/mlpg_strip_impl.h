@@ -101,10 +101,6 @@ enum { rT00, rT01, rT11, rH0, rH1, rD11, rD12, rD22, rF1, rF2, rL11, rL12, rL21,
 //   words 2-3 mask of the lanes (systems) that met a failing pivot, word 4 time-out seen;
 //   then one flag per strip, Rpad = R rounded up to a line per system group: flag[g * Rpad + r].
 constexpr int kCtrlLine = 32;
-// words of line 0 and of a group's line that the walk form uses (mlpg_walk_impl.h); verdict_kernel zeroes them with the rest
-constexpr int kCtrlWalkTicket = 8;   // line 0: the walk kernel's next utterance group
-constexpr int kCtrlMarked = 9;       // line 0: utterance groups the walk kernel left to the general route
-constexpr int kLineMarked = 5;       // a group's line: left to the general route
 #ifndef MLPG_STRIP_POLL_SLEEP
 #define MLPG_STRIP_POLL_SLEEP 16  // x 64 cycles between two looks at the neighbours' flags (4 .. 64 measured: no difference)
 #endif
@@ -229,7 +225,6 @@ struct Args {
                  // block j of system group g is "virtual group" g * nb + j, virtual group v belongs to list v % nlists):
                  // nb = 1, bs = R while an utterance fits into a list's share of the grid, more blocks for long ones
   StreamMap sm;  // MULTI kernels only: the streams whose static dims sit side by side on the lanes
-  int only_marked;  // the launch behind a walk-form launch: only the utterance groups that one marked (all of them: 0)
   int stagger;   // start ramp: the workgroup that draws ticket tk < wpl of a list as its FIRST item starts it tk * stagger / wpl ticks
   int wpl;       // (100 MHz) late; wpl = workgroups per list.  0: everybody starts at once.  See launch_impl.
 };
@@ -669,7 +664,7 @@ struct RingDepth<float> { static constexpr int value = MLPG_STRIP_RING_F32; };  
 // LT (the transposed form with a lengths vector): T is the frame count of the lane group's LONGEST utterance -- what the clamped loads
 // and everything wave-uniform go by -- and Tu this lane's own: its dead frames enter with precision 0 and mean 0 by per-lane
 // SELECTS (their values are padding: anything), its rows >= Tu become identity rows.
-template <typename TIN, bool BWD, int VM, bool EDGE, int NW, bool MULTI = false, bool KEEP = false, bool LT = false, int RING = 0>
+template <typename TIN, bool BWD, int VM, bool EDGE, int NW, bool MULTI = false, bool KEEP = false, bool LT = false>
 __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, __amdgpu_buffer_rsrc_t vrs,
                                                    __amdgpu_buffer_rsrc_t grs, const TIN *__restrict__ vglob,
                                                    unsigned loff, long ldi, long ldg, int sd, int f0, int T, int mw,
@@ -701,7 +696,7 @@ __device__ __forceinline__ bool assemble_eliminate(__amdgpu_buffer_rsrc_t mrs, _
       k[w].tau_glob = t1;
     }
   }
-  constexpr int kRing = RING > 0 ? RING : RingDepth<TIN>::value;  // (RING: the walk form, one wavefront per SIMD, can afford a deeper ring)
+  constexpr int kRing = RingDepth<TIN>::value;
   TIN rv[kRing][NW], rm[kRing][NW];
   auto load_frame = [&](TIN (&v)[NW], TIN (&m)[NW], const int i) __attribute__((always_inline)) {
     // BWD: the frame's row offset as an opaque scalar, so that the 18 multiples i * ldi_bytes (and their EDGE variants) are
@@ -1785,7 +1780,6 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
   // (Starting the second workgroup of each CU half an item late was measured in round 2 -- no gain -- and removed in round 5; round 6's
   // trace shows why: whatever the start, the workgroups of an utterance's strips re-align within two items.  See the start ramp in
   // launch_impl for the part of a staggered start that does pay.)
-  if (a.only_marked && __hip_atomic_load(a.ctrl + kCtrlMarked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;  // nothing was marked
   bool first_item = true;
   const long long t_launch = (long long)__builtin_amdgcn_s_memrealtime();
   for (int k = 0; k < a.nlists; ++k) {
@@ -1818,9 +1812,7 @@ __global__ __launch_bounds__(kW * 64, MLPG_STRIP_WGS) void strip_kernel(Problem 
 #endif
       int g_it, r_it;
       ticket_item<MULTI>(a, tk, lst, g_it, r_it);
-      const bool mine = !a.only_marked ||
-                        __hip_atomic_load(a.ctrl + (1 + kMaxLists + g_it) * kCtrlLine + kLineMarked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-      if (r_it < R && mine) body(g_it, r_it);  // (the last block of a long utterance may be short: tickets past its end are nobody's)
+      if (r_it < R) body(g_it, r_it);  // (the last block of a long utterance may be short: tickets past its end are nobody's)
       __syncthreads();
     }
     __syncthreads();
@@ -1842,7 +1834,7 @@ __global__ void __launch_bounds__(256) verdict_kernel(const Problem p, const Win
   const int timed_out = line[4];
   // leave every control word as the next launch needs it: zero (launch_strip then skips its memset)
   __builtin_amdgcn_wave_barrier();
-  if (lane < 6) line[lane] = 0;
+  if (lane < 5) line[lane] = 0;
   for (int i = lane; i < flag_pitch(a.R); i += 64) a.ctrl[(1 + kMaxLists + a.nsg) * kCtrlLine + (size_t)g * flag_pitch(a.R) + i] = 0;
   if (g == 0)
     for (int i = lane; i < (1 + kMaxLists) * kCtrlLine; i += 64) a.ctrl[i] = 0;
@@ -1922,21 +1914,6 @@ inline int resident_grid(const void *kern, int threads, size_t lds, int *out) {
   return 0;
 }
 
-}  // namespace strip
-namespace walk {
-// mlpg_walk_impl.h (included behind this header by the translation units that launch it: the forward instantiations)
-template <typename TIN, typename TOUT, int VM>
-__global__ void walk_kernel(Problem p, WinSet ws, strip::Args a);
-size_t walk_lds_bytes();
-}  // namespace walk
-namespace strip {
-#ifndef MLPG_WALK_STAGGER_DEFAULT_US
-#define MLPG_WALK_STAGGER_DEFAULT_US 10  // span of the walk kernel's start ramp in microseconds (MLPG_WALK_STAGGER_US overrides it at run time)
-#endif
-#ifndef MLPG_STRIP_WALK
-#define MLPG_STRIP_WALK 0  // 1: this translation unit includes mlpg_walk_impl.h and may launch the walk form
-#endif
-
 template <typename TIN, typename TOUT, bool BWD, bool MULTI, bool TR = false>
 int launch_impl(hipStream_t st, const Problem &p, const WinSet &ws, void *scratch_base, int R, int ndg, int dgw,
                 bool zero_ctrl, const StreamMap *smap) {
@@ -2013,37 +1990,6 @@ int launch_impl(hipStream_t st, const Problem &p, const WinSet &ws, void *scratc
       static const double us = [] { const char *e = getenv("MLPG_STRIP_STAGGER_US"); return e ? atof(e) : (double)MLPG_STRIP_STAGGER_DEFAULT_US; }();
       if (us > 0 && a.wpl >= 2 && nitems >= 3 * grid) a.stagger = (int)(us * 100.0);
     }
-    a.only_marked = 0;
-#if MLPG_STRIP_WALK
-    if constexpr (!BWD && !MULTI && std::is_same<TIN, TOUT>::value) {
-      // The walk form (mlpg_walk_impl.h): one workgroup per utterance, no exchange between workgroups.  Per-frame variances, three
-      // windows, one dim group, utterances of at least four strips, and -- it is utterance-granular -- a launch whose utterances
-      // fill the one-workgroup-per-CU grid's rounds to at least 85 %.  Utterances it cannot finish (a strip's one-strip look-ahead
-      // bound is not below 2^-66: tight dynamic variances) are marked and taken by the strip kernel behind it, which then looks at
-      // marked utterances only.  MLPG_STRIP_WALK=0 / 1 in the environment: never / wherever it is supported (tests, A/B runs).
-      const char *e = getenv("MLPG_STRIP_WALK");
-      const int force = e ? atoi(e) : -1;
-      bool use = force != 0 && ws.nw == 3 && p.var_mode == MLPG_HIP_VAR_FRAME && ndg == 1 && a.nlists >= 1 && R >= 1;
-      int wgrid = 0;
-      if (use) {
-        if (int rc = resident_grid((const void *)walk::walk_kernel<TIN, TOUT, MLPG_HIP_VAR_FRAME>, kW * 64, walk::walk_lds_bytes(), &wgrid)) return rc;
-        const long rounds = (nsg + wgrid - 1) / wgrid;
-        if (force != 1) use = R >= 4 && nsg >= wgrid / 2 && (double)nsg >= 0.85 * (double)(rounds * wgrid);
-      }
-      if (use) {
-        note_launch(kCountWalk);
-        const long wg = nsg < wgrid ? nsg : wgrid;
-        Args aw = a;
-        {
-          const char *es = getenv("MLPG_WALK_STAGGER_US");
-          aw.stagger = (int)((es ? atof(es) : (double)MLPG_WALK_STAGGER_DEFAULT_US) * 100.0);
-        }
-        hipLaunchKernelGGL((walk::walk_kernel<TIN, TOUT, MLPG_HIP_VAR_FRAME>), dim3((unsigned)wg), dim3(kW * 64), walk::walk_lds_bytes(), st, p, ws, aw);
-        MLPG_HIP_CHECK(hipGetLastError());
-        a.only_marked = 1;
-      }
-    }
-#endif
     note_launch(TR ? kCountStripTr : MULTI ? kCountStripMulti : kCountStrip);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kW * 64), kLdsBytes, st, p, ws, a);
     MLPG_HIP_CHECK(hipGetLastError());
