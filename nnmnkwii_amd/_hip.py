@@ -842,7 +842,8 @@ def _mse_workspace(device, B, T, D, nw, fir_form):
         if capturing:
             raise HipExtensionError(
                 "unit_mse_step: the workspace of this stream does not exist yet or is too small (%d bytes needed) and cannot be "
-                "allocated while the stream is being captured -- run one eager step of this shape on the stream first" % need)
+                "allocated while the stream is being captured -- run one eager step of this shape on the capturing stream first "
+                "(torch.cuda.graph(g, stream=s) with the stream s the warm-up ran on: the default capture stream is torch's own)" % need)
         size = need if ent is None else max(need, ent[0].numel() * 3 // 2)
         if ent is not None and ent[1]:
             _MSE_WORKSPACE_RETIRED.append(ent[0])

@@ -303,7 +303,9 @@ def unit_variance_mlpg_mse_loss(R_or_windows, means, target):
     :func:`nnmnkwii_amd.paramgen.unit_variance_mlpg_matrix` (recognised by content, as in
     :func:`unit_variance_mlpg`) or the window list itself.  Falls back to the two-node form -- same value, same
     gradients -- for a foreign ``R``, outside the step's limits (float32 batches of 96 frames and more: window extents <= 2;
-    otherwise T <= 1024 and window extents <= 1) and when ``target`` wants a gradient.  The loss lives on ``means.device`` (as in the eager form)."""
+    otherwise T <= 1024 and window extents <= 1) and when ``target`` wants a gradient.  The loss lives on ``means.device`` (as in the eager form).
+    Under a HIP-graph capture the step's per-stream workspace must already exist: run one eager step on the stream, then capture on
+    that stream (``torch.cuda.graph(g, stream=s)``); the call raises ``HipExtensionError`` with this advice otherwise."""
     if torch.is_tensor(R_or_windows):
         ident = _identify_R(R_or_windows)
         if ident is None or means.shape[-2] != R_or_windows.shape[0]:

@@ -526,8 +526,8 @@ def _run(only, quick, device_index):
             torch.cuda.current_stream().wait_stream(side2)
             torch.cuda.synchronize()
             means.grad = None
-            with torch.cuda.graph(g2):
-                AF.unit_variance_mlpg_mse_loss(R, means, target).backward()
+            with torch.cuda.graph(g2, stream=side2):   # (the stream that was warmed up: the step's workspace is per stream and is
+                AF.unit_variance_mlpg_mse_loss(R, means, target).backward()     # never created inside a capture, _hip._mse_workspace)
             ms_fused_graph = gpu_time(g2.replay, steps=20)
         except Exception as e:  # noqa: BLE001
             ms_fused_graph = "capture failed: %s" % str(e)[:120]
