@@ -638,13 +638,21 @@ int forward_host_small(int device, int dtype, int algo, const void *mean_h, cons
     }
     return 0;
   };
-  if (int rc = stage_send(0, mean_h, mean_bytes, 0)) return rc;
+  auto drained = [&](int rc) {  // an error return leaves nothing in flight on the cached staging buffers
+    (void)hipStreamSynchronize(c.st);
+    (void)hipGetLastError();
+    return rc;
+  };
+  if (int rc = stage_send(0, mean_h, mean_bytes, 0)) return drained(rc);
   if (len_bytes) memcpy(c.pin_in + o_len, lengths_h, len_bytes);
   // (variances and lengths are neighbours in the staging buffer: the lengths ride on the variances' last transfer)
   if (var_bytes) {
-    if (int rc = stage_send(o_var, var_h, var_bytes, len_bytes ? o_len + len_bytes - (o_var + var_bytes) : 0)) return rc;
+    if (int rc = stage_send(o_var, var_h, var_bytes, len_bytes ? o_len + len_bytes - (o_var + var_bytes) : 0)) return drained(rc);
   } else if (len_bytes && !direct_in) {
-    MLPG_HIP_CHECK(hipMemcpyAsync(c.dev + o_len, c.pin_in + o_len, len_bytes, hipMemcpyHostToDevice, c.st));
+    if (hipMemcpyAsync(c.dev + o_len, c.pin_in + o_len, len_bytes, hipMemcpyHostToDevice, c.st) != hipSuccess) {
+      set_error("host call: copying the lengths failed: %s", hipGetErrorString(hipGetLastError()));
+      return drained(MLPG_HIP_ERUNTIME);
+    }
   }
   Problem p;
   p.mean = src;
@@ -665,11 +673,7 @@ int forward_host_small(int device, int dtype, int algo, const void *mean_h, cons
   const double ts = tr.on ? HostTrace::now() : 0.0;
   int rc = dispatch_solve(c.st, dtype, dtype, algo, false, p, ws, device);
   if (!rc) rc = small_wait(c);
-  if (rc) {  // nothing is left in flight
-    (void)hipStreamSynchronize(c.st);
-    (void)hipGetLastError();
-    return rc;
-  }
+  if (rc) return drained(rc);
   const double tw = tr.on ? HostTrace::now() : 0.0;
   pool->copy(out_h, c.pin_out, out_bytes);
   if (status_h) memcpy(status_h, c.pin_out + o_status, st_bytes);

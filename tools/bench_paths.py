@@ -62,6 +62,24 @@ def gpu_time(fn, steps=10, warmup=2, settle_ms=None):
     return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
 
+def wall_time(fn, steps=1000, warmup=50, repeats=3):
+    """Wall-clock milliseconds per call over a back-to-back loop with one synchronize at its end (best of `repeats`): what a
+    training loop sees, and how the reference times its own loop (perf/autograd_mlpg_perf.py:56-86: time.time() around the loop).
+    For host-bound steps the event pair of gpu_time() around every single call reads 1.5-2.5 x this (profiles/r06_notes.md section 10)."""
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / steps * 1e3)
+    return best
+
+
 HBM_PEAK_GBS = 8000.0
 
 
@@ -465,6 +483,14 @@ def _run(only, quick, device_index):
             loss_fn(y, target).backward()
 
         ms = gpu_time(step)
+        nwall = 200 if args.quick else 1000
+        ms_wall = wall_time(step, steps=nwall)
+
+        def step_plain():      # the same loop with a trivial node in place of MLPG: what the framework itself costs per step
+            means.grad = None
+            loss_fn(means[..., :D // 3] * 1.0, target).backward()
+
+        ms_wall_plain = wall_time(step_plain, steps=nwall)
         by = 1920.0 * B * T    # 960 B/frame forward + 960 B/frame backward
         # the same training step captured once into a HIP graph and replayed (eager mode is host-bound: a dozen
         # framework launches of a few microseconds each around two short kernels)
@@ -510,6 +536,7 @@ def _run(only, quick, device_index):
             AF.unit_variance_mlpg_mse_loss(R, means, target).backward()
 
         ms_fused = gpu_time(step_fused, steps=20)
+        ms_fused_wall = wall_time(step_fused, steps=nwall)
         ms_fused_kernel = gpu_time(lambda: _hip.unit_mse_step(md, target, WINDOWS), steps=20)
         full = torch.full((B,), T, dtype=torch.int32, device=dev)     # (a lengths vector keeps the call on the one-launch kernel)
         ms_one_launch = gpu_time(lambda: _hip.unit_mse_step(md, target, WINDOWS, lengths=full), steps=20)
@@ -531,13 +558,19 @@ def _run(only, quick, device_index):
             ms_fused_graph = gpu_time(g2.replay, steps=20)
         except Exception as e:  # noqa: BLE001
             ms_fused_graph = "capture failed: %s" % str(e)[:120]
-        emit(path="c3-fused-unit-mse-step", ms=ms_fused_kernel, ms_one_launch_kernel=ms_one_launch, ms_autograd_eager=ms_fused, ms_hip_graph_replay=ms_fused_graph,
+        emit(path="c3-fused-unit-mse-step", ms=ms_fused_kernel, ms_one_launch_kernel=ms_one_launch, ms_autograd_eager=ms_fused,
+             ms_autograd_eager_wall_loop=ms_fused_wall, ms_hip_graph_replay=ms_fused_graph,
              frames_per_s=B * T / ms_fused_kernel * 1e3, alg_bytes=by + 4.0 * 60 * B * T, GBps=(by + 4.0 * 60 * B * T) / ms_fused_kernel / 1e6,
              note="ms = one mlpg_hip_unit_mse_step call (float32 without lengths: the FIR form, two launches, nothing allocated; "
                   "ms_one_launch_kernel: the wave-per-system kernel that takes the call when lengths are given): forward + MSE loss + backward of config 3; "
-                  "ms_autograd_eager / ms_hip_graph_replay = the same through autograd.unit_variance_mlpg_mse_loss(...).backward()")
+                  "ms_autograd_eager / ms_hip_graph_replay = the same through autograd.unit_variance_mlpg_mse_loss(...).backward(); "
+                  "ms_autograd_eager_wall_loop: wall clock per step of %d back-to-back eager steps, one synchronize at the end" % nwall)
         emit(path="c3-unit-variance-autograd-fwd+bwd", ms=ms, frames_per_s=B * T / ms * 1e3, alg_bytes=by,
-             GBps=by / ms / 1e6, ms_hip_graph_replay=ms_graph,
+             GBps=by / ms / 1e6, ms_wall_loop=ms_wall, ms_wall_loop_plain_torch_ops_no_mlpg_node=ms_wall_plain, ms_hip_graph_replay=ms_graph,
+             note="ms: median HIP-event pair around ONE eager step (host-bound: the pair reads the host's issue time of a step that starts on an idle "
+                  "device); ms_wall_loop: wall clock per step of %d back-to-back eager steps with one synchronize at the end -- how the reference "
+                  "times this loop (perf/autograd_mlpg_perf.py:56-86); ..._plain_torch_ops_no_mlpg_node: the same loop with `means[..., :60] * 1.0` "
+                  "in place of the MLPG node" % nwall,
              GBps_hip_graph_replay=(by / ms_graph / 1e6 if isinstance(ms_graph, float) else None),
              cpu_dense_matmul_1thread_frames_per_s=B * T / cpu_s)
 
