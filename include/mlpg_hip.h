@@ -305,6 +305,23 @@ int mlpg_hip_backward(int device, void *stream, int in_dtype, int out_dtype,
                       int32_t *status);
 
 /*
+ * The same call on HOST memory (ABI 14): the literal paramgen.mlpg_grad(mean_frames, variance_frames, windows, grad_output) of the
+ * reference (paramgen/_mlpg.py:202-281: numpy in, float32 numpy out; 0.8 ms there at T = 100 x 2 static dims, seconds at T = 1000 x
+ * 60) and the backward of autograd.MLPG on CPU tensors (autograd/_impl/mlpg.py:57-67).  All pointers are HOST pointers: var_h /
+ * grad_out_h of in_dtype, grad_h (B, Tmax, D) of out_dtype, status_h (B * D/nw, may be NULL), lengths_h may be NULL.  Synchronous.
+ * The batch runs through the short path of mlpg_hip_forward_host -- one stream, cached pinned staging, up to 48 KB of input read
+ * by the kernel in place, the gradient written by the kernel into pinned host memory, a polled sequence number -- in pieces of
+ * whole utterances of at most MLPG_HIP_HOST_SMALL_MB of input, one after the other (the reference's call is one utterance; a large
+ * batch belongs on mlpg_hip_backward).  mlpg_hip_launch_count(10 / 11) counts the pieces.
+ */
+int mlpg_hip_backward_host(int device, int in_dtype, int out_dtype, int algo,
+                           const void *var_h, int var_mode, const void *grad_out_h,
+                           const int32_t *lengths_h, int B, int Tmax, int D,
+                           int num_windows, const int32_t *win_l_h,
+                           const int32_t *win_u_h, const double *win_coef_h,
+                           void *grad_h, int32_t *status_h);
+
+/*
  * Delta features (the step BEFORE MLPG in every pipeline).  Replaces
  * preprocessing.delta_features (preprocessing/generic.py:229-288: a Python loop over feature
  * dims of np.correlate(x[:, d], window, "same")), batched:

@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 F32, F64 = 0, 1
-ABI_VERSION = 13               # mlpg_hip_abi_version() of the library this binding was written for
+ABI_VERSION = 14               # mlpg_hip_abi_version() of the library this binding was written for
 VAR_FRAME, VAR_GLOBAL, VAR_UNIT = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_WAVE, ALGO_STRIP, ALGO_PIPE, ALGO_CONST, ALGO_CHUNK, ALGO_FIR = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -56,6 +56,7 @@ EXPORTS = (
     "mlpg_hip_unit_mse_workspace_bytes_t",
     "mlpg_hip_unit_mse_form",
     "mlpg_hip_host_copy",
+    "mlpg_hip_backward_host",
 )
 
 
@@ -122,6 +123,8 @@ def lib():
         L.mlpg_hip_forward.argtypes = [ci, vp, ci, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
         L.mlpg_hip_forward_host.restype = ci
         L.mlpg_hip_forward_host.argtypes = [ci, ci, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
+        L.mlpg_hip_backward_host.restype = ci
+        L.mlpg_hip_backward_host.argtypes = [ci, ci, ci, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
         L.mlpg_hip_fastdtw_host.restype = ci
         L.mlpg_hip_fastdtw_host.argtypes = [ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_double, ci, ctypes.c_double,
                                             vp, vp, vp, vp, vp, vp]
@@ -449,6 +452,47 @@ def forward_host(mean, var, windows, lengths=None, algo=ALGO_AUTO, device=None):
         if rc != 0:
             _check(rc, "mlpg_hip_forward_host")
     return out, status
+
+
+def backward_host(var, grad_out, windows, D, out_dtype=np.float32, lengths=None, algo=ALGO_AUTO, device=None):
+    """MLPG backward, numpy in -> numpy out through mlpg_hip_backward_host (no torch involved): grad_out (B, T, sd)
+    float32/float64 C-contiguous, var (B, T, D) / (D,) of the same dtype / None (unit variances), lengths int32 (B,) or None.
+    Returns (grad (B, T, D) of out_dtype, status int32 (B, sd)).  The literal paramgen.mlpg_grad call and the backward of
+    autograd.MLPG on CPU tensors: the library's short path (see forward_host), in pieces of whole utterances."""
+    global _host_gpu_seen
+    L = lib()
+    if not _host_gpu_seen:
+        if L.mlpg_hip_device_count() <= 0:
+            raise HipExtensionError("nnmnkwii_amd needs an AMD GPU (none visible to the HIP runtime); there is no CPU fallback")
+        _host_gpu_seen = True
+    assert grad_out.ndim == 3 and grad_out.flags.c_contiguous and grad_out.dtype in (np.float32, np.float64)
+    B, T, sd = grad_out.shape
+    pw = cached_windows(windows)
+    nw = pw[3]
+    assert D == nw * sd
+    pl, pu, pc = pw.ptrs()
+    dt = F32 if grad_out.dtype == np.float32 else F64
+    out_dtype = np.dtype(out_dtype)
+    assert out_dtype in (np.float32, np.float64)
+    if var is None:
+        mode, pv = VAR_UNIT, None
+    else:
+        assert var.dtype == grad_out.dtype and var.flags.c_contiguous
+        mode = VAR_GLOBAL if var.ndim == 1 else VAR_FRAME
+        assert var.shape == ((D,) if var.ndim == 1 else (B, T, D))
+        pv = var.ctypes.data
+    plen = None
+    if lengths is not None:
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        assert lengths.shape == (B,)
+        plen = lengths.ctypes.data
+    grad = np.empty((B, T, D), dtype=out_dtype)
+    status = np.zeros((B, sd), dtype=np.int32)
+    rc = L.mlpg_hip_backward_host(current_device_index(device), dt, F32 if out_dtype == np.float32 else F64, algo, pv, mode,
+                                  grad_out.ctypes.data, plen, B, T, D, nw, pl, pu, pc, grad.ctypes.data, status.ctypes.data)
+    if rc != 0:
+        _check(rc, "mlpg_hip_backward_host")
+    return grad, status
 
 
 class _PinnedOwner(object):

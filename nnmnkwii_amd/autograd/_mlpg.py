@@ -68,6 +68,11 @@ class MLPG(Function):
     @staticmethod
     def backward(ctx, grad_output):
         means, variances = ctx.saved_tensors
+        if not means.is_cuda and not variances.is_cuda and not grad_output.is_cuda:
+            # CPU tensors (the reference: paramgen.mlpg_grad on .numpy(), autograd/_impl/mlpg.py:57-67): the host-memory entry
+            # point's short path, as in forward
+            g = G.mlpg_grad(means.detach().numpy(), variances.detach().numpy(), ctx.windows, grad_output.detach().numpy())
+            return torch.from_numpy(g).to(means.dtype), None, None
         dev = _hip.require_gpu(means.device if means.is_cuda else None)
         v = _to_gpu(variances, dev)
         if v.dtype not in (torch.float32, torch.float64):

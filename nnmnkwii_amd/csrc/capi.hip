@@ -393,7 +393,7 @@ using namespace mlpg;
 
 extern "C" {
 
-__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 13; }
+__attribute__((visibility("default"))) int mlpg_hip_abi_version(void) { return 14; }
 
 __attribute__((visibility("default"))) long long mlpg_hip_launch_count(int kind) {
   if (kind >= 100) return host_chunks_on_device(kind - 100);  // chunks the host-memory calls enqueued on device kind - 100

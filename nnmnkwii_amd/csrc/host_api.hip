@@ -595,9 +595,11 @@ int run_chunks(const DevList &dl, long nchunks, Submit submit, Collect collect) 
   return rc;
 }
 
-// One small MLPG call on one device (see SmallCtx); g_host_mu is held by the caller.
-int forward_host_small(int device, int dtype, int algo, const void *mean_h, const void *var_h, int var_mode, const int32_t *lengths_h,
-                       int B, int Tmax, int D, int num_windows, const WinSet &ws, void *out_h, int32_t *status_h) {
+// One small MLPG call on one device (see SmallCtx), forward (first_h = the means (B, Tmax, D), out_h = the trajectories (B, Tmax, sd),
+// both `dtype`) or backward (first_h = grad_out (B, Tmax, sd) of `dtype`, out_h = the gradient (B, Tmax, D) of `out_dtype`);
+// g_host_mu is held by the caller.
+int host_small(int device, int dtype, int out_dtype, int algo, bool backward, const void *first_h, const void *var_h, int var_mode,
+               const int32_t *lengths_h, int B, int Tmax, int D, int num_windows, const WinSet &ws, void *out_h, int32_t *status_h) {
   HostTrace tr;
   int prev = -1;
   MLPG_HIP_CHECK(hipGetDevice(&prev));
@@ -607,11 +609,12 @@ int forward_host_small(int device, int dtype, int algo, const void *mean_h, cons
     ~Restore() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
   } restore{prev, device};
   SmallCtx &c = g_small[device];
-  const size_t esz = dtype == MLPG_HIP_F32 ? 4 : 8;
+  const size_t esz = dtype == MLPG_HIP_F32 ? 4 : 8, esz_out = out_dtype == MLPG_HIP_F32 ? 4 : 8;
   const int sd = D / num_windows;
   const bool fvar = var_mode == MLPG_HIP_VAR_FRAME;
-  const size_t mean_bytes = (size_t)B * Tmax * D * esz, out_bytes = (size_t)B * Tmax * sd * esz;
-  const size_t var_bytes = fvar ? mean_bytes : (var_mode == MLPG_HIP_VAR_GLOBAL ? (size_t)D * esz : 0);
+  const size_t mean_bytes = (size_t)B * Tmax * (backward ? sd : D) * esz;  // (the first array: means, or grad_out in a backward call)
+  const size_t out_bytes = (size_t)B * Tmax * (backward ? D : sd) * esz_out;
+  const size_t var_bytes = fvar ? (size_t)B * Tmax * D * esz : (var_mode == MLPG_HIP_VAR_GLOBAL ? (size_t)D * esz : 0);
   const size_t len_bytes = lengths_h ? (size_t)B * sizeof(int32_t) : 0, st_bytes = (size_t)B * sd * sizeof(int32_t);
   const size_t o_var = up256(mean_bytes), o_len = o_var + up256(var_bytes), in_total = o_len + up256(len_bytes);
   const size_t o_status = up256(out_bytes), out_total = o_status + up256(st_bytes);
@@ -643,7 +646,7 @@ int forward_host_small(int device, int dtype, int algo, const void *mean_h, cons
     (void)hipGetLastError();
     return rc;
   };
-  if (int rc = stage_send(0, mean_h, mean_bytes, 0)) return drained(rc);
+  if (int rc = stage_send(0, first_h, mean_bytes, 0)) return drained(rc);
   if (len_bytes) memcpy(c.pin_in + o_len, lengths_h, len_bytes);
   // (variances and lengths are neighbours in the staging buffer: the lengths ride on the variances' last transfer)
   if (var_bytes) {
@@ -655,9 +658,9 @@ int forward_host_small(int device, int dtype, int algo, const void *mean_h, cons
     }
   }
   Problem p;
-  p.mean = src;
+  p.mean = backward ? nullptr : src;
   p.var = var_bytes ? src + o_var : nullptr;
-  p.grad_out = nullptr;
+  p.grad_out = backward ? src : nullptr;
   p.lengths = len_bytes ? (const int32_t *)(src + o_len) : nullptr;
   p.out = c.pin_out;  // pinned host memory: written by the kernel over PCIe
   p.status = (int32_t *)(c.pin_out + o_status);
@@ -667,11 +670,11 @@ int forward_host_small(int device, int dtype, int algo, const void *mean_h, cons
   p.D = D;
   p.sd = sd;
   p.ld_in = D;
-  p.ld_gout = 0;
-  p.ld_out = sd;
+  p.ld_gout = backward ? sd : 0;
+  p.ld_out = backward ? D : sd;
   p.ld_status = sd;
   const double ts = tr.on ? HostTrace::now() : 0.0;
-  int rc = dispatch_solve(c.st, dtype, dtype, algo, false, p, ws, device);
+  int rc = dispatch_solve(c.st, dtype, out_dtype, algo, backward, p, ws, device);
   if (!rc) rc = small_wait(c);
   if (rc) return drained(rc);
   const double tw = tr.on ? HostTrace::now() : 0.0;
@@ -785,7 +788,7 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_host_multi(const int
   const size_t utt_in = (size_t)Tmax * D * esz, utt_out = (size_t)Tmax * sd * esz;
   // one small call on one device: the short path (no chunk plan, no thread, one stream)
   if (dl.n == 1 && (size_t)B * utt_in * (fvar ? 2 : 1) <= small_limit_bytes())
-    return forward_host_small(dl.dev[0], dtype, algo, mean_h, var_h, var_mode, lengths_h, B, Tmax, D, num_windows, ws, out_h, status_h);
+    return host_small(dl.dev[0], dtype, dtype, algo, false, mean_h, var_h, var_mode, lengths_h, B, Tmax, D, num_windows, ws, out_h, status_h);
   const bool mean_pinned = is_pinned(mean_h), var_pinned = fvar && is_pinned(var_h), out_pinned = is_pinned(out_h);
 
   // ~64 MB of input per chunk
@@ -873,6 +876,61 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_host(int device, int
   const int32_t one = device;
   return mlpg_hip_forward_host_multi(&one, 1, dtype, algo, mean_h, var_h, var_mode, lengths_h, B, Tmax, D, num_windows, win_l_h,
                                      win_u_h, win_coef_h, out_h, status_h);
+}
+
+// MLPG backward on HOST memory: the literal paramgen.mlpg_grad call (paramgen/_mlpg.py:202-281: numpy in, float32 numpy out) and the
+// backward of autograd.MLPG on CPU tensors (autograd/_impl/mlpg.py:57-67).  var_h / grad_out_h of in_dtype, grad_h (B, Tmax, D) of
+// out_dtype, status_h (B * sd, may be NULL).  The batch goes through the short path of mlpg_hip_forward_host (one stream, pinned
+// staging, the kernel writes the gradient into pinned host memory) in pieces of whole utterances of at most MLPG_HIP_HOST_SMALL_MB of
+// input each, one after the other: the reference's call is one utterance; a large batch is better served by mlpg_hip_backward on
+// device memory.
+__attribute__((visibility("default"))) int mlpg_hip_backward_host(int device, int in_dtype, int out_dtype, int algo, const void *var_h,
+                                                                  int var_mode, const void *grad_out_h, const int32_t *lengths_h,
+                                                                  int B, int Tmax, int D, int num_windows, const int32_t *win_l_h,
+                                                                  const int32_t *win_u_h, const double *win_coef_h, void *grad_h,
+                                                                  int32_t *status_h) {
+  if (device < 0 || device >= kMaxHostDevices) {
+    set_error("bad device %d", device);
+    return MLPG_HIP_EINVAL;
+  }
+  if (B < 0 || Tmax < 0 || D < 0 || num_windows < 1 || D % num_windows != 0) {
+    set_error("backward_host: bad sizes (B=%d, Tmax=%d, D=%d, num_windows=%d)", B, Tmax, D, num_windows);
+    return MLPG_HIP_EINVAL;
+  }
+  if ((in_dtype != MLPG_HIP_F32 && in_dtype != MLPG_HIP_F64) || (out_dtype != MLPG_HIP_F32 && out_dtype != MLPG_HIP_F64)) {
+    set_error("dtype must be MLPG_HIP_F32 or MLPG_HIP_F64");
+    return MLPG_HIP_EINVAL;
+  }
+  if (var_mode < 0 || var_mode > 2 || (var_mode != MLPG_HIP_VAR_UNIT && !var_h)) {
+    set_error("bad var_mode %d / NULL var", var_mode);
+    return MLPG_HIP_EINVAL;
+  }
+  WinSet ws;
+  if (int rc = pack_windows_public(num_windows, win_l_h, win_u_h, win_coef_h, &ws)) return rc;
+  if ((long)B * Tmax * D == 0) return 0;
+  if (!grad_out_h || !grad_h) {
+    set_error("NULL data pointer");
+    return MLPG_HIP_EINVAL;
+  }
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  const int32_t one = device;
+  DevList dl;
+  if (int rc = resolve_devices(&one, 1, &dl)) return rc;
+  const bool fvar = var_mode == MLPG_HIP_VAR_FRAME;
+  const size_t esz = in_dtype == MLPG_HIP_F32 ? 4 : 8, esz_out = out_dtype == MLPG_HIP_F32 ? 4 : 8;
+  const int sd = D / num_windows;
+  const size_t utt_go = (size_t)Tmax * sd * esz, utt_var = fvar ? (size_t)Tmax * D * esz : 0, utt_grad = (size_t)Tmax * D * esz_out;
+  const size_t lim = std::max<size_t>(small_limit_bytes(), 1u << 20);
+  const int per = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, lim / (utt_go + utt_var)));
+  for (int b0 = 0; b0 < B; b0 += per) {
+    const int nb = std::min(per, B - b0);
+    const char *v = !var_h ? nullptr : (fvar ? (const char *)var_h + (size_t)b0 * utt_var : (const char *)var_h);
+    if (int rc = host_small(dl.dev[0], in_dtype, out_dtype, algo, true, (const char *)grad_out_h + (size_t)b0 * utt_go, v, var_mode,
+                            lengths_h ? lengths_h + b0 : nullptr, nb, Tmax, D, num_windows, ws, (char *)grad_h + (size_t)b0 * utt_grad,
+                            status_h ? status_h + (size_t)b0 * sd : nullptr))
+      return rc;
+  }
+  return 0;
 }
 
 // fastdtw for N utterance pairs held in HOST memory: what DTWAligner.transform (preprocessing/alignment.py:41-76) does

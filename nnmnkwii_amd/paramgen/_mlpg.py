@@ -157,15 +157,20 @@ def _mlpg_batch_host(means, variances, windows, lengths, algo, check, device):
     # default: the process's current GPU, not GPU 0; a list of indices or "all": the chunks dealt over those devices
     out, status = _hip.forward_host(m, v, windows, lengths, algo=algo, device=device)
     if check and status.any():
-        st = status.ravel()
-        bad = np.flatnonzero(st)
-        if bad.size:
-            k = int(st[bad[0]])
-            if k > 0:
-                raise np.linalg.LinAlgError("%d-th leading minor not positive definite" % k)
-            raise np.linalg.LinAlgError("the blocked elimination broke down (numerically singular system)" if k == -2
-                                        else "internal error: inter-workgroup wait timed out")
+        _raise_host_status(status)
     return out if out.dtype == out_dtype else out.astype(out_dtype)
+
+
+def _raise_host_status(status):
+    """The reference's LinAlgError (linalg.pyx:79-82) for the first failing (utterance, dim) system of a host-memory call."""
+    st = status.ravel()
+    bad = np.flatnonzero(st)
+    if bad.size:
+        k = int(st[bad[0]])
+        if k > 0:
+            raise np.linalg.LinAlgError("%d-th leading minor not positive definite" % k)
+        raise np.linalg.LinAlgError("the blocked elimination broke down (numerically singular system)" if k == -2
+                                    else "internal error: inter-workgroup wait timed out")
 
 
 def multi_stream_mlpg(inputs, variances, windows, stream_sizes, has_dynamic_features, lengths=None,
@@ -272,22 +277,23 @@ def mlpg_grad(mean_frames, variance_frames, windows, grad_output):
     Drop-in for ``nnmnkwii.paramgen.mlpg_grad`` (paramgen/_mlpg.py:202-281).
     The reference solves a dense ``T x T`` right-hand side per (dim, window);
     the HIP kernel computes the same quantity in O(T):
-    ``grad[:, w*sd+d] = tau_w * (W_w P_d^-1 o_d)``.
+    ``grad[:, w*sd+d] = tau_w * (W_w P_d^-1 o_d)``.  ``variance_frames`` ``(T, D)``, or a global ``(D,)`` (the reference
+    leaves that broadcast to its caller, autograd/_impl/mlpg.py:196-197).
     """
-    torch = _hip.torch_mod()
     mean_frames = np.asarray(mean_frames)
-    variance_frames = _as_float(variance_frames)
+    v = np.ascontiguousarray(_as_float(variance_frames))
     T, D = mean_frames.shape
-    dev = _hip.require_gpu()
-    dt = torch.float32 if variance_frames.dtype == np.float32 else torch.float64
-    v = torch.from_numpy(np.ascontiguousarray(variance_frames)).to(dev)
-    if v.dim() == 2:
+    if v.ndim == 2:
         assert v.shape == (T, D)
         v = v[None]
-    go = torch.from_numpy(np.ascontiguousarray(np.asarray(grad_output))).to(device=dev, dtype=dt)[None].contiguous()
-    grad, status = _hip.backward(v, go, windows, D, out_dtype=torch.float32)
-    _hip.raise_on_status(status, D // len(windows))
-    return grad[0].cpu().numpy()
+    # numpy in -> numpy out through the host-memory entry point (mlpg_hip_backward_host: the library's short path -- no torch
+    # tensor, one C call; the arithmetic runs in the variances' dtype class as before: float32 variances -> float32 inputs)
+    go = np.ascontiguousarray(np.asarray(grad_output), dtype=v.dtype)
+    assert go.shape == (T, D // len(windows))
+    grad, status = _hip.backward_host(v, go[None], windows, D, out_dtype=np.float32)
+    if status.any():
+        _raise_host_status(status)
+    return grad[0]
 
 
 # registry of MLPG matrices handed out by unit_variance_mlpg_matrix, so that

@@ -31,7 +31,7 @@ def test_exports_match_header(L):
     assert declared == set(_hip.EXPORTS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.mlpg_hip_abi_version() == _hip.ABI_VERSION == 13
+    assert L.mlpg_hip_abi_version() == _hip.ABI_VERSION == 14
 
 
 def test_argument_validation_without_gpu(L):
@@ -81,6 +81,26 @@ def test_unit_mse_form_validates_without_gpu(L):
     assert L.mlpg_hip_unit_mse_form(0, None, 9, 0, 2, 100, 4, 2, p(wl), p(wu), p(wc)) == -1      # bad dtype
     assert L.mlpg_hip_unit_mse_form(0, None, 0, 0, 0, 100, 4, 2, p(wl), p(wu), p(wc)) == 1       # an empty batch: the step answers it
     assert L.mlpg_hip_launch_count(10) >= 0 and L.mlpg_hip_launch_count(11) >= 0 and L.mlpg_hip_launch_count(12) == -1
+
+
+def test_backward_host_validates_without_gpu(L):
+    """mlpg_hip_backward_host (ABI 14: the literal paramgen.mlpg_grad call on host memory): argument errors and empty
+    batches are answered before any device is touched."""
+    wl = np.array([0, 1], dtype=np.int32)
+    wu = np.array([0, 1], dtype=np.int32)
+    wc = np.array([1.0, -0.5, 0.0, 0.5])
+    go = np.zeros((1, 4, 2))
+    var = np.ones((1, 4, 4))
+    grad = np.zeros((1, 4, 4), dtype=np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    args = (p(wl), p(wu), p(wc), p(grad), None)
+    assert L.mlpg_hip_backward_host(0, 1, 0, 0, p(var), 0, p(go), None, 1, 4, 5, 2, *args) == -1       # D not a multiple of nw
+    assert b"bad sizes" in L.mlpg_hip_last_error()
+    assert L.mlpg_hip_backward_host(0, 7, 0, 0, p(var), 0, p(go), None, 1, 4, 4, 2, *args) == -1       # bad dtype
+    assert L.mlpg_hip_backward_host(0, 1, 0, 0, None, 0, p(go), None, 1, 4, 4, 2, *args) == -1         # per-frame variances, NULL
+    assert L.mlpg_hip_backward_host(-1, 1, 0, 0, p(var), 0, p(go), None, 1, 4, 4, 2, *args) == -1       # bad device
+    assert L.mlpg_hip_backward_host(0, 1, 0, 0, p(var), 0, p(go), None, 0, 4, 4, 2, *args) == 0        # an empty batch
+    assert L.mlpg_hip_backward_host(0, 1, 0, 0, p(var), 0, p(go), None, 1, 0, 4, 2, *args) == 0        # no frames
 
 
 def test_host_copy_pool_copies_every_byte_and_survives_shutdown(L):
@@ -283,7 +303,7 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, env=env)
     assert out.returncode == 0, out.stdout
-    assert out.stdout.split() == ["13", "5", "3"], out.stdout
+    assert out.stdout.split() == ["14", "5", "3"], out.stdout
 
 
 def test_host_chunk_plan_deals_round_robin_and_covers_the_batch():

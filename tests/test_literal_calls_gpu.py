@@ -2,7 +2,7 @@
 per utterance, as the reference's users write it (paramgen/_mlpg.py:92; the loop: util/__init__.py:56-66).
 
 Such a call is small -- 9.6 KB at BASELINE config 1, 2.9 MB at one config-2 utterance -- and takes the SHORT PATH of
-mlpg_hip_forward_host (csrc/host_api.hip forward_host_small: one stream, one pinned staging buffer, no thread, the kernel
+mlpg_hip_forward_host (csrc/host_api.hip host_small: one stream, one pinned staging buffer, no thread, the kernel
 writing into pinned host memory, a polled sequence number).  Checked here: WHICH route a call takes (the library's call
 counters 10 / 11), parity of that route with the oracle in every variance mode / dtype / with lengths / at the edge
 lengths, the reference's exception for a failing pivot, that the per-list window cache follows in-place edits, growth of
@@ -231,3 +231,111 @@ def test_a_config2_utterance_call_is_faster_than_the_reference_by_a_wide_margin(
         G.mlpg(m, v, W)
         ts.append(time.perf_counter() - t0)
     assert float(np.median(ts)) < 1e-3, np.median(ts)
+
+
+# ---- the literal backward call: paramgen.mlpg_grad on numpy arrays, autograd.MLPG on CPU tensors (mlpg_hip_backward_host) ----
+
+def _grad_rel(g, gr):
+    gr = gr.astype(np.float64)                        # (the oracle's gradient is float32, as the reference's)
+    scale = np.abs(gr).max(axis=0) + 1e-300
+    return float((np.abs(g.astype(np.float64) - gr) / scale).max())
+
+
+def test_mlpg_grad_config1_takes_the_direct_route_and_matches_the_oracle():
+    """paramgen.mlpg_grad(mean_frames, variance_frames, windows, grad_output) at BASELINE config 1 (T = 100, 2 static dims):
+    the short path with the kernel reading the pinned staging buffer, float32 (T, D) out as the reference (_mlpg.py:248)."""
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(11)
+    m = rng.rand(100, 6)
+    v = rng.rand(100, 6) + 0.1
+    go = rng.randn(100, 2)
+    c0, d0 = _routes()
+    g = G.mlpg_grad(m, v, W, go)
+    assert _routes() == (c0, d0 + 1)
+    assert g.shape == (100, 6) and g.dtype == np.float32
+    assert _grad_rel(g, O.mlpg_grad(m, v, W, go)) <= 1e-6            # (float32 result)
+    # float32 variances, float64 grad_output: the arithmetic's inputs are float32, as through the device entry point
+    g32 = G.mlpg_grad(m, v.astype(np.float32), W, go)
+    assert g32.dtype == np.float32 and _grad_rel(g32, O.mlpg_grad(m, v.astype(np.float32).astype(np.float64), W, go.astype(np.float32))) <= 2e-5
+    # a global (D,) variance vector
+    gg = G.mlpg_grad(m, v[0], W, go)
+    assert _grad_rel(gg, O.mlpg_grad(m, np.tile(v[0], (100, 1)), W, go)) <= 1e-6
+
+
+@pytest.mark.parametrize("wname", ["std3", "std2", "wide3", "asym2"])
+@pytest.mark.parametrize("T,sd", [(1, 3), (2, 1), (3, 2), (5, 7), (17, 1), (64, 60), (333, 25), (1000, 60), (2049, 5)])
+def test_mlpg_grad_short_path_against_the_device_entry_point(wname, T, sd):
+    """Every length / width / window set: the host-memory call returns exactly what mlpg_hip_backward returns for the same arrays on
+    the device (same kernels, same routing; only where the arrays live differs), and the oracle's dense gradient for the small ones."""
+    import torch
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd import paramgen as G
+    w = WINDOW_SETS[wname]
+    nw = len(w)
+    rng = np.random.RandomState(T * 131 + sd)
+    m = np.zeros((T, nw * sd))
+    v = rng.rand(T, nw * sd) + 0.1
+    go = rng.randn(T, sd)
+    g = G.mlpg_grad(m, v, w, go)
+    gd, st = _hip.backward(torch.from_numpy(v[None]).cuda(), torch.from_numpy(go[None]).cuda(), w, nw * sd, out_dtype=torch.float32)
+    assert int(st.abs().max()) == 0
+    assert np.array_equal(g, gd[0].cpu().numpy())
+    if T <= 333:
+        assert _grad_rel(g, O.mlpg_grad(m, v, w, go)) <= 2e-6
+
+
+def test_mlpg_grad_batches_are_cut_into_pieces_of_whole_utterances():
+    """mlpg_hip_backward_host on a batch larger than the short path's limit: pieces of whole utterances, one after the other; lengths
+    and the status rows follow their utterances; global and unit variances."""
+    import torch
+    from nnmnkwii_amd import _hip
+    rng = np.random.RandomState(5)
+    B, T, sd = 9, 700, 60
+    V_ = rng.rand(B, T, 3 * sd) + 0.1                   # 9 x 1.0 MB of variances + 0.34 MB of grad_out each: pieces of 4 utterances
+    go = rng.randn(B, T, sd)
+    lengths = np.array([700, 1, 350, 0, 699, 700, 2, 3, 500], dtype=np.int32)
+    c0, d0 = _routes()
+    g, st = _hip.backward_host(V_, go, W, 3 * sd, out_dtype=np.float64, lengths=lengths)
+    c1, d1 = _routes()
+    assert (c1 - c0) + (d1 - d0) == 3 and not st.any()
+    gd, _ = _hip.backward(torch.from_numpy(V_).cuda(), torch.from_numpy(go).cuda(), W, 3 * sd, lengths=torch.from_numpy(lengths).cuda(),
+                          out_dtype=torch.float64)
+    assert np.array_equal(g, gd.cpu().numpy())
+    for b in range(B):
+        assert not g[b, lengths[b]:].any()
+    for var in (V_[0, 0].copy(), None):
+        g, st = _hip.backward_host(var, go, W, 3 * sd, out_dtype=np.float32)
+        gd, _ = _hip.backward(None if var is None else torch.from_numpy(var).cuda(), torch.from_numpy(go).cuda(), W, 3 * sd, out_dtype=torch.float32)
+        assert np.array_equal(g, gd.cpu().numpy()) and not st.any()
+    # a failing pivot in utterance 6 of 9: the reference's exception, with its k
+    V_bad = V_.copy()
+    V_bad[6, 41, 7] = -1e-9
+    g, st = _hip.backward_host(V_bad, go, W, 3 * sd)
+    assert st[6, 7] == 42 and not np.delete(st, 6, axis=0).any()
+    from nnmnkwii_amd import paramgen as G
+    with pytest.raises(np.linalg.LinAlgError, match="42-th leading minor not positive definite"):
+        G.mlpg_grad(np.zeros((T, 3 * sd)), V_bad[6], W, go[6])
+
+
+def test_autograd_mlpg_on_cpu_tensors_runs_both_passes_on_the_short_path():
+    """autograd.mlpg on CPU tensors (the reference's tensors, autograd/_impl/mlpg.py:50-67): forward and backward are one host-memory
+    call each (no torch device tensor), float32 out, the gradient equal to paramgen.mlpg_grad's and in the means' dtype."""
+    import torch
+    from nnmnkwii_amd import autograd as AF
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(2)
+    for T, sd, dt in ((100, 2, torch.float32), (1000, 60, torch.float32), (100, 2, torch.float64)):
+        m = torch.from_numpy(rng.rand(T, 3 * sd)).to(dt).requires_grad_()
+        v = torch.from_numpy(rng.rand(T, 3 * sd) + 0.1).to(dt)
+        wgt = torch.from_numpy(rng.randn(T, sd)).to(torch.float32)
+        r0 = sum(_routes())
+        y = AF.mlpg(m, v, W)
+        (y * wgt).sum().backward()
+        assert sum(_routes()) == r0 + 2
+        assert y.dtype == torch.float32 and m.grad.dtype == dt and not m.grad.is_cuda
+        want = G.mlpg_grad(m.detach().numpy(), v.numpy(), W, wgt.numpy())
+        assert np.array_equal(m.grad.numpy(), want.astype(m.grad.numpy().dtype))
+        # the same through CUDA tensors
+        mc = m.detach().cuda().requires_grad_()
+        (AF.mlpg(mc, v.cuda(), W) * wgt.cuda()).sum().backward()
+        assert np.allclose(mc.grad.cpu().numpy(), m.grad.numpy(), rtol=2e-5, atol=1e-7)

@@ -211,6 +211,8 @@ def literal_calls(emit, quick=False, long_reference_backward=True):
         us_f, _ = _wall_us(lambda: AF.mlpg(mt.detach(), vt, WINDOWS), nrep)
         us_fb, _ = _wall_us(fb, nrep)
         mn, vn = mt.detach().numpy(), vt.numpy()
+        go_n = np.random.RandomState(5).randn(T, sd).astype(np.float32)
+        us_g, _ = _wall_us(lambda: G.mlpg_grad(mn, vn, WINDOWS, go_n), nrep)    # the literal numpy -> numpy paramgen.mlpg_grad call
 
         class RefMLPG(torch.autograd.Function):
             # what the reference's node does (autograd/_impl/mlpg.py:50-67): paramgen.mlpg / mlpg_grad on .numpy() views
@@ -235,7 +237,7 @@ def literal_calls(emit, quick=False, long_reference_backward=True):
             gerr = float(np.abs(mt.grad.numpy() - gr).max())
         else:
             gerr = None
-        emit(path=name, us_forward=us_f, us_forward_backward=us_fb, cpu_us_forward=rus_f, cpu_us_backward_mlpg_grad=rus_b,
+        emit(path=name, us_forward=us_f, us_forward_backward=us_fb, us_paramgen_mlpg_grad=us_g, cpu_us_forward=rus_f, cpu_us_backward_mlpg_grad=rus_b,
              cpu_kind=ref_kind + " inside a torch.autograd.Function, as the reference's node calls it",
              grad_abs_err_vs_cpu=gerr, T=T, D=3 * sd)
     # DTWAligner.transform on ONE pair (alignment.py:41-76 is a per-pair loop)

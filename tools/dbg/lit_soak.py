@@ -29,7 +29,7 @@ WSETS = {
 }
 L = _hip.lib()
 t_end = time.time() + seconds
-n = n_fail = n_direct = n_copied = n_big = 0
+n = n_fail = n_direct = n_copied = n_big = n_bwd = 0
 worst = {np.float64: 0.0, np.float32: 0.0}
 routes0 = [int(L.mlpg_hip_launch_count(k)) for k in range(12)]
 while time.time() < t_end:
@@ -103,9 +103,27 @@ while time.time() < t_end:
         tol = (1e-7 if spread >= 3.0 else 1e-9) if dt == np.float64 else 2e-3 if spread >= 3.0 else 5e-5
         assert err <= tol, ("case %d: %s T=%d sd=%d B=%d mode %d %s spread %g: rel err %.3e" % (n, wname, T, sd, B, mode, dt.__name__, spread, err))
         assert not y[b, tl:].any()
+    # the literal backward call on the same variances (mlpg_hip_backward_host) against mlpg_hip_backward on device copies: same
+    # kernels and routing, so the two must agree bit for bit; small ones also against the oracle's dense mlpg_grad
+    if mode != 2 and not bad and n % 3 == 0:
+        import torch
+        go = rng.randn(B, T, sd).astype(dt)
+        od = np.float32 if rng.rand() < 0.7 else np.float64
+        g, st = _hip.backward_host(var if mode == 1 else V, go, w, nw * sd, out_dtype=od, lengths=lengths)
+        vd = torch.from_numpy(var if mode == 1 else V).cuda()
+        gd, std = _hip.backward(vd, torch.from_numpy(go).cuda(), w, nw * sd, lengths=None if lengths is None else torch.from_numpy(lengths).cuda(),
+                                out_dtype=torch.float32 if od == np.float32 else torch.float64)
+        assert np.array_equal(st.ravel(), std.cpu().numpy().ravel()) and np.array_equal(g, gd.cpu().numpy()), (
+            "case %d backward: %s T=%d sd=%d B=%d mode %d %s" % (n, wname, T, sd, B, mode, dt.__name__))
+        n_bwd += 1
+        if T <= 200 and lengths is None and dt == np.float64 and spread < 3.0:
+            gr = O.mlpg_grad(np.zeros((T, nw * sd)), V[0] if mode == 0 else np.tile(var, (T, 1)), w, go[0]).astype(np.float64)
+            sc = np.abs(gr).max(axis=0) + 1e-300
+            assert float((np.abs(g[0].astype(np.float64) - gr) / sc).max()) <= 2e-6, "case %d backward vs oracle" % n
 routes1 = [int(L.mlpg_hip_launch_count(k)) for k in range(12)]
 names = "generic wave strip strip-multi const fused chunk fir const-multi strip-tr short-copied short-direct".split()
 print("lit soak: %d calls in %.0f s (%d of them with a failing pivot: the reference's exception and k), %d on the short path with copied inputs, "
-      "%d with the kernel reading pinned inputs, %d beside it; worst rel err float64 %.2e float32 %.2e; no mismatch"
-      % (n, seconds, n_fail, n_copied, n_direct, n_big, worst[np.float64], worst[np.float32]))
+      "%d with the kernel reading pinned inputs, %d beside it; %d backward calls (mlpg_hip_backward_host == mlpg_hip_backward bit for bit); "
+      "worst rel err float64 %.2e float32 %.2e; no mismatch"
+      % (n, seconds, n_fail, n_copied, n_direct, n_big, n_bwd, worst[np.float64], worst[np.float32]))
 print("kernel launches by family:", {nm: b - a for nm, a, b in zip(names, routes0, routes1) if b != a})
