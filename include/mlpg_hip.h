@@ -164,12 +164,15 @@ int mlpg_hip_forward(int device, void *stream, int dtype, int algo,
  * memory is staged through pinned buffers by a few copy threads, memory from mlpg_hip_host_alloc (or any pinned /
  * registered host memory) is transferred in place.  All pointers are HOST pointers; shapes, dtypes, windows,
  * var_mode and status as for mlpg_hip_forward (lengths_h may be NULL).
- * A SMALL call -- at most 6 MB of input (MLPG_HIP_HOST_SMALL_MB) on one device: the literal per-utterance
+ * A SMALL call -- at most 64 MB of input (MLPG_HIP_HOST_SMALL_MB) on one device: the literal per-utterance
  * paramgen.mlpg(mean_frames (T, D), variance_frames, windows) of the reference (_mlpg.py:92), 9.6 KB at T = 100 x 2 static
- * dims, 2.9 MB at T = 1000 x 60 -- takes a short path instead: one stream, one cached pinned staging buffer, no chunk plan and
- * no thread; the arrays are staged and sent one behind the other (up to 48 KB the kernel reads the pinned buffer itself), the
- * kernel writes trajectory and verdicts straight into pinned host memory, and the host polls a sequence number written behind
- * them (round 6; mlpg_hip_launch_count(10 / 11) counts these calls).
+ * dims, 2.9 MB at T = 1000 x 60, and batches of a few utterances -- takes a short path instead: one stream, one cached pinned
+ * staging buffer, no chunk plan and no thread; the arrays are staged and sent one behind the other (up to 48 KB the kernel reads
+ * the pinned buffer itself), the kernel writes trajectory and verdicts straight into pinned host memory, and the host polls a
+ * sequence number written behind them (round 6; mlpg_hip_launch_count(10 / 11) counts these calls).  An array of at least 1.2 MB
+ * (MLPG_HIP_HOST_DIRECT_KB) that the library has been handed before (same address and size, one of its last 16), and any array of
+ * at least 4 MB (MLPG_HIP_HOST_DIRECT_ALWAYS_KB), is not staged: the runtime copies it straight from -- the result: to -- the
+ * caller's pageable memory at the pinned rate (mapping pages the device has never seen costs more than staging them, up to a few MB).
  */
 int mlpg_hip_forward_host(int device, int dtype, int algo, const void *mean_h,
                           const void *var_h, int var_mode,

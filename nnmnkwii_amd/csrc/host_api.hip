@@ -215,8 +215,28 @@ inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 //     at 0.5 MB), followed by a one-thread kernel that writes a sequence number behind them;
 //   * the host polls that word instead of hipStreamSynchronize (6.3 against 10.9 us for an empty launch), looking at
 //     hipStreamQuery every few thousand polls so that a failed launch is an error, not a hang.
-// MLPG_HIP_HOST_SMALL_MB: calls of at most this many MB of input take the short path (default 6; 0: never).
+//   * an array of at least MLPG_HIP_HOST_DIRECT_KB (default 1200) is not staged at all: hipMemcpyAsync takes it straight from (the
+//     result: to) the caller's pageable memory at the pinned rate (host_small below; tools/dbg/pageable_direct.hip).
+// MLPG_HIP_HOST_SMALL_MB: calls of at most this many MB of input take the short path (default 64 -- up to there one stream and
+// the runtime's direct copies beat the chunk plan's threads by 1.6-1.9 x, profiles/r06_host_direct_ab.txt; 0: never).
+// The arrays (address, size) of the last calls that were large enough for a direct copy: see host_small.
+struct SeenArrays {
+  static constexpr int kN = 16;
+  const void *ptr[kN] = {};
+  size_t bytes[kN] = {};
+  int next = 0;
+  // was (p, n) handed in by one of the last calls?  remembers it either way
+  bool seen_and_note(const void *p, size_t n) {
+    for (int k = 0; k < kN; ++k)
+      if (ptr[k] == p && bytes[k] == n) return true;
+    ptr[next] = p;
+    bytes[next] = n;
+    next = (next + 1) % kN;
+    return false;
+  }
+};
 struct SmallCtx {
+  SeenArrays seen;
   hipStream_t st = nullptr;
   char *pin_in = nullptr, *pin_out = nullptr, *dev = nullptr;
   size_t pin_in_bytes = 0, pin_out_bytes = 0, dev_bytes = 0;
@@ -234,10 +254,29 @@ __global__ void small_flag_kernel(volatile unsigned *flag, unsigned v) {
 size_t small_limit_bytes() {
   static const size_t lim = [] {
     const char *e = getenv("MLPG_HIP_HOST_SMALL_MB");
-    const double v = e ? atof(e) : 6.0;
+    const double v = e ? atof(e) : 64.0;
     return (size_t)(v <= 0 ? 0 : v * 1048576.0);
   }();
   return lim;
+}
+// MLPG_HIP_HOST_DIRECT_KB: an array of at least this many KB that the library has been handed before (same address and size, one of
+// the last 16) is copied by the runtime straight from / to the caller's memory instead of through the pinned staging buffers
+// (default 1200; 0: never); MLPG_HIP_HOST_DIRECT_ALWAYS_KB: from this size on also an array seen for the first time (default 4096).
+size_t host_direct_bytes() {
+  static const size_t thr = [] {
+    const char *e = getenv("MLPG_HIP_HOST_DIRECT_KB");
+    const double v = e ? atof(e) : 1200.0;
+    return (size_t)(v <= 0 ? 0 : v * 1024.0);
+  }();
+  return thr;
+}
+size_t host_direct_always_bytes() {
+  static const size_t thr = [] {
+    const char *e = getenv("MLPG_HIP_HOST_DIRECT_ALWAYS_KB");
+    const double v = e ? atof(e) : 4096.0;
+    return (size_t)(v <= 0 ? 0 : v * 1024.0);
+  }();
+  return thr;
 }
 // MLPG_HIP_HOST_SMALL_WAIT=sync: hipStreamSynchronize instead of polling the flag word (A/B runs)
 bool small_wait_by_flag() {
@@ -616,10 +655,38 @@ int host_small(int device, int dtype, int out_dtype, int algo, bool backward, co
   const size_t out_bytes = (size_t)B * Tmax * (backward ? D : sd) * esz_out;
   const size_t var_bytes = fvar ? (size_t)B * Tmax * D * esz : (var_mode == MLPG_HIP_VAR_GLOBAL ? (size_t)D * esz : 0);
   const size_t len_bytes = lengths_h ? (size_t)B * sizeof(int32_t) : 0, st_bytes = (size_t)B * sd * sizeof(int32_t);
+  // device layout: [first | variances | lengths | (the result, when it goes back by a copy)]
   const size_t o_var = up256(mean_bytes), o_len = o_var + up256(var_bytes), in_total = o_len + up256(len_bytes);
-  const size_t o_status = up256(out_bytes), out_total = o_status + up256(st_bytes);
   const bool direct_in = in_total <= kSmallDirectIn;  // the kernel reads the pinned staging buffer itself
-  if (int rc = small_ensure(c, in_total, out_total, direct_in ? 0 : in_total)) return rc;
+  // A large array is not staged: hipMemcpyAsync takes it straight from / to the caller's (pageable) memory -- the runtime maps the
+  // pages for the copy engine, which then moves them at the pinned rate (tools/dbg/pageable_direct.hip: 1.44 MB 48-52 us against 45
+  // from pinned memory; the call blocks the host for the copy's time), where staging costs a memcpy in front of the first piece and
+  // a bubble per piece: a config-2 utterance 168 -> 131 us.  But the mapping of pages the device has never seen costs more than the
+  // staging it saves up to a few MB (a list of 48 distinct T = 2000 utterances, one call each: 462 against 390 us; from 5.8 MB per
+  // array on it is the other way round: 688 against 722-779 us), so the rule is: an array of at least host_direct_bytes() goes
+  // direct if the library was handed the same address and size in one of its last calls (a caller's preallocated buffer, a loop
+  // over a buffer that numpy's allocator hands out again), from host_direct_always_bytes() on also the first time
+  // (profiles/r06_host_direct_ab*.txt).  Below ~1 MB the runtime itself stages, and the kernel writing into pinned memory + one
+  // memcpy beats a device -> pageable copy (480 KB: 31 against 50 us).
+  const size_t thr = host_direct_bytes(), thr_always = host_direct_always_bytes();
+  auto via_runtime = [&](const void *ptr, size_t bytes) {
+    if (!thr || bytes < thr || !ptr) return false;
+    const bool seen = c.seen.seen_and_note(ptr, bytes);
+    return seen || (thr_always && bytes >= thr_always);
+  };
+  const bool first_rt = !direct_in && via_runtime(first_h, mean_bytes), var_rt = !direct_in && via_runtime(var_h, var_bytes),
+             out_rt = via_runtime(out_h, out_bytes);
+  // pinned layout: the staged arrays only (the same offsets as on the device when nothing goes direct)
+  size_t pin_need = 0;
+  const size_t p_first = pin_need;
+  if (!first_rt) pin_need += up256(mean_bytes);
+  const size_t p_var = pin_need;
+  if (!var_rt) pin_need += up256(var_bytes);
+  const size_t p_len = pin_need;
+  pin_need += up256(len_bytes);
+  const size_t o_status = out_rt ? 0 : up256(out_bytes), out_total = o_status + up256(st_bytes);
+  const size_t o_out_dev = direct_in ? 0 : in_total, dev_need = (direct_in ? 0 : in_total) + (out_rt ? up256(out_bytes) : 0);
+  if (int rc = small_ensure(c, pin_need, out_total, dev_need)) return rc;
   note_launch(direct_in ? kCountHostSmallDirect : kCountHostSmall);
   char *src = direct_in ? c.pin_in : c.dev;
   CopyPool *pool = CopyPool::get();  // (small copies are plain memcpys of the calling thread)
@@ -629,13 +696,14 @@ int host_small(int device, int dtype, int out_dtype, int algo, bool backward, co
   // 0.6 us -- and two streams do not move a pair of halves faster than one moves them in a row.)
   // (A shorter very first piece -- 64 / 192 / 384 KB, so that the copy engine starts earlier -- was measured in round 6: no difference
   // beyond the 8 % a config-2 utterance's call varies from process to process.)
-  auto stage_send = [&](size_t off, const void *from, size_t bytes, size_t tail) -> int {  // tail: staged bytes right behind, sent along
+  auto stage_send = [&](size_t pin_off, size_t dev_off, const void *from, size_t bytes, size_t tail) -> int {  // tail: staged bytes right behind, sent along
     constexpr size_t kPiece = 768u << 10;
     for (size_t o = 0; o < bytes;) {
       const size_t n = std::min(kPiece, bytes - o);
-      pool->copy(c.pin_in + off + o, (const char *)from + o, n);
+      pool->copy(c.pin_in + pin_off + o, (const char *)from + o, n);
       const bool last = o + n >= bytes;
-      if (!direct_in) MLPG_HIP_CHECK(hipMemcpyAsync(c.dev + off + o, c.pin_in + off + o, n + (last ? tail : 0), hipMemcpyHostToDevice, c.st));
+      if (!direct_in)
+        MLPG_HIP_CHECK(hipMemcpyAsync(c.dev + dev_off + o, c.pin_in + pin_off + o, n + (last ? tail : 0), hipMemcpyHostToDevice, c.st));
       if (last) break;
       o += n;
     }
@@ -646,23 +714,35 @@ int host_small(int device, int dtype, int out_dtype, int algo, bool backward, co
     (void)hipGetLastError();
     return rc;
   };
-  if (int rc = stage_send(0, first_h, mean_bytes, 0)) return drained(rc);
-  if (len_bytes) memcpy(c.pin_in + o_len, lengths_h, len_bytes);
-  // (variances and lengths are neighbours in the staging buffer: the lengths ride on the variances' last transfer)
-  if (var_bytes) {
-    if (int rc = stage_send(o_var, var_h, var_bytes, len_bytes ? o_len + len_bytes - (o_var + var_bytes) : 0)) return drained(rc);
-  } else if (len_bytes && !direct_in) {
-    if (hipMemcpyAsync(c.dev + o_len, c.pin_in + o_len, len_bytes, hipMemcpyHostToDevice, c.st) != hipSuccess) {
-      set_error("host call: copying the lengths failed: %s", hipGetErrorString(hipGetLastError()));
-      return drained(MLPG_HIP_ERUNTIME);
+  auto send_direct = [&](size_t dev_off, const void *from, size_t bytes) -> int {
+    if (hipMemcpyAsync(c.dev + dev_off, from, bytes, hipMemcpyHostToDevice, c.st) != hipSuccess) {
+      set_error("host call: copying %zu bytes from the caller's memory failed: %s", bytes, hipGetErrorString(hipGetLastError()));
+      return MLPG_HIP_ERUNTIME;
     }
+    return 0;
+  };
+  if (int rc = first_rt ? send_direct(0, first_h, mean_bytes) : stage_send(p_first, 0, first_h, mean_bytes, 0)) return drained(rc);
+  if (len_bytes) memcpy(c.pin_in + p_len, lengths_h, len_bytes);
+  // (staged variances and the lengths are neighbours in both buffers: the lengths ride on the variances' last transfer)
+  bool len_sent = !len_bytes || direct_in;
+  if (var_bytes) {
+    if (var_rt) {
+      if (int rc = send_direct(o_var, var_h, var_bytes)) return drained(rc);
+    } else {
+      if (int rc = stage_send(p_var, o_var, var_h, var_bytes, len_bytes ? o_len + len_bytes - (o_var + var_bytes) : 0)) return drained(rc);
+      len_sent = true;
+    }
+  }
+  if (!len_sent && hipMemcpyAsync(c.dev + o_len, c.pin_in + p_len, len_bytes, hipMemcpyHostToDevice, c.st) != hipSuccess) {
+    set_error("host call: copying the lengths failed: %s", hipGetErrorString(hipGetLastError()));
+    return drained(MLPG_HIP_ERUNTIME);
   }
   Problem p;
   p.mean = backward ? nullptr : src;
   p.var = var_bytes ? src + o_var : nullptr;
   p.grad_out = backward ? src : nullptr;
   p.lengths = len_bytes ? (const int32_t *)(src + o_len) : nullptr;
-  p.out = c.pin_out;  // pinned host memory: written by the kernel over PCIe
+  p.out = out_rt ? c.dev + o_out_dev : c.pin_out;  // pinned host memory: written by the kernel over PCIe
   p.status = (int32_t *)(c.pin_out + o_status);
   p.var_mode = var_mode;
   p.B = B;
@@ -675,15 +755,20 @@ int host_small(int device, int dtype, int out_dtype, int algo, bool backward, co
   p.ld_status = sd;
   const double ts = tr.on ? HostTrace::now() : 0.0;
   int rc = dispatch_solve(c.st, dtype, out_dtype, algo, backward, p, ws, device);
+  if (!rc && out_rt && hipMemcpyAsync(out_h, c.dev + o_out_dev, out_bytes, hipMemcpyDeviceToHost, c.st) != hipSuccess) {
+    set_error("host call: copying %zu bytes into the caller's memory failed: %s", out_bytes, hipGetErrorString(hipGetLastError()));
+    rc = MLPG_HIP_ERUNTIME;
+  }
   if (!rc) rc = small_wait(c);
   if (rc) return drained(rc);
   const double tw = tr.on ? HostTrace::now() : 0.0;
-  pool->copy(out_h, c.pin_out, out_bytes);
+  if (!out_rt) pool->copy(out_h, c.pin_out, out_bytes);
   if (status_h) memcpy(status_h, c.pin_out + o_status, st_bytes);
   if (tr.on)
-    fprintf(stderr, "[mlpg_hip host] short path (%s inputs): %.1f us total = %.1f staging/enqueue + %.1f launch/wait + %.1f copying results\n",
-            direct_in ? "pinned, read by the kernel" : "copied to the device", 1e6 * (HostTrace::now() - tr.t0), 1e6 * (ts - tr.t0), 1e6 * (tw - ts),
-            1e6 * (HostTrace::now() - tw));
+    fprintf(stderr, "[mlpg_hip host] short path (%s inputs%s%s%s): %.1f us total = %.1f staging/enqueue + %.1f launch/wait + %.1f copying results\n",
+            direct_in ? "pinned, read by the kernel" : "copied to the device", first_rt ? ", first array straight from the caller's memory" : "",
+            var_rt ? ", variances straight from the caller's memory" : "", out_rt ? ", result copied straight into the caller's memory" : "",
+            1e6 * (HostTrace::now() - tr.t0), 1e6 * (ts - tr.t0), 1e6 * (tw - ts), 1e6 * (HostTrace::now() - tw));
   return 0;
 }
 

@@ -73,16 +73,76 @@ def test_config2_utterance_takes_the_copied_route_and_matches_the_oracle():
     assert y32.dtype == np.float32 and _rel(y32, O.mlpg(m.astype(np.float32), v.astype(np.float32), W)) <= 2e-6
 
 
+def test_a_buffer_handed_in_again_is_copied_in_place_with_the_same_result():
+    """A config-2 utterance (two arrays of 1.44 MB): staged through the pinned buffer the first time, copied by the runtime straight from
+    the caller's arrays from the second call with the same arrays on -- the same bits either way; an edit of the arrays in between is seen."""
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(41)
+    m = rng.randn(1000, 180)
+    v = rng.rand(1000, 180) + 0.1
+    y1 = G.mlpg(m, v, W)                              # first sight: staged
+    y2 = G.mlpg(m, v, W)                              # seen before: direct
+    y3 = G.mlpg(m.copy(), v.copy(), W)                # other arrays, same numbers
+    assert np.array_equal(y1, y2) and np.array_equal(y1, y3)
+    assert _rel(y1, O.mlpg(m, v, W)) <= 1e-12
+    m[500:] *= 2.0
+    v[:500] *= 0.5
+    y4 = G.mlpg(m, v, W)
+    assert _rel(y4, O.mlpg(m, v, W)) <= 1e-12 and not np.array_equal(y4, y1)
+    g1 = G.mlpg_grad(m, v, W, y4)
+    g2 = G.mlpg_grad(m, v, W, y4)
+    assert np.array_equal(g1, g2)
+
+
 def test_a_config2_batch_does_not_take_the_short_path():
     from nnmnkwii_amd import paramgen as G
     rng = np.random.RandomState(3)
-    M_ = rng.randn(12, 500, 180)                      # 17 MB of means and variances: the chunked path
-    V_ = rng.rand(12, 500, 180) + 0.1
+    M_ = rng.randn(50, 500, 180)                      # 72 MB of means and variances (the limit is 64 MiB): the chunked path
+    V_ = rng.rand(50, 500, 180) + 0.1
     r0 = _routes()
     y = G.mlpg_batch(M_, V_, W)
     assert _routes() == r0
     yo, _, rc = O.mlpg_batch(M_, V_, W)
     assert rc == 0 and _rel(y, yo) <= 1e-12
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("mode", ["frame", "global", "unit"])
+def test_a_batch_of_a_few_utterances_goes_straight_from_and_to_the_callers_arrays(mode, dt):
+    """Arrays of 4 MB and more -- and arrays of 1.2 MB and more that the library has been handed before -- are not staged: the runtime
+    copies them straight from / to the caller's pageable memory (MLPG_HIP_HOST_DIRECT_KB / _ALWAYS_KB).  8 utterances of T = 1000 x 60 dims (23 MB of means and variances in float64, 3.8 MB out), ragged with
+    junk in the padding: one call on the one-stream path, equal to the device entry point bit for bit, the oracle within its bound;
+    the caller's arrays are left untouched."""
+    import torch
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(17)
+    B, T, sd = 8, 1000, 60
+    M_ = rng.randn(B, T, 3 * sd).astype(dt)
+    V_ = (rng.rand(B, T, 3 * sd) + 0.1).astype(dt)
+    lengths = np.array([1000, 999, 3, 0, 517, 1000, 64, 2], dtype=np.int32)
+    for b in range(B):
+        M_[b, lengths[b]:] = 1e30
+    var = {"frame": V_, "global": V_[0, 0].copy(), "unit": None}[mode]
+    M0, V0 = M_.copy(), V_.copy()
+    r0 = _routes()
+    y = G.mlpg_batch(M_, var, W, lengths)
+    assert sum(_routes()) == sum(r0) + 1
+    assert np.array_equal(M_, M0) and np.array_equal(V_, V0)
+    yd, st = _hip.forward(torch.from_numpy(M_).cuda(), None if var is None else torch.from_numpy(var).cuda(), W, torch.from_numpy(lengths).cuda())
+    assert int(st.abs().max()) == 0 and np.array_equal(y, yd.cpu().numpy())
+    yo, _, rc = O.mlpg_batch(M_, var if var is not None else np.ones(3 * sd, dtype=dt), W, lengths)
+    assert rc == 0
+    for b in range(B):
+        if lengths[b]:
+            assert _rel(y[b, :lengths[b]].astype(np.float64), yo[b, :lengths[b]]) <= (1e-12 if dt == np.float64 else 2e-6)
+        assert not y[b, lengths[b]:].any()
+    # the backward of the same batch: the gradient (B, T, D) goes back the same way
+    go = rng.randn(B, T, sd).astype(dt)
+    g, stb = _hip.backward_host(var, go, W, 3 * sd, out_dtype=np.float32, lengths=lengths)
+    gd, _ = _hip.backward(None if var is None else torch.from_numpy(var).cuda(), torch.from_numpy(go).cuda(), W, 3 * sd,
+                          lengths=torch.from_numpy(lengths).cuda(), out_dtype=torch.float32)
+    assert not stb.any() and np.array_equal(g, gd.cpu().numpy())
 
 
 @pytest.mark.parametrize("T", [1, 2, 3, 4, 17, 64, 100, 333])
@@ -285,36 +345,45 @@ def test_mlpg_grad_short_path_against_the_device_entry_point(wname, T, sd):
 
 
 def test_mlpg_grad_batches_are_cut_into_pieces_of_whole_utterances():
-    """mlpg_hip_backward_host on a batch larger than the short path's limit: pieces of whole utterances, one after the other; lengths
-    and the status rows follow their utterances; global and unit variances."""
+    """mlpg_hip_backward_host on a batch larger than the short path's limit (64 MiB of input): pieces of whole utterances, one after
+    the other; lengths and the status rows follow their utterances; global and unit variances."""
     import torch
     from nnmnkwii_amd import _hip
     rng = np.random.RandomState(5)
-    B, T, sd = 9, 700, 60
-    V_ = rng.rand(B, T, 3 * sd) + 0.1                   # 9 x 1.0 MB of variances + 0.34 MB of grad_out each: pieces of 4 utterances
+    B, T, sd = 60, 700, 60
+    V_ = rng.rand(B, T, 3 * sd) + 0.1                   # 60 x (1.0 MB of variances + 0.34 MB of grad_out): 49 utterances fit the limit
     go = rng.randn(B, T, sd)
-    lengths = np.array([700, 1, 350, 0, 699, 700, 2, 3, 500], dtype=np.int32)
+    lengths = rng.randint(0, T + 1, size=B).astype(np.int32)
+    lengths[[0, 1, 2, 3, 48, 49, 59]] = [700, 1, 350, 0, 699, 700, 2]
+    per = max(1, min(B, (64 << 20) // (T * sd * 8 + T * 3 * sd * 8)))
     c0, d0 = _routes()
     g, st = _hip.backward_host(V_, go, W, 3 * sd, out_dtype=np.float64, lengths=lengths)
     c1, d1 = _routes()
-    assert (c1 - c0) + (d1 - d0) == 3 and not st.any()
+    assert per == 49 and (c1 - c0) + (d1 - d0) == 2 and not st.any()
+    # piece by piece the same bits as mlpg_hip_backward on device copies of that piece (AUTO picks its kernel by the batch's size, so
+    # the whole batch in one device call may differ in the last bit), the whole batch within rounding
+    for b0 in range(0, B, per):
+        sl = slice(b0, min(B, b0 + per))
+        gp, _ = _hip.backward(torch.from_numpy(V_[sl]).cuda(), torch.from_numpy(go[sl]).cuda(), W, 3 * sd,
+                              lengths=torch.from_numpy(lengths[sl]).cuda(), out_dtype=torch.float64)
+        assert np.array_equal(g[sl], gp.cpu().numpy())
     gd, _ = _hip.backward(torch.from_numpy(V_).cuda(), torch.from_numpy(go).cuda(), W, 3 * sd, lengths=torch.from_numpy(lengths).cuda(),
                           out_dtype=torch.float64)
-    assert np.array_equal(g, gd.cpu().numpy())
+    assert np.abs(g - gd.cpu().numpy()).max() <= 1e-12 * np.abs(g).max()
     for b in range(B):
         assert not g[b, lengths[b]:].any()
+    del gd, gp
     for var in (V_[0, 0].copy(), None):
         g, st = _hip.backward_host(var, go, W, 3 * sd, out_dtype=np.float32)
         gd, _ = _hip.backward(None if var is None else torch.from_numpy(var).cuda(), torch.from_numpy(go).cuda(), W, 3 * sd, out_dtype=torch.float32)
         assert np.array_equal(g, gd.cpu().numpy()) and not st.any()
-    # a failing pivot in utterance 6 of 9: the reference's exception, with its k
-    V_bad = V_.copy()
-    V_bad[6, 41, 7] = -1e-9
-    g, st = _hip.backward_host(V_bad, go, W, 3 * sd)
-    assert st[6, 7] == 42 and not np.delete(st, 6, axis=0).any()
+    # a failing pivot in utterance 55 (the second piece): the status row of that utterance, the reference's exception with its k
+    V_[55, 41, 7] = -1e-9
+    g, st = _hip.backward_host(V_, go, W, 3 * sd)
+    assert st[55, 7] == 42 and not np.delete(st, 55, axis=0).any()
     from nnmnkwii_amd import paramgen as G
     with pytest.raises(np.linalg.LinAlgError, match="42-th leading minor not positive definite"):
-        G.mlpg_grad(np.zeros((T, 3 * sd)), V_bad[6], W, go[6])
+        G.mlpg_grad(np.zeros((T, 3 * sd)), V_[55], W, go[55])
 
 
 def test_autograd_mlpg_on_cpu_tensors_runs_both_passes_on_the_short_path():

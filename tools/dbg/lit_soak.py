@@ -1,5 +1,5 @@
 """Random soak of the short host path of mlpg_hip_forward_host (one small numpy -> numpy call: paramgen.mlpg / mlpg_batch with at
-most 6 MB of input) against the C oracle: random T (1 .. 2500), static dims (1 .. 70), batch sizes (1 .. 6), window sets (static only,
+most 6 MB of input, now and then 24 MB: the arrays the runtime copies directly) against the C oracle: random T (1 .. 2500), static dims (1 .. 70), batch sizes (1 .. 6), window sets (static only,
 two and three windows, the reference's 5-tap windows, asymmetric, scaled dynamic windows), per-frame / global / unit variances of
 log-normal spread 0 / 1 / 3, float64 / float32, ragged lengths with junk in the padding, occasional negative variances (the reference's
 LinAlgError with its k), non-contiguous inputs.  Every AUTO route is reached through pinned-memory outputs (and, below 48 KB, inputs).
@@ -40,7 +40,10 @@ while time.time() < t_end:
     B = 1 if rng.rand() < 0.6 else int(rng.randint(2, 7))
     T = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 333, 1000, 2049])) if rng.rand() < 0.4 else int(rng.randint(1, 2500))
     sd = int(rng.choice([1, 2, 5, 25, 60, 64, 70])) if rng.rand() < 0.6 else int(rng.randint(1, 71))
-    while B * T * nw * sd * np.dtype(dt).itemsize * 2 > (6 << 20) and T > 1:
+    cap = (24 << 20) if rng.rand() < 0.15 else (6 << 20)      # (arrays of 1.2 MB and more go straight from / to the caller's memory)
+    if cap > (6 << 20) and B > 1:
+        T = int(rng.randint(1500, 4000))
+    while B * T * nw * sd * np.dtype(dt).itemsize * 2 > cap and T > 1:
         T //= 2
     spread = [0.0, 1.0, 3.0][rng.randint(3)]
     M = rng.randn(B, T, nw * sd).astype(dt)
