@@ -885,6 +885,9 @@ __attribute__((visibility("default"))) int mlpg_hip_forward_host_multi(const int
   const size_t o_mean = 0, o_var = up256((size_t)cb * utt_in), o_out = o_var + (fvar ? up256((size_t)cb * utt_in) : up256((size_t)D * esz)),
                o_status = o_out + up256((size_t)cb * utt_out), o_len = o_status + up256((size_t)cb * sd * sizeof(int32_t)),
                dev_bytes = o_len + up256((size_t)cb * sizeof(int32_t));
+  // (Copying a chunk's pageable inputs straight from the caller's memory, as host_small does, instead of staging them by the copy
+  // threads was measured in round 6, alternating inside one process on the whole config-2 batch: 25-28 ms either way,
+  // profiles/r06_chunk_direct_ab.txt.)
   if (int rc = ensure_all(dl, in_bytes, out_bytes, dev_bytes)) return rc;
   Prefault prefault;
   if (!out_pinned) prefault.start(out_h, (size_t)B * utt_out);
