@@ -432,8 +432,8 @@ int small_ensure(SmallCtx &c, size_t in_bytes, size_t out_bytes, size_t dev_byte
 }
 
 // Waits for everything enqueued on c.st: a sequence number written to pinned memory behind it, polled.
-int small_wait(SmallCtx &c) {
-  if (!small_wait_by_flag()) {
+int small_wait(SmallCtx &c, bool by_sync = false) {
+  if (by_sync || !small_wait_by_flag()) {
     MLPG_HIP_CHECK(hipStreamSynchronize(c.st));
     return 0;
   }
@@ -533,6 +533,36 @@ int run_chunks(const DevList &dl, long nchunks, Submit submit, Collect collect) 
   if (hipGetDevice(&prev) != hipSuccess) {
     (void)hipGetLastError();
     prev = -1;
+  }
+  if (nchunks == 1) {  // one chunk: nothing to overlap, so no collector thread (creating and joining one costs 30-50 us of a small call)
+    int rc = 0;
+    if (hipSetDevice(dl.dev[0]) != hipSuccess) {
+      set_error("hipSetDevice(%d) failed: %s", dl.dev[0], hipGetErrorString(hipGetLastError()));
+      rc = MLPG_HIP_ERUNTIME;
+    }
+    const double ts = tr.on ? HostTrace::now() : 0.0;
+    if (!rc) {
+      g_host_chunks[dl.dev[0]].fetch_add(1);
+      rc = submit(0, 0, 0L);
+    }
+    if (tr.on) tr.t_submit += HostTrace::now() - ts;
+    const double tw = tr.on ? HostTrace::now() : 0.0;
+    if (!rc && hipStreamSynchronize(dl.ctx[0]->st[0]) != hipSuccess) {
+      set_error("host call: waiting for the chunk on device %d failed: %s", dl.dev[0], hipGetErrorString(hipGetLastError()));
+      rc = MLPG_HIP_ERUNTIME;
+    }
+    if (tr.on) tr.t_wait += HostTrace::now() - tw;
+    const double tc = tr.on ? HostTrace::now() : 0.0;
+    if (!rc) rc = collect(0, 0, 0L);
+    if (tr.on) tr.t_collect = HostTrace::now() - tc;
+    if (rc) {  // nothing is left in flight
+      for (int k = 0; k < 2; ++k)
+        if (dl.ctx[0]->st[k]) (void)hipStreamSynchronize(dl.ctx[0]->st[k]);
+      (void)hipGetLastError();
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    tr.report(nchunks, dl.n);
+    return rc;
   }
   // The collector thread waits for each chunk's event (in chunk order) and moves its staged results into the caller's
   // arrays while this thread stages the next chunks: with pageable inputs the calling thread is the critical path.
@@ -759,7 +789,8 @@ int host_small(int device, int dtype, int out_dtype, int algo, bool backward, co
     set_error("host call: copying %zu bytes into the caller's memory failed: %s", out_bytes, hipGetErrorString(hipGetLastError()));
     rc = MLPG_HIP_ERUNTIME;
   }
-  if (!rc) rc = small_wait(c);
+  // (a copy into the caller's pageable memory is the runtime's business down to its last host-side step: wait for it the runtime's way)
+  if (!rc) rc = small_wait(c, out_rt);
   if (rc) return drained(rc);
   const double tw = tr.on ? HostTrace::now() : 0.0;
   if (!out_rt) pool->copy(out_h, c.pin_out, out_bytes);
@@ -1065,12 +1096,12 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw_host_multi(const int
   const size_t so_pj = up256((size_t)cb * pl * 4), so_pl = 2 * so_pj, so_lx = so_pl + up256((size_t)cb * 4),
                so_ly = so_lx + up256((size_t)cb * 4), so_c = so_ly + up256((size_t)cb * 4),
                out_bytes = so_c + (size_t)cb * 8;
-  // device: X | Y | X64 | Y64 (float32 input only) | lenx | leny | path_i | path_j | path_len | cost
+  // device: X | Y | X64 | Y64 (float32 input only) | the results, laid out like the pinned block (a full chunk's results go back
+  // in ONE copy: six small copies cost 8 us each behind a kernel that takes 300 us for one pair)
   const size_t o_x = 0, o_y = up256((size_t)cb * px * esz), o_x64 = o_y + up256((size_t)cb * py * esz),
                o_y64 = o_x64 + (dtype == MLPG_HIP_F32 ? up256((size_t)cb * px * 8) : 0),
-               o_lx = o_y64 + (dtype == MLPG_HIP_F32 ? up256((size_t)cb * py * 8) : 0), o_ly = o_lx + up256((size_t)cb * 4),
-               o_pi = o_ly + up256((size_t)cb * 4), o_pj = o_pi + so_pj, o_pl = o_pj + so_pj,
-               o_c = o_pl + up256((size_t)cb * 4), dev_bytes = o_c + up256((size_t)cb * 8);
+               o_res = o_y64 + (dtype == MLPG_HIP_F32 ? up256((size_t)cb * py * 8) : 0), o_pi = o_res, o_pj = o_res + so_pj,
+               o_pl = o_res + so_pl, o_lx = o_res + so_lx, o_ly = o_res + so_ly, o_c = o_res + so_c, dev_bytes = o_res + up256(out_bytes);
   if (int rc = ensure_all(dl, in_bytes, out_bytes, dev_bytes)) return rc;
   const bool x_pinned = is_pinned(X_h), y_pinned = is_pinned(Y_h);
 
@@ -1111,6 +1142,10 @@ __attribute__((visibility("default"))) int mlpg_hip_fastdtw_host_multi(const int
                                 (int32_t *)(d + o_pi), (int32_t *)(d + o_pj), (int32_t *)(d + o_pl), (double *)(d + o_c)))
       return rc;
     char *o = (char *)c.pin_out[slot];
+    if (nb == cb) {
+      MLPG_HIP_CHECK(hipMemcpyAsync(o, d + o_res, out_bytes, hipMemcpyDeviceToHost, st));
+      return 0;
+    }
     MLPG_HIP_CHECK(hipMemcpyAsync(o, d + o_pi, (size_t)nb * pl * 4, hipMemcpyDeviceToHost, st));
     MLPG_HIP_CHECK(hipMemcpyAsync(o + so_pj, d + o_pj, (size_t)nb * pl * 4, hipMemcpyDeviceToHost, st));
     MLPG_HIP_CHECK(hipMemcpyAsync(o + so_pl, d + o_pl, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
