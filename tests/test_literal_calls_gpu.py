@@ -94,6 +94,36 @@ def test_a_buffer_handed_in_again_is_copied_in_place_with_the_same_result():
     assert np.array_equal(g1, g2)
 
 
+def test_a_preallocated_result_array_is_filled_in_place_from_the_second_call_on():
+    """The C entry point with the caller's own result array (1.9 MB: between the two direct-copy thresholds): staged through pinned
+    memory at first sight, written by the runtime's device -> host copy straight into the array when it is handed in again -- same bits,
+    and the bytes around the array are left alone."""
+    import ctypes
+    from nnmnkwii_amd import _hip
+    L = _hip.lib()
+    rng = np.random.RandomState(43)
+    B, T, sd = 4, 1000, 60
+    M_ = rng.randn(B, T, 3 * sd)
+    V_ = rng.rand(B, T, 3 * sd) + 0.1
+    pw = _hip.cached_windows(W)
+    pl, pu, pc = pw.ptrs()
+    guard = 4096
+    buf = np.full(B * T * sd + 2 * guard, 7.25)
+    out = buf[guard:guard + B * T * sd].reshape(B, T, sd)
+    status = np.zeros((B, sd), dtype=np.int32)
+    results = []
+    for k in range(3):
+        out[...] = -1.0
+        rc = L.mlpg_hip_forward_host(0, _hip.F64, 0, M_.ctypes.data, V_.ctypes.data, _hip.VAR_FRAME, None, B, T, 3 * sd, 3, pl, pu, pc,
+                                     out.ctypes.data, status.ctypes.data)
+        assert rc == 0 and not status.any()
+        assert (buf[:guard] == 7.25).all() and (buf[-guard:] == 7.25).all()
+        results.append(out.copy())
+    assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
+    yo, _, rc = O.mlpg_batch(M_, V_, W)
+    assert rc == 0 and _rel(results[0], yo) <= 1e-12
+
+
 def test_a_config2_batch_does_not_take_the_short_path():
     from nnmnkwii_amd import paramgen as G
     rng = np.random.RandomState(3)

@@ -240,6 +240,18 @@ def literal_calls(emit, quick=False, long_reference_backward=True):
         emit(path=name, us_forward=us_f, us_forward_backward=us_fb, us_paramgen_mlpg_grad=us_g, cpu_us_forward=rus_f, cpu_us_backward_mlpg_grad=rus_b,
              cpu_kind=ref_kind + " inside a torch.autograd.Function, as the reference's node calls it",
              grad_abs_err_vs_cpu=gerr, T=T, D=3 * sd)
+    # paramgen.unit_variance_mlpg_matrix(windows, T) (a9: _mlpg.py:297-373; once per minibatch length in the reference's training loop)
+    if not quick:
+        for T in (100, 500):
+            us_m, us_m_min = _wall_us(lambda: G.unit_variance_mlpg_matrix(WINDOWS, T), 10, warm=2)
+            rus_m = merr = None
+            if Gref is not None:
+                t0 = time.perf_counter()
+                Rr = Gref.unit_variance_mlpg_matrix(WINDOWS, T)
+                rus_m = (time.perf_counter() - t0) * 1e6
+                merr = float(np.abs(G.unit_variance_mlpg_matrix(WINDOWS, T) - Rr).max())
+            emit(path="lit-unit_variance_mlpg_matrix-T%d" % T, us_per_call=us_m, us_per_call_min=us_m_min, cpu_us_per_call=rus_m, cpu_kind=ref_kind,
+                 abs_err_vs_cpu=merr, speedup_vs_cpu=(rus_m / us_m if rus_m else None), T=T)
     # DTWAligner.transform on ONE pair (alignment.py:41-76 is a per-pair loop)
     a, b = 812, 777
     X = np.zeros((1, 900, 25))
