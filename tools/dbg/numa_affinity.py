@@ -67,6 +67,30 @@ def measure(tag):
         G.mlpg_batch(M_, V_, W)
         ts.append(time.perf_counter() - t0)
     res.append("batch of 32 (92 MB): %.2f ms (min %.2f)" % (np.median(ts) * 1e3, min(ts) * 1e3))
+    # config 3's eager training loop (host-bound: a dozen launches per step), wall clock per step
+    import torch
+    from nnmnkwii_amd import autograd as AF
+    dev = torch.device("cuda:0")
+    R = torch.from_numpy(G.unit_variance_mlpg_matrix(W, 500)).to(dev)
+    means = torch.rand(64, 500, 180, device=dev, requires_grad=True)
+    y = torch.rand(64, 500, 60, device=dev)
+    crit = torch.nn.MSELoss()
+
+    def step():
+        means.grad = None
+        crit(AF.unit_variance_mlpg(R, means), y).backward()
+
+    for _ in range(100):
+        step()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(1000):
+            step()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / 1000 * 1e6)
+    res.append("config-3 eager loop: %.1f us per step" % best)
     print("%-34s %s" % (tag, "; ".join(res)), flush=True)
 
 
