@@ -376,8 +376,11 @@ def current_device_index(device=None):
         if idx is not None:
             return int(idx)
     t = sys.modules.get("torch")
-    if t is not None and t.cuda.is_initialized():
-        return int(t.cuda.current_device())
+    # (another thread may be in the middle of `import torch`: sys.modules then holds a module without its attributes yet)
+    cuda = getattr(t, "cuda", None)
+    ready = getattr(cuda, "is_initialized", None)
+    if ready is not None and ready():
+        return int(cuda.current_device())
     return 0
 
 

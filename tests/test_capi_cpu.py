@@ -168,6 +168,17 @@ def test_cached_windows_follow_the_list():
         _hip.cached_windows([(1, 1, np.array([1.0]))])
 
 
+def test_current_device_index_survives_a_half_imported_torch(monkeypatch):
+    """A numpy entry point called while another thread is inside `import torch` sees a module object without attributes in
+    sys.modules (found by tools/dbg/lit_threads_soak.py): the device index falls back to 0 instead of raising."""
+    import sys
+    import types
+    from nnmnkwii_amd import _hip
+    monkeypatch.setitem(sys.modules, "torch", types.ModuleType("torch"))
+    assert _hip.current_device_index() == 0
+    assert _hip.current_device_index("cuda:3") == 3 and _hip.current_device_index(2) == 2
+
+
 def test_pack_windows():
     from nnmnkwii_amd import _hip
     wl, wu, wc = _hip.pack_windows(WINDOW_SETS["wide3"])
