@@ -124,6 +124,33 @@ def test_a_preallocated_result_array_is_filled_in_place_from_the_second_call_on(
     assert rc == 0 and _rel(results[0], yo) <= 1e-12
 
 
+def test_memmapped_inputs_and_a_file_backed_result(tmp_path):
+    """Arrays that are not ordinary anonymous memory at the sizes the runtime copies directly (>= 4 MB): read-only np.memmap inputs
+    (np.load(..., mmap_mode="r")) and a writable file-backed result array handed to the C entry point -- the same bits as on copies."""
+    from nnmnkwii_amd import _hip
+    from nnmnkwii_amd import paramgen as G
+    rng = np.random.RandomState(47)
+    B, T, sd = 6, 1000, 60
+    M_ = rng.randn(B, T, 3 * sd)
+    V_ = rng.rand(B, T, 3 * sd) + 0.1
+    want = G.mlpg_batch(M_.copy(), V_.copy(), W)
+    np.save(tmp_path / "m.npy", M_)
+    np.save(tmp_path / "v.npy", V_)
+    Mr = np.load(tmp_path / "m.npy", mmap_mode="r")
+    Vr = np.load(tmp_path / "v.npy", mmap_mode="r")
+    assert not Mr.flags.writeable
+    for _ in range(2):
+        assert np.array_equal(G.mlpg_batch(Mr, Vr, W), want)
+    out = np.lib.format.open_memmap(tmp_path / "y.npy", mode="w+", dtype=np.float64, shape=(B, T, sd))
+    st = np.zeros((B, sd), dtype=np.int32)
+    pl, pu, pc = _hip.cached_windows(W).ptrs()
+    for _ in range(2):
+        out[...] = 0
+        rc = _hip.lib().mlpg_hip_forward_host(0, _hip.F64, 0, Mr.ctypes.data, Vr.ctypes.data, _hip.VAR_FRAME, None, B, T, 3 * sd, 3, pl, pu, pc,
+                                              out.ctypes.data, st.ctypes.data)
+        assert rc == 0 and np.array_equal(np.asarray(out), want)
+
+
 def test_a_config2_batch_does_not_take_the_short_path():
     from nnmnkwii_amd import paramgen as G
     rng = np.random.RandomState(3)
