@@ -113,6 +113,10 @@ int launch_const_multi(hipStream_t s, int dtype, const Problem &p, const WinSet 
 bool chunk_supported(const Problem &p, const WinSet &w);
 bool chunk_preferred(const Problem &p, const WinSet &w, bool backward);
 int launch_chunk(hipStream_t s, int dtype, int out_dtype, bool backward, const Problem &p, const WinSet &w, int device);
+int launch_chunk_fwd_f64(hipStream_t s, const Problem &p, const WinSet &w, int device);
+int launch_chunk_fwd_f32(hipStream_t s, const Problem &p, const WinSet &w, int device);
+int launch_chunk_bwd_f64(hipStream_t s, const Problem &p, const WinSet &w, int device);
+int launch_chunk_bwd_f32(hipStream_t s, const Problem &p, const WinSet &w, int device);
 // unit variances on float32 tensors as a FIR filter; launch_fir returns kFirNotApplicable when the window set's inverse does not decay
 // fast enough (or its tap table cannot be built now: stream capture)
 constexpr int kFirNotApplicable = -2000;

@@ -1,0 +1,7 @@
+// chunked MLPG kernels (window extents up to 2): forward, float
+#include "mlpg_chunk_impl.h"
+namespace mlpg {
+int launch_chunk_fwd_f32(hipStream_t st, const Problem &p, const WinSet &ws, int device) {
+  return chunk::launch_t<float, float, false>(st, p, ws, device);
+}
+}  // namespace mlpg

@@ -12,7 +12,7 @@ objs=""
 for src in "$@"; do
   o=/tmp/variant_$tag/${src%.hip}.o
   extra="-ffp-contract=fast"
-  case $src in mlpg_fir.hip|mlpg_chunk.hip) extra="-ffp-contract=fast -mllvm -pragma-unroll-threshold=200000 -mllvm -unroll-threshold=200000";; dtw*|modspec*) extra="-ffp-contract=off";; esac
+  case $src in mlpg_fir.hip|mlpg_chunk_*.hip) extra="-ffp-contract=fast -mllvm -pragma-unroll-threshold=200000 -mllvm -unroll-threshold=200000";; dtw*|modspec*) extra="-ffp-contract=off";; esac
   /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function $extra $flags -c $src -o $o &
   skip="$skip ${src%.hip}.o"
   objs="$objs $o"
