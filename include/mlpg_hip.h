@@ -173,6 +173,8 @@ int mlpg_hip_forward(int device, void *stream, int dtype, int algo,
  * (MLPG_HIP_HOST_DIRECT_KB) that the library has been handed before (same address and size, one of its last 16), and any array of
  * at least 4 MB (MLPG_HIP_HOST_DIRECT_ALWAYS_KB), is not staged: the runtime copies it straight from -- the result: to -- the
  * caller's pageable memory at the pinned rate (mapping pages the device has never seen costs more than staging them, up to a few MB).
+ * While the device works the calling thread touches the result array's pages (a store of 0 per page: the array must not overlap
+ * the inputs), so that a fresh array's page faults are not taken one by one in the copy out (MLPG_HIP_HOST_PREFAULT=0: off).
  */
 int mlpg_hip_forward_host(int device, int dtype, int algo, const void *mean_h,
                           const void *var_h, int var_mode,
