@@ -198,7 +198,12 @@ def literal_calls(emit, quick=False, long_reference_backward=True):
          ms_one_mlpg_batch_call_incl_stacking=batch_s * 1e3,
          note="[paramgen.mlpg(m, v, windows) for m, v in utterances]: the reference's own loop shape (util/__init__.py:56-66), numpy in, numpy out")
     del utts, ys, yr, yb
-    # autograd.mlpg on CPU tensors (the reference's tensors are CPU tensors: autograd/_impl/mlpg.py:50-67), forward + backward
+    # autograd.mlpg on CPU tensors (the reference's tensors are CPU tensors: autograd/_impl/mlpg.py:50-67), forward + backward.
+    # One torch CPU thread, as the reference's CI pins it (OMP_NUM_THREADS=1, ci.yaml:16-17): with the default pool of one thread per
+    # core (128 here) torch's own small CPU ops take milliseconds (a 60 k-element sum 27 us -> 2 us, an autograd step on (1000, 180) 2 ms -> 63 us,
+    # tools/dbg/torch_cpu_threads.py) and its idle workers spin under the calls that follow; both sides of the comparison run under the same setting.
+    torch_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
     for name, T, sd, nrep in (("lit-c1-autograd.mlpg-cpu-tensor-T100-sd2", 100, 2, n_small), ("lit-c2utt-autograd.mlpg-cpu-tensor-T1000-sd60", 1000, 60, 30)):
         torch.manual_seed(1234)
         mt = torch.rand(T, 3 * sd, requires_grad=True)
@@ -239,7 +244,8 @@ def literal_calls(emit, quick=False, long_reference_backward=True):
             gerr = None
         emit(path=name, us_forward=us_f, us_forward_backward=us_fb, us_paramgen_mlpg_grad=us_g, cpu_us_forward=rus_f, cpu_us_backward_mlpg_grad=rus_b,
              cpu_kind=ref_kind + " inside a torch.autograd.Function, as the reference's node calls it",
-             grad_abs_err_vs_cpu=gerr, T=T, D=3 * sd)
+             grad_abs_err_vs_cpu=gerr, T=T, D=3 * sd, torch_cpu_threads=1)
+    torch.set_num_threads(torch_threads)
     # paramgen.unit_variance_mlpg_matrix(windows, T) (a9: _mlpg.py:297-373; once per minibatch length in the reference's training loop)
     if not quick:
         for T in (100, 500):
