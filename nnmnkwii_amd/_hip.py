@@ -795,9 +795,10 @@ def fastdtw_host(X, Y, radius=1, dist_kind=DIST_L2, dist_scale=1.0, lenx=None, l
     all-zero frames are trimmed on the device (eps as trim_zeros_frames).  Returns numpy
     (path_i, path_j (N, Tx+Ty) int32, path_len (N,), cost (N,), lenx, leny)."""
     L = lib()
-    devs = device_list(device)
-    X = np.ascontiguousarray(X)
-    Y = np.ascontiguousarray(Y)
+    if not X.flags.c_contiguous:
+        X = np.ascontiguousarray(X)
+    if not Y.flags.c_contiguous:
+        Y = np.ascontiguousarray(Y)
     # one dtype for the C entry point; mixed or non-float inputs are WIDENED to float64 (each array from its own
     # dtype, as the device route and the reference's fastdtw do), never narrowed
     if X.dtype != Y.dtype or X.dtype not in (np.float32, np.float64):
@@ -806,20 +807,28 @@ def fastdtw_host(X, Y, radius=1, dist_kind=DIST_L2, dist_scale=1.0, lenx=None, l
     assert X.ndim == 3 and Y.ndim == 3 and X.shape[0] == Y.shape[0] and X.shape[2] == Y.shape[2]
     N, Tx, D = X.shape
     Ty = Y.shape[1]
-    path_i = np.zeros((N, Tx + Ty), dtype=np.int32)
-    path_j = np.zeros((N, Tx + Ty), dtype=np.int32)
-    path_len = np.zeros((N,), dtype=np.int32)
+    # (the library fills every slot: the path's entries, zeros behind them -- nothing to clear here; addresses as ints: numpy's
+    # `.ctypes.data_as` costs microseconds per argument, and DTWAligner.transform on one pair is a 0.3 ms call)
+    path_i = np.empty((N, Tx + Ty), dtype=np.int32)
+    path_j = np.empty((N, Tx + Ty), dtype=np.int32)
+    small = np.zeros((3, N), dtype=np.int32)           # path_len, lenx, leny
+    path_len, lx_out, ly_out = small[0], small[1], small[2]
     cost = np.zeros((N,), dtype=np.float64)
-    lx_out = np.zeros((N,), dtype=np.int32)
-    ly_out = np.zeros((N,), dtype=np.int32)
+    plx = ply = None
     if lenx is not None:
         lenx = np.ascontiguousarray(lenx, dtype=np.int32)
         leny = np.ascontiguousarray(leny, dtype=np.int32)
-    rc = L.mlpg_hip_fastdtw_host_multi(_np(devs) if len(devs) else None, len(devs), F32 if X.dtype == np.float32 else F64,
-                                       _np(X), _np(Y), None if lenx is None else _np(lenx), None if leny is None else _np(leny),
-                                       N, Tx, Ty, D, int(radius), int(dist_kind), float(dist_scale), int(tie_rule), float(eps),
-                                       _np(path_i), _np(path_j), _np(path_len), _np(cost), _np(lx_out), _np(ly_out))
-    _check(rc, "mlpg_hip_fastdtw_host_multi")
+        plx, ply = lenx.ctypes.data, leny.ctypes.data
+    dt = F32 if X.dtype == np.float32 else F64
+    tail = (N, Tx, Ty, D, int(radius), int(dist_kind), float(dist_scale), int(tie_rule), float(eps),
+            path_i.ctypes.data, path_j.ctypes.data, path_len.ctypes.data, cost.ctypes.data, lx_out.ctypes.data, ly_out.ctypes.data)
+    if isinstance(device, (list, tuple, np.ndarray)) or (isinstance(device, str) and device == "all"):
+        devs = device_list(device)
+        rc = L.mlpg_hip_fastdtw_host_multi(_np(devs) if len(devs) else None, len(devs), dt, X.ctypes.data, Y.ctypes.data, plx, ply, *tail)
+    else:
+        rc = L.mlpg_hip_fastdtw_host(current_device_index(device), dt, X.ctypes.data, Y.ctypes.data, plx, ply, *tail)
+    if rc != 0:
+        _check(rc, "mlpg_hip_fastdtw_host")
     return path_i, path_j, path_len, cost, lx_out, ly_out
 
 

@@ -116,6 +116,9 @@ class DTWAligner(object):
     # download the aligned arrays: 4-6 ms for 128 config-4 pairs); larger ones through the host-pointer entry point
     # (chunked, transfers overlapped with the kernels) with the aligned arrays assembled on the host.
     _HOST_ENTRY_BYTES = 64 << 20
+    # ... and a call on very few pairs (the reference's literal per-pair use): one C call and row copies on the host instead of two
+    # uploads, five launches and eight downloads through the framework (one pair: 0.50 -> 0.39 ms, profiles/r06_notes.md section 17)
+    _HOST_ENTRY_PAIRS = 2
 
     def _paths(self, X, Y):
         """Trim + fastdtw of every pair.  Returns numpy (path_i, path_j, path_len, cost, lenx, leny) and a gather
@@ -134,7 +137,7 @@ class DTWAligner(object):
             return self._paths_callable(X, Y, tie, dev)
         dist_kind, dist_scale = resolved
         devices = getattr(self, "devices", None)
-        if devices is not None or X.nbytes + Y.nbytes >= self._HOST_ENTRY_BYTES:
+        if devices is not None or X.nbytes + Y.nbytes >= self._HOST_ENTRY_BYTES or X.shape[0] <= self._HOST_ENTRY_PAIRS:
             out = _hip.fastdtw_host(X, Y, self.radius, dist_kind, dist_scale, tie_rule=tie,
                                     device=dev.index if devices is None else devices)   # alignment.py:46-50
             return out + ((lambda is_x, path, plen, T_out, dtype: _gather(X if is_x else Y, path, plen, T_out, dtype)),)
